@@ -1,0 +1,185 @@
+"""ClothBatch: E independent cloths resident on one MI355X, stepped by libclothhip.
+
+This is the batched counterpart of the reference's `Cloth` + `Gripper` pair (gym_cloth/physics/cloth.pyx:21,
+gripper.pyx:8); the single-cloth façade with the reference's attribute names lives in physics.py.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import F32, F64, SCHED_DTYPE, check
+
+
+def make_schedules(n, **fields):
+    """A zeroed ClothSchedule[n] numpy record array with `fields` broadcast in."""
+    s = np.zeros(n, dtype=SCHED_DTYPE)
+    for k, v in fields.items():
+        s[k] = v
+    return s
+
+
+def schedule_bounds(iters_up, iters_up_rest, iters_pull, iters_grip_rest, iters_rest):
+    """Integer phase boundaries of ClothEnv.step (cloth_env.py:472-475) / _pull (:352-367).
+
+    The reference compares an int `i` with cumulative sums that may be floats (tier 3 draws a float
+    iters_up, cloth_env.py:960); `i < b` for integer i is `i < ceil(b)`, so the ceilings are exact.
+    The sums are formed left to right exactly as the reference writes them.
+    """
+    b1 = iters_up
+    b2 = iters_up + iters_up_rest
+    b3 = iters_up + iters_up_rest + iters_pull
+    b4 = iters_up + iters_up_rest + iters_pull + iters_grip_rest
+    b5 = iters_up + iters_up_rest + iters_pull + iters_grip_rest + iters_rest
+    return tuple(int(np.ceil(b)) for b in (b1, b2, b3, b4, b5))
+
+
+class ClothBatch(object):
+    def __init__(self, cfg, n_envs=1, device=0, precision="f32", gravity=-9.8, minimum_z=0.0):
+        self._L = _lib.load()
+        self.cfg = cfg
+        self.params = _lib.params_from_cfg(cfg, gravity=gravity, minimum_z=minimum_z)
+        self.precision = {"f64": F64, "f32": F32, F64: F64, F32: F32}[precision]
+        h = C.c_void_p()
+        check(self._L.clothhip_create(C.byref(self.params), int(n_envs), int(device), self.precision, C.byref(h)))
+        self._h = h
+        self.E = int(n_envs)
+        self.P = self._L.clothhip_num_points(h)
+        self.S = self._L.clothhip_num_springs(h)
+        self.N = self.params.n_side
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.clothhip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    # ---- construction helpers (host, double) ---------------------------------------------------------
+    def init_grid(self, tier=1, init_side=False, rand_draws=None):
+        """(pos[P,3], rest[S]) of a freshly constructed Cloth (cloth.pyx:92-146, :411-417)."""
+        pos = np.empty((self.P, 3)); rest = np.empty(self.S)
+        rd = None if rand_draws is None else np.ascontiguousarray(rand_draws, dtype=np.float64)
+        check(self._L.clothhip_init_grid(C.byref(self.params), int(tier), int(bool(init_side)),
+                                         _lib.dp(rd), _lib.dp(pos), _lib.dp(rest)))
+        return pos, rest
+
+    def topology(self):
+        a = np.empty(self.S, dtype=np.int32); b = np.empty(self.S, dtype=np.int32)
+        t = np.empty(self.S, dtype=np.uint8)
+        check(self._L.clothhip_spring_topology(C.byref(self.params), _lib.i32p(a), _lib.i32p(b), _lib.u8p(t)))
+        return a, b, t
+
+    # ---- state -----------------------------------------------------------------------------------------
+    def set_state(self, pos=None, prev=None, pinned=None, rest=None, env0=0, n=None, rest_shared=None):
+        n = self.E - env0 if n is None else n
+        f = lambda a, shp: None if a is None else np.ascontiguousarray(
+            np.broadcast_to(np.asarray(a, dtype=np.float64), shp))
+        pos = f(pos, (n, self.P, 3)); prev = f(prev, (n, self.P, 3))
+        pin = None if pinned is None else np.ascontiguousarray(
+            np.broadcast_to(np.asarray(pinned, dtype=np.uint8), (n, self.P)))
+        if rest is not None:
+            rest = np.asarray(rest, dtype=np.float64)
+            if rest_shared is None:
+                rest_shared = rest.ndim == 1
+            rest = np.ascontiguousarray(rest if rest_shared else np.broadcast_to(rest, (n, self.S)))
+        check(self._L.clothhip_set_state(self._h, env0, n, _lib.dp(pos), _lib.dp(prev), _lib.u8p(pin),
+                                         _lib.dp(rest), int(bool(rest_shared))))
+
+    def get_state(self, env0=0, n=None, want_prev=True, want_pinned=True):
+        n = self.E - env0 if n is None else n
+        pos = np.empty((n, self.P, 3))
+        prev = np.empty((n, self.P, 3)) if want_prev else None
+        pin = np.empty((n, self.P), dtype=np.uint8) if want_pinned else None
+        check(self._L.clothhip_get_state(self._h, env0, n, _lib.dp(pos), _lib.dp(prev), _lib.u8p(pin)))
+        return pos, prev, pin
+
+    def positions(self, env0=0, n=None):
+        return self.get_state(env0, n, want_prev=False, want_pinned=False)[0]
+
+    @property
+    def tear(self):
+        t = np.empty(self.E, dtype=np.uint8)
+        check(self._L.clothhip_get_tear(self._h, _lib.u8p(t)))
+        return t.astype(bool)
+
+    @tear.setter
+    def tear(self, v):
+        t = np.ascontiguousarray(np.broadcast_to(np.asarray(v, dtype=np.uint8), (self.E,)))
+        check(self._L.clothhip_set_tear(self._h, _lib.u8p(t)))
+
+    # ---- gripper ---------------------------------------------------------------------------------------
+    def _grab(self, fn, xy, radius, active):
+        xy = np.ascontiguousarray(np.broadcast_to(np.asarray(xy, dtype=np.float64), (self.E, 2)))
+        rad = None if radius is None else np.ascontiguousarray(
+            np.broadcast_to(np.asarray(radius, dtype=np.float64), (self.E,)))
+        act = None if active is None else np.ascontiguousarray(
+            np.broadcast_to(np.asarray(active, dtype=np.uint8), (self.E,)))
+        n = np.zeros(self.E, dtype=np.int32)
+        check(fn(self._h, _lib.dp(xy), _lib.dp(rad), _lib.u8p(act), _lib.i32p(n)))
+        return n
+
+    def grab_top(self, xy, radius=None, active=None):
+        return self._grab(self._L.clothhip_grab_top, xy, radius, active)
+
+    def grab(self, xy, radius=None, active=None):
+        return self._grab(self._L.clothhip_grab, xy, radius, active)
+
+    def release(self, active=None):
+        act = None if active is None else np.ascontiguousarray(
+            np.broadcast_to(np.asarray(active, dtype=np.uint8), (self.E,)))
+        check(self._L.clothhip_release(self._h, _lib.u8p(act)))
+
+    def pin_points(self, env, idx):
+        idx = np.ascontiguousarray(np.atleast_1d(idx), dtype=np.int32)
+        check(self._L.clothhip_pin_points(self._h, int(env), _lib.i32p(idx), len(idx)))
+
+    # ---- stepping --------------------------------------------------------------------------------------
+    def run(self, sched):
+        """Run ClothSchedule[E] (see include/clothhip.h); returns executed update() counts [E]."""
+        sched = np.ascontiguousarray(sched, dtype=SCHED_DTYPE)
+        if sched.shape != (self.E,):
+            raise ValueError("sched must have shape (%d,)" % self.E)
+        ex = np.zeros(self.E, dtype=np.int32)
+        check(self._L.clothhip_run(self._h, sched.ctypes.data_as(C.c_void_p), _lib.i32p(ex)))
+        return ex
+
+    def run_async(self, sched):
+        sched = np.ascontiguousarray(sched, dtype=SCHED_DTYPE)
+        if sched.shape != (self.E,):
+            raise ValueError("sched must have shape (%d,)" % self.E)
+        check(self._L.clothhip_run_async(self._h, sched.ctypes.data_as(C.c_void_p)))
+
+    def sync(self, want_executed=True):
+        ex = np.zeros(self.E, dtype=np.int32) if want_executed else None
+        check(self._L.clothhip_sync(self._h, _lib.i32p(ex)))
+        return ex
+
+    def update(self, n=1, delta=None):
+        """n x Cloth.update() (cloth.pyx:169), each preceded by Gripper.adjust(*delta) if delta is given."""
+        d = None if delta is None else np.ascontiguousarray(delta, dtype=np.float64)
+        check(self._L.clothhip_update(self._h, int(n), _lib.dp(d)))
+
+    @property
+    def last_kernel_ms(self):
+        return float(self._L.clothhip_last_kernel_ms(self._h))
+
+    # ---- device-resident paths (multi-GPU driver) --------------------------------------------------------
+    def run_device_sched_async(self, d_sched_ptr):
+        check(self._L.clothhip_run_device_sched_async(self._h, C.c_void_p(int(d_sched_ptr))))
+
+    def write_obs_f32_device(self, d_out_ptr):
+        check(self._L.clothhip_write_obs_f32_device(self._h, C.c_void_p(int(d_out_ptr))))
+
+    @property
+    def stream(self):
+        return self._L.clothhip_stream(self._h)

@@ -1,0 +1,120 @@
+// cloth_tables.hpp -- host-side static tables of the cloth stepper (depend only on n_side).
+//
+// The reference builds a list of Spring objects in row-major owner order (cloth.pyx:134-146) and walks
+// that list twice per substep: _hookes (cloth.pyx:221-237, a sum whose rounding follows list order) and
+// _limit_spring_changes (cloth.pyx:258-296, an in-place Gauss-Seidel sweep).  The device never sees the
+// list; it sees two tables derived from it here:
+//
+//   * gather table: for every point the <=12 incident springs in ascending list index, so a per-point
+//     gather adds the Hooke forces in exactly the order the reference's scatter does;
+//   * level schedule: springs grouped into dependency levels (level = 1 + max(level of the previous
+//     spring touching either endpoint)).  Springs inside a level share no endpoint; executing the levels
+//     in order reproduces the sequential sweep exactly.
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+namespace clothhip {
+
+enum : uint8_t { SPRING_STRUCTURAL = 0, SPRING_SHEARING = 1, SPRING_BENDING = 2 };
+
+// gather-table entry layout (uint32)
+constexpr uint32_t HK_NBR_MASK = 0xFFFu;        // bits 0..11  neighbour point index (P <= 4096)
+constexpr int HK_POS_SHIFT = 12;                // bits 12..27 position of the spring in level order
+constexpr uint32_t HK_POS_MASK = 0xFFFFu;
+constexpr uint32_t HK_ASB = 1u << 28;           // this point is the spring's ptB (owner): f += -(F)
+constexpr uint32_t HK_BEND = 1u << 29;          // BENDING spring: ks * 0.2
+constexpr uint32_t HK_VALID = 1u << 31;
+constexpr int HK_SLOTS = 12;
+constexpr int MAX_SIDE = 64;                    // 12-bit point index
+
+struct Topology {
+    int N = 0, P = 0, S = 0;
+    std::vector<int32_t> a, b;       // ptA (earlier point), ptB (owning point)   cloth.pyx:136-146
+    std::vector<uint8_t> type;
+};
+
+inline int spring_count(int N) { return 2 * N * (N - 1) + 2 * (N - 1) * (N - 1) + 2 * N * (N - 2); }
+
+// cloth.pyx:134-146: six springs per owning point (r,c), in this order.
+inline Topology build_topology(int N) {
+    Topology t;
+    t.N = N; t.P = N * N; t.S = spring_count(N);
+    t.a.reserve(t.S); t.b.reserve(t.S); t.type.reserve(t.S);
+    auto add = [&](int ai, int bi, uint8_t ty) { t.a.push_back(ai); t.b.push_back(bi); t.type.push_back(ty); };
+    for (int r = 0; r < N; r++)
+        for (int c = 0; c < N; c++) {
+            int i = r * N + c;
+            if (r > 0) add((r - 1) * N + c, i, SPRING_STRUCTURAL);
+            if (c > 0) add(r * N + c - 1, i, SPRING_STRUCTURAL);
+            if (r > 0 && c > 0) add((r - 1) * N + c - 1, i, SPRING_SHEARING);
+            if (r > 0 && c + 1 < N) add((r - 1) * N + c + 1, i, SPRING_SHEARING);
+            if (r > 1) add((r - 2) * N + c, i, SPRING_BENDING);
+            if (c > 1) add(r * N + c - 2, i, SPRING_BENDING);
+        }
+    return t;
+}
+
+struct LevelSchedule {
+    int n_levels = 0, max_width = 0;
+    std::vector<int32_t> off;        // [n_levels+1] offsets into the level-ordered spring arrays
+    std::vector<int32_t> order;      // level-ordered position -> spring list index
+    std::vector<int32_t> pos_of;     // spring list index -> level-ordered position
+    std::vector<uint32_t> ent;       // level-ordered: ptA | ptB << 16
+};
+
+inline LevelSchedule build_levels(const Topology &t) {
+    LevelSchedule L;
+    std::vector<int> last(t.P, 0), lvl(t.S, 0);
+    int nl = 0;
+    for (int s = 0; s < t.S; s++) {
+        int l = 1 + std::max(last[t.a[s]], last[t.b[s]]);
+        lvl[s] = l; last[t.a[s]] = l; last[t.b[s]] = l;
+        nl = std::max(nl, l);
+    }
+    L.n_levels = nl;
+    L.off.assign(nl + 1, 0);
+    for (int s = 0; s < t.S; s++) L.off[lvl[s]]++;          // count per level (1-based) ...
+    for (int l = 1; l <= nl; l++) { L.max_width = std::max(L.max_width, L.off[l]); }
+    {   // ... exclusive prefix: off[l-1] = start of level l
+        int run = 0;
+        for (int l = 1; l <= nl; l++) { int cnt = L.off[l]; L.off[l - 1] = run; run += cnt; }
+        L.off[nl] = run;
+    }
+    L.order.assign(t.S, 0); L.pos_of.assign(t.S, 0); L.ent.assign(t.S, 0);
+    std::vector<int> fill(L.off.begin(), L.off.end() - 1);
+    for (int s = 0; s < t.S; s++) {                           // ascending list index inside a level
+        int p = fill[lvl[s] - 1]++;
+        L.order[p] = s; L.pos_of[s] = p;
+        L.ent[p] = (uint32_t)t.a[s] | ((uint32_t)t.b[s] << 16);
+    }
+    return L;
+}
+
+// gather table [HK_SLOTS][Ppad]: slot k of point i = its k-th incident spring in ascending list index.
+inline std::vector<uint32_t> build_gather(const Topology &t, const LevelSchedule &L, int Ppad) {
+    std::vector<uint32_t> tab((size_t)HK_SLOTS * Ppad, 0u);
+    std::vector<int> n(t.P, 0);
+    for (int s = 0; s < t.S; s++) {
+        uint32_t common = ((uint32_t)L.pos_of[s] << HK_POS_SHIFT) | HK_VALID |
+                          (t.type[s] == SPRING_BENDING ? HK_BEND : 0u);
+        int a = t.a[s], b = t.b[s];
+        tab[(size_t)n[a]++ * Ppad + a] = common | (uint32_t)b;            // point is ptA: f += F
+        tab[(size_t)n[b]++ * Ppad + b] = common | (uint32_t)a | HK_ASB;   // point is ptB: f += -F
+    }
+    return tab;
+}
+
+// Gripper.grab_top level table (gripper.pyx:31-41): curZ = height; while curZ > 0: ...; curZ -= thickness
+inline std::vector<double> build_grab_levels(double height, double thickness) {
+    std::vector<double> lv;
+    if (!(thickness > 0)) return lv;
+    double z = height;
+    while (z > 0 && lv.size() < 100000) { lv.push_back(z); z -= thickness; }
+    return lv;
+}
+
+}  // namespace clothhip

@@ -1,0 +1,529 @@
+// clothhip_api.hip -- C-ABI implementation of libclothhip.so (see include/clothhip.h).
+// Host side only orchestrates: tables, uploads, launches. All physics runs in cloth_kernels.hpp.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "cloth_kernels.hpp"
+
+using namespace clothhip;
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHECK(expr)                                                                          \
+    do {                                                                                        \
+        hipError_t err_ = (expr);                                                               \
+        if (err_ != hipSuccess)                                                                 \
+            return fail(CLOTHHIP_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(err_), \
+                        __FILE__, __LINE__);                                                    \
+    } while (0)
+
+constexpr int NT_STEP = 256;
+
+struct clothhip_handle {
+    ClothParams prm{};
+    int E = 0, N = 0, P = 0, Ppad = 0, S = 0, Spad = 0, Psort = 0, precision = 0, device = 0;
+    size_t tsz = 8;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool have_timing = false, pending_exec = false;
+    void *d_pos = nullptr, *d_prev = nullptr, *d_rest = nullptr;
+    uint8_t *d_cnt = nullptr, *d_active = nullptr;
+    int rest_stride = 0;
+    int32_t *d_tear = nullptr, *d_exec = nullptr, *d_ngrab = nullptr;
+    ClothSchedule *d_sched = nullptr, *h_sched = nullptr;   // h_sched: pinned staging
+    uint32_t *d_gather = nullptr, *d_lv_ent = nullptr;
+    int32_t *d_lv_off = nullptr;
+    double *d_levels = nullptr, *d_xy = nullptr, *d_radius = nullptr;
+    int n_grab_levels = 0;
+    Topology topo;
+    LevelSchedule lv;
+    std::vector<unsigned char> stage;   // host staging for layout conversion
+    std::vector<double> flat_rest;
+};
+
+extern "C" const char *clothhip_last_error(void) { return g_err.c_str(); }
+extern "C" int clothhip_abi_version(void) { return CLOTHHIP_ABI_VERSION; }
+
+extern "C" int clothhip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+static int check_params(const ClothParams *p) {
+    if (!p) return fail(CLOTHHIP_EINVAL, "params is NULL");
+    if (p->n_side < 3 || p->n_side > MAX_SIDE) return fail(CLOTHHIP_EINVAL, "n_side %d outside [3,%d]", p->n_side, MAX_SIDE);
+    if (!(p->width > 0) || !(p->height > 0)) return fail(CLOTHHIP_EINVAL, "width/height must be > 0");
+    if (p->height != p->width) return fail(CLOTHHIP_EINVAL, "height must equal width (cloth.pyx:91)");
+    if (p->frames_per_sec <= 0 || p->simulation_steps <= 0) return fail(CLOTHHIP_EINVAL, "frames_per_sec/simulation_steps must be > 0");
+    if (!(p->density > 0) || !(p->thickness > 0)) return fail(CLOTHHIP_EINVAL, "density/thickness must be > 0");
+    return 0;
+}
+
+// ---- host restatement of Cloth.__init__ grid + rest lengths (cloth.pyx:92-146, :411-417) -----------
+extern "C" int clothhip_init_grid(const ClothParams *p, int32_t tier, int32_t init_side,
+                                  const double *rand_draws, double *pos, double *rest) {
+    if (int rc = check_params(p)) return rc;
+    if (tier < 1 || tier > 3) return fail(CLOTHHIP_EINVAL, "init tier %d (ValueError, cloth.pyx:131-132)", tier);
+    if (tier == 2 && !rand_draws) return fail(CLOTHHIP_EINVAL, "tier 2 needs the P rand() draws");
+    if (!pos) return fail(CLOTHHIP_EINVAL, "pos is NULL");
+    const int N = p->n_side;
+    const double dx = p->width * 1.0 / (N - 1), dy = p->height * 1.0 / (N - 1);   // cloth.pyx:55-56
+    for (int r = 0; r < N; r++)
+        for (int c = 0; c < N; c++) {
+            const int i = r * N + c;
+            double x, y, z;
+            if (tier == 2) {
+                double noise = rand_draws[i] * 0.01 - 0.005;           // cloth.pyx:101
+                if (r == 0) noise = 0;                                 // :102-103
+                x = init_side ? 0.0 + std::fabs(noise) : 1.0 - std::fabs(noise);   // :104-107
+                y = dx * c; z = dy * r;                                // :109-110
+            } else {
+                x = dx * r; y = dy * c; z = 0.0;                       // :122-124
+            }
+            pos[3 * i] = x; pos[3 * i + 1] = y; pos[3 * i + 2] = z;
+        }
+    if (rest) {
+        Topology t = build_topology(N);
+        for (int s = 0; s < t.S; s++) {
+            const double *A = pos + 3 * t.a[s], *B = pos + 3 * t.b[s];
+            const double ux = A[0] - B[0], uy = A[1] - B[1], uz = A[2] - B[2];
+            rest[s] = std::sqrt(ux * ux + uy * uy + uz * uz);         // cloth.pyx:417 via :17-18
+        }
+    }
+    return 0;
+}
+
+extern "C" int clothhip_spring_topology(const ClothParams *p, int32_t *a, int32_t *b, uint8_t *type) {
+    if (int rc = check_params(p)) return rc;
+    Topology t = build_topology(p->n_side);
+    if (a) memcpy(a, t.a.data(), sizeof(int32_t) * t.S);
+    if (b) memcpy(b, t.b.data(), sizeof(int32_t) * t.S);
+    if (type) memcpy(type, t.type.data(), t.S);
+    return 0;
+}
+
+template <typename T> static DevConsts<T> make_consts(const ClothParams &p) {
+    const int N = p.n_side;
+    const double dx = p.width * 1.0 / (N - 1), dy = p.height * 1.0 / (N - 1);
+    const double mass = p.density / N / N;                              // cloth.pyx:178
+    const double delta_t = 1.0 / p.frames_per_sec / p.simulation_steps; // :180
+    const double w = 3 * dx, h = 3 * dy, t = (w > h) ? w : h;           // :308-310
+    DevConsts<T> k;
+    k.mg = (T)(mass * p.gravity);
+    k.ksK[0] = (T)(p.ks * 1.0); k.ksK[1] = (T)(p.ks * 0.2);
+    k.dsm = (T)((delta_t * delta_t) / mass);
+    k.damp = (T)(1.0 - p.damping / 100.0);
+    k.cw = (T)w; k.ch = (T)h; k.ct = (T)t;
+    k.thresh = (T)(2.0 * p.thickness);
+    k.sim_steps = (T)p.simulation_steps;
+    k.min_z = (T)p.minimum_z;
+    k.surf_off = (T)0.0001;
+    k.one_m_fric = (T)(1. - p.plane_friction);
+    k.tear_thresh = (T)p.tear_thresh;
+    k.c11 = (T)1.1;
+    return k;
+}
+
+static void free_handle(clothhip_handle *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    void *ptrs[] = {h->d_pos, h->d_prev, h->d_rest, h->d_cnt, h->d_active, h->d_tear, h->d_exec, h->d_ngrab,
+                    h->d_sched, h->d_gather, h->d_lv_ent, h->d_lv_off, h->d_levels, h->d_xy, h->d_radius};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (h->h_sched) (void)hipHostFree(h->h_sched);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_t device, int32_t precision,
+                               clothhip_handle **out) {
+    if (!out) return fail(CLOTHHIP_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (int rc = check_params(params)) return rc;
+    if (n_envs < 1) return fail(CLOTHHIP_EINVAL, "n_envs must be >= 1");
+    if (precision != CLOTHHIP_F64 && precision != CLOTHHIP_F32) return fail(CLOTHHIP_EINVAL, "precision must be 0 (f64) or 1 (f32)");
+    int ndev = clothhip_device_count();
+    if (ndev <= 0) return fail(CLOTHHIP_ENODEV, "no HIP device visible: libclothhip has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(CLOTHHIP_EINVAL, "device %d outside [0,%d)", device, ndev);
+    HIPCHECK(hipSetDevice(device));
+    clothhip_handle *h = new (std::nothrow) clothhip_handle();
+    if (!h) return fail(CLOTHHIP_ENOMEM, "out of host memory");
+    h->prm = *params; h->E = n_envs; h->device = device; h->precision = precision;
+    h->N = params->n_side; h->P = h->N * h->N; h->Ppad = (h->P + 63) / 64 * 64;
+    h->tsz = precision == CLOTHHIP_F64 ? 8 : 4;
+    h->topo = build_topology(h->N);
+    h->lv = build_levels(h->topo);
+    h->S = h->topo.S; h->Spad = (h->S + 63) / 64 * 64;
+    h->Psort = 1; while (h->Psort < h->P) h->Psort <<= 1;
+    std::vector<uint32_t> gather = build_gather(h->topo, h->lv, h->Ppad);
+    std::vector<double> levels = build_grab_levels(params->height, params->thickness);
+    h->n_grab_levels = (int)levels.size();
+
+#define HC(expr)                                                                                      \
+    do {                                                                                              \
+        hipError_t err_ = (expr);                                                                     \
+        if (err_ != hipSuccess) {                                                                     \
+            int rc_ = fail(err_ == hipErrorOutOfMemory ? CLOTHHIP_ENOMEM : CLOTHHIP_EHIP,             \
+                           "%s failed: %s", #expr, hipGetErrorString(err_));                          \
+            free_handle(h);                                                                           \
+            return rc_;                                                                               \
+        }                                                                                             \
+    } while (0)
+    HC(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HC(hipEventCreate(&h->ev0));
+    HC(hipEventCreate(&h->ev1));
+    const size_t E = h->E;
+    HC(hipMalloc(&h->d_pos, E * 3 * h->Ppad * h->tsz));
+    HC(hipMalloc(&h->d_prev, E * 3 * h->Ppad * h->tsz));
+    HC(hipMalloc(&h->d_rest, E * h->Spad * h->tsz));
+    HC(hipMalloc(&h->d_cnt, E * h->Ppad));
+    HC(hipMalloc(&h->d_active, E));
+    HC(hipMalloc(&h->d_tear, E * 4));
+    HC(hipMalloc(&h->d_exec, E * 4));
+    HC(hipMalloc(&h->d_ngrab, E * 4));
+    HC(hipMalloc(&h->d_sched, E * sizeof(ClothSchedule)));
+    HC(hipHostMalloc((void **)&h->h_sched, E * sizeof(ClothSchedule), hipHostMallocDefault));
+    HC(hipMalloc(&h->d_gather, gather.size() * 4));
+    HC(hipMalloc(&h->d_lv_ent, (size_t)h->S * 4));
+    HC(hipMalloc(&h->d_lv_off, (size_t)(h->lv.n_levels + 1) * 4));
+    HC(hipMalloc(&h->d_levels, (levels.size() + 1) * 8));
+    HC(hipMalloc(&h->d_xy, E * 2 * 8));
+    HC(hipMalloc(&h->d_radius, E * 8));
+    HC(hipMemcpy(h->d_gather, gather.data(), gather.size() * 4, hipMemcpyHostToDevice));
+    HC(hipMemcpy(h->d_lv_ent, h->lv.ent.data(), (size_t)h->S * 4, hipMemcpyHostToDevice));
+    HC(hipMemcpy(h->d_lv_off, h->lv.off.data(), (size_t)(h->lv.n_levels + 1) * 4, hipMemcpyHostToDevice));
+    if (!levels.empty()) HC(hipMemcpy(h->d_levels, levels.data(), levels.size() * 8, hipMemcpyHostToDevice));
+    HC(hipMemset(h->d_exec, 0, E * 4));
+    // large dynamic LDS (up to the CU's 160 KiB) for the stepper kernels
+    {
+        int lds = precision == CLOTHHIP_F64 ? LdsLayout<double>(h->Ppad, h->Psort).total : LdsLayout<float>(h->Ppad, h->Psort).total;
+        if (lds > 160 * 1024) { free_handle(h); return fail(CLOTHHIP_EINVAL, "n_side %d needs %d B of LDS (> 160 KiB)", h->N, lds); }
+        if (precision == CLOTHHIP_F64)
+            HC(hipFuncSetAttribute((const void *)k_run_schedule<double, NT_STEP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        else
+            HC(hipFuncSetAttribute((const void *)k_run_schedule<float, NT_STEP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    }
+#undef HC
+    // initial state: flat tier-1 grid for every env, shared rest table
+    std::vector<double> pos((size_t)h->P * 3), rest(h->S);
+    int rc = clothhip_init_grid(params, 1, 0, nullptr, pos.data(), rest.data());
+    if (rc) { free_handle(h); return rc; }
+    h->flat_rest = rest;
+    std::vector<double> all((size_t)h->E * h->P * 3);
+    for (int e = 0; e < h->E; e++) memcpy(all.data() + (size_t)e * h->P * 3, pos.data(), sizeof(double) * h->P * 3);
+    std::vector<uint8_t> pin((size_t)h->E * h->P, 0);
+    rc = clothhip_set_state(h, 0, h->E, all.data(), all.data(), pin.data(), rest.data(), 1);
+    if (rc) { free_handle(h); return rc; }
+    *out = h;
+    return 0;
+}
+
+extern "C" int clothhip_destroy(clothhip_handle *h) {
+    if (!h) return fail(CLOTHHIP_EINVAL, "handle is NULL");
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    free_handle(h);
+    return 0;
+}
+
+extern "C" int clothhip_num_points(const clothhip_handle *h) { return h ? h->P : fail(CLOTHHIP_EINVAL, "handle is NULL"); }
+extern "C" int clothhip_num_springs(const clothhip_handle *h) { return h ? h->S : fail(CLOTHHIP_EINVAL, "handle is NULL"); }
+extern "C" int clothhip_num_envs(const clothhip_handle *h) { return h ? h->E : fail(CLOTHHIP_EINVAL, "handle is NULL"); }
+extern "C" int clothhip_precision(const clothhip_handle *h) { return h ? h->precision : fail(CLOTHHIP_EINVAL, "handle is NULL"); }
+extern "C" void *clothhip_stream(clothhip_handle *h) { return h ? (void *)h->stream : nullptr; }
+
+static int check_range(const clothhip_handle *h, int env0, int n) {
+    if (!h) return fail(CLOTHHIP_EINVAL, "handle is NULL");
+    if (env0 < 0 || n < 0 || env0 + n > h->E) return fail(CLOTHHIP_EINVAL, "env range [%d,%d) outside [0,%d)", env0, env0 + n, h->E);
+    return 0;
+}
+
+// [n][P][3] double  ->  [n][3][Ppad] T
+template <typename T> static void aos_to_soa(const double *src, T *dst, int n, int P, int Ppad) {
+    for (int e = 0; e < n; e++) {
+        const double *s = src + (size_t)e * P * 3;
+        T *d = dst + (size_t)e * 3 * Ppad;
+        for (int i = 0; i < P; i++) { d[i] = (T)s[3 * i]; d[Ppad + i] = (T)s[3 * i + 1]; d[2 * Ppad + i] = (T)s[3 * i + 2]; }
+        for (int i = P; i < Ppad; i++) { d[i] = 0; d[Ppad + i] = 0; d[2 * Ppad + i] = 0; }
+    }
+}
+template <typename T> static void soa_to_aos(const T *src, double *dst, int n, int P, int Ppad) {
+    for (int e = 0; e < n; e++) {
+        const T *s = src + (size_t)e * 3 * Ppad;
+        double *d = dst + (size_t)e * P * 3;
+        for (int i = 0; i < P; i++) { d[3 * i] = (double)s[i]; d[3 * i + 1] = (double)s[Ppad + i]; d[3 * i + 2] = (double)s[2 * Ppad + i]; }
+    }
+}
+
+extern "C" int clothhip_set_state(clothhip_handle *h, int32_t env0, int32_t n, const double *pos, const double *prev,
+                                  const uint8_t *pinned, const double *rest, int32_t rest_shared) {
+    if (int rc = check_range(h, env0, n)) return rc;
+    HIPCHECK(hipSetDevice(h->device));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    const size_t per = (size_t)3 * h->Ppad * h->tsz;
+    for (int pass = 0; pass < 2; pass++) {
+        const double *src = pass == 0 ? pos : prev;
+        if (!src) continue;
+        h->stage.resize(per * n);
+        if (h->precision == CLOTHHIP_F64) aos_to_soa<double>(src, (double *)h->stage.data(), n, h->P, h->Ppad);
+        else aos_to_soa<float>(src, (float *)h->stage.data(), n, h->P, h->Ppad);
+        char *dst = (char *)(pass == 0 ? h->d_pos : h->d_prev) + per * env0;
+        HIPCHECK(hipMemcpy(dst, h->stage.data(), per * n, hipMemcpyHostToDevice));
+    }
+    if (pos) HIPCHECK(hipMemset(h->d_tear + env0, 0, (size_t)n * 4));
+    if (pinned) {
+        std::vector<uint8_t> c((size_t)n * h->Ppad, 0);
+        for (int e = 0; e < n; e++)
+            for (int i = 0; i < h->P; i++) c[(size_t)e * h->Ppad + i] = pinned[(size_t)e * h->P + i] ? 1 : 0;
+        HIPCHECK(hipMemcpy(h->d_cnt + (size_t)env0 * h->Ppad, c.data(), c.size(), hipMemcpyHostToDevice));
+    }
+    if (rest) {
+        if (!rest_shared && h->rest_stride == 0 && !(env0 == 0 && n == h->E)) {
+            // switching from the shared table to per-env tables: replicate the shared one first
+            std::vector<unsigned char> one((size_t)h->Spad * h->tsz);
+            HIPCHECK(hipMemcpy(one.data(), h->d_rest, one.size(), hipMemcpyDeviceToHost));
+            for (int e = 1; e < h->E; e++)
+                HIPCHECK(hipMemcpy((char *)h->d_rest + (size_t)e * one.size(), one.data(), one.size(), hipMemcpyHostToDevice));
+        }
+        const int nt = rest_shared ? 1 : n;
+        std::vector<unsigned char> buf((size_t)nt * h->Spad * h->tsz, 0);
+        for (int e = 0; e < nt; e++)
+            for (int p = 0; p < h->S; p++) {
+                const double v = rest[(size_t)e * h->S + h->lv.order[p]];     // list order -> level order
+                if (h->precision == CLOTHHIP_F64) ((double *)buf.data())[(size_t)e * h->Spad + p] = v;
+                else ((float *)buf.data())[(size_t)e * h->Spad + p] = (float)v;
+            }
+        char *dst = (char *)h->d_rest + (rest_shared ? 0 : (size_t)env0 * h->Spad * h->tsz);
+        HIPCHECK(hipMemcpy(dst, buf.data(), buf.size(), hipMemcpyHostToDevice));
+        h->rest_stride = rest_shared ? 0 : h->Spad;
+    }
+    return 0;
+}
+
+extern "C" int clothhip_get_state(clothhip_handle *h, int32_t env0, int32_t n, double *pos, double *prev, uint8_t *pinned) {
+    if (int rc = check_range(h, env0, n)) return rc;
+    HIPCHECK(hipSetDevice(h->device));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    const size_t per = (size_t)3 * h->Ppad * h->tsz;
+    for (int pass = 0; pass < 2; pass++) {
+        double *dst = pass == 0 ? pos : prev;
+        if (!dst) continue;
+        h->stage.resize(per * n);
+        const char *src = (const char *)(pass == 0 ? h->d_pos : h->d_prev) + per * env0;
+        HIPCHECK(hipMemcpy(h->stage.data(), src, per * n, hipMemcpyDeviceToHost));
+        if (h->precision == CLOTHHIP_F64) soa_to_aos<double>((const double *)h->stage.data(), dst, n, h->P, h->Ppad);
+        else soa_to_aos<float>((const float *)h->stage.data(), dst, n, h->P, h->Ppad);
+    }
+    if (pinned) {
+        std::vector<uint8_t> c((size_t)n * h->Ppad);
+        HIPCHECK(hipMemcpy(c.data(), h->d_cnt + (size_t)env0 * h->Ppad, c.size(), hipMemcpyDeviceToHost));
+        for (int e = 0; e < n; e++)
+            for (int i = 0; i < h->P; i++) pinned[(size_t)e * h->P + i] = c[(size_t)e * h->Ppad + i] ? 1 : 0;
+    }
+    return 0;
+}
+
+extern "C" int clothhip_get_tear(clothhip_handle *h, uint8_t *tear) {
+    if (!h || !tear) return fail(CLOTHHIP_EINVAL, "NULL argument");
+    HIPCHECK(hipSetDevice(h->device));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    std::vector<int32_t> t(h->E);
+    HIPCHECK(hipMemcpy(t.data(), h->d_tear, (size_t)h->E * 4, hipMemcpyDeviceToHost));
+    for (int e = 0; e < h->E; e++) tear[e] = t[e] ? 1 : 0;
+    return 0;
+}
+
+extern "C" int clothhip_set_tear(clothhip_handle *h, const uint8_t *tear) {
+    if (!h || !tear) return fail(CLOTHHIP_EINVAL, "NULL argument");
+    HIPCHECK(hipSetDevice(h->device));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    std::vector<int32_t> t(h->E);
+    for (int e = 0; e < h->E; e++) t[e] = tear[e] ? 1 : 0;
+    HIPCHECK(hipMemcpy(h->d_tear, t.data(), (size_t)h->E * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
+static int do_grab(clothhip_handle *h, const double *xy, const double *radius, const uint8_t *active,
+                   int32_t *n_grabbed, int top) {
+    if (!h || !xy) return fail(CLOTHHIP_EINVAL, "NULL argument");
+    HIPCHECK(hipSetDevice(h->device));
+    HIPCHECK(hipMemcpyAsync(h->d_xy, xy, (size_t)h->E * 16, hipMemcpyHostToDevice, h->stream));
+    if (radius) HIPCHECK(hipMemcpyAsync(h->d_radius, radius, (size_t)h->E * 8, hipMemcpyHostToDevice, h->stream));
+    if (active) HIPCHECK(hipMemcpyAsync(h->d_active, active, (size_t)h->E, hipMemcpyHostToDevice, h->stream));
+    if (h->precision == CLOTHHIP_F64) {
+        GrabArgs<double> a{(const double *)h->d_pos, h->d_cnt, h->d_xy, radius ? h->d_radius : nullptr,
+                           active ? h->d_active : nullptr, h->d_ngrab, h->d_levels, h->n_grab_levels, h->P, h->Ppad, top,
+                           h->prm.grip_radius, 2 * h->prm.thickness};
+        hipLaunchKernelGGL(k_grab<double>, dim3(h->E), dim3(64), 0, h->stream, a);
+    } else {
+        GrabArgs<float> a{(const float *)h->d_pos, h->d_cnt, h->d_xy, radius ? h->d_radius : nullptr,
+                          active ? h->d_active : nullptr, h->d_ngrab, h->d_levels, h->n_grab_levels, h->P, h->Ppad, top,
+                          h->prm.grip_radius, 2 * h->prm.thickness};
+        hipLaunchKernelGGL(k_grab<float>, dim3(h->E), dim3(64), 0, h->stream, a);
+    }
+    HIPCHECK(hipGetLastError());
+    if (n_grabbed) HIPCHECK(hipMemcpyAsync(n_grabbed, h->d_ngrab, (size_t)h->E * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int clothhip_grab_top(clothhip_handle *h, const double *xy, const double *radius, const uint8_t *active, int32_t *n_grabbed) {
+    return do_grab(h, xy, radius, active, n_grabbed, 1);
+}
+extern "C" int clothhip_grab(clothhip_handle *h, const double *xy, const double *radius, const uint8_t *active, int32_t *n_grabbed) {
+    return do_grab(h, xy, radius, active, n_grabbed, 0);
+}
+
+extern "C" int clothhip_release(clothhip_handle *h, const uint8_t *active) {
+    if (!h) return fail(CLOTHHIP_EINVAL, "handle is NULL");
+    HIPCHECK(hipSetDevice(h->device));
+    if (active) HIPCHECK(hipMemcpyAsync(h->d_active, active, (size_t)h->E, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_release, dim3(h->E), dim3(64), 0, h->stream, h->d_cnt, active ? h->d_active : nullptr, h->Ppad);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int clothhip_pin_points(clothhip_handle *h, int32_t env, const int32_t *idx, int32_t n) {
+    if (int rc = check_range(h, env, 1)) return rc;
+    if (n < 0 || (n > 0 && !idx)) return fail(CLOTHHIP_EINVAL, "bad idx/n");
+    HIPCHECK(hipSetDevice(h->device));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    std::vector<uint8_t> c(h->Ppad);
+    HIPCHECK(hipMemcpy(c.data(), h->d_cnt + (size_t)env * h->Ppad, c.size(), hipMemcpyDeviceToHost));
+    for (int k = 0; k < n; k++) {
+        if (idx[k] < 0 || idx[k] >= h->P) return fail(CLOTHHIP_EINVAL, "point index %d outside [0,%d)", idx[k], h->P);
+        c[idx[k]] |= CNT_EXT_PIN;
+    }
+    HIPCHECK(hipMemcpy(h->d_cnt + (size_t)env * h->Ppad, c.data(), c.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
+template <typename T> static void launch_run(clothhip_handle *h, const ClothSchedule *d_sched) {
+    StepArgs<T> a;
+    a.pos = (T *)h->d_pos; a.prev = (T *)h->d_prev; a.cnt = h->d_cnt; a.rest = (const T *)h->d_rest;
+    a.tear = h->d_tear; a.executed = h->d_exec; a.sched = d_sched;
+    a.gather = h->d_gather; a.lv_ent = h->d_lv_ent; a.lv_off = h->d_lv_off; a.n_levels = h->lv.n_levels;
+    a.N = h->N; a.P = h->P; a.Ppad = h->Ppad; a.S = h->S; a.Spad = h->Spad; a.Psort = h->Psort;
+    a.rest_stride = h->rest_stride;
+    a.k = make_consts<T>(h->prm);
+    const int lds = LdsLayout<T>(h->Ppad, h->Psort).total;
+    hipLaunchKernelGGL((k_run_schedule<T, NT_STEP>), dim3(h->E), dim3(NT_STEP), lds, h->stream, a);
+}
+
+static int run_common(clothhip_handle *h, const ClothSchedule *d_sched) {
+    HIPCHECK(hipEventRecord(h->ev0, h->stream));
+    if (h->precision == CLOTHHIP_F64) launch_run<double>(h, d_sched);
+    else launch_run<float>(h, d_sched);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipEventRecord(h->ev1, h->stream));
+    h->have_timing = true;
+    h->pending_exec = true;
+    return 0;
+}
+
+extern "C" int clothhip_run_async(clothhip_handle *h, const ClothSchedule *sched) {
+    if (!h || !sched) return fail(CLOTHHIP_EINVAL, "NULL argument");
+    for (int e = 0; e < h->E; e++) {
+        const ClothSchedule &s = sched[e];
+        if (s.n_total < 0 || s.n_up_end < 0 || s.n_uprest_end < s.n_up_end || s.n_pull_end < s.n_uprest_end ||
+            s.n_griprest_end < s.n_pull_end || s.n_total < s.n_griprest_end)
+            return fail(CLOTHHIP_EINVAL, "env %d: phase boundaries must be non-decreasing and <= n_total", e);
+    }
+    HIPCHECK(hipSetDevice(h->device));
+    HIPCHECK(hipStreamSynchronize(h->stream));      // h_sched may still be in flight from a previous _async call
+    memcpy(h->h_sched, sched, (size_t)h->E * sizeof(ClothSchedule));
+    HIPCHECK(hipMemcpyAsync(h->d_sched, h->h_sched, (size_t)h->E * sizeof(ClothSchedule), hipMemcpyHostToDevice, h->stream));
+    return run_common(h, h->d_sched);
+}
+
+extern "C" int clothhip_run_device_sched_async(clothhip_handle *h, const void *d_sched) {
+    if (!h || !d_sched) return fail(CLOTHHIP_EINVAL, "NULL argument");
+    HIPCHECK(hipSetDevice(h->device));
+    return run_common(h, (const ClothSchedule *)d_sched);
+}
+
+extern "C" int clothhip_sync(clothhip_handle *h, int32_t *executed) {
+    if (!h) return fail(CLOTHHIP_EINVAL, "handle is NULL");
+    HIPCHECK(hipSetDevice(h->device));
+    if (executed && h->pending_exec)
+        HIPCHECK(hipMemcpyAsync(executed, h->d_exec, (size_t)h->E * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int clothhip_run(clothhip_handle *h, const ClothSchedule *sched, int32_t *executed) {
+    if (int rc = clothhip_run_async(h, sched)) return rc;
+    return clothhip_sync(h, executed);
+}
+
+extern "C" int clothhip_update(clothhip_handle *h, int32_t n_sub, const double *delta) {
+    if (!h) return fail(CLOTHHIP_EINVAL, "handle is NULL");
+    if (n_sub < 0) return fail(CLOTHHIP_EINVAL, "n_sub < 0");
+    std::vector<ClothSchedule> s(h->E);
+    for (auto &x : s) {
+        memset(&x, 0, sizeof(x));
+        x.active = 1; x.break_on_tear = 0; x.n_total = n_sub; x.n_griprest_end = n_sub;
+        if (delta) {   // n x { adjust(delta) ; update }: the whole run is one "pull" phase
+            x.n_pull_end = n_sub;
+            x.dx_pull = delta[0]; x.dy_pull = delta[1]; x.dz_pull = delta[2];
+        }
+    }
+    return clothhip_run(h, s.data(), nullptr);
+}
+
+extern "C" int clothhip_write_obs_f32_device(clothhip_handle *h, void *d_out) {
+    if (!h || !d_out) return fail(CLOTHHIP_EINVAL, "NULL argument");
+    HIPCHECK(hipSetDevice(h->device));
+    if (h->precision == CLOTHHIP_F64)
+        hipLaunchKernelGGL(k_write_obs<double>, dim3(h->E), dim3(256), 0, h->stream, (const double *)h->d_pos, (float *)d_out, h->P, h->Ppad);
+    else
+        hipLaunchKernelGGL(k_write_obs<float>, dim3(h->E), dim3(256), 0, h->stream, (const float *)h->d_pos, (float *)d_out, h->P, h->Ppad);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" double clothhip_last_kernel_ms(clothhip_handle *h) {
+    if (!h || !h->have_timing) return -1.0;
+    if (hipSetDevice(h->device) != hipSuccess) return -1.0;
+    if (hipEventSynchronize(h->ev1) != hipSuccess) return -1.0;
+    float ms = -1.f;
+    if (hipEventElapsedTime(&ms, h->ev0, h->ev1) != hipSuccess) return -1.0;
+    return (double)ms;
+}
+
+extern "C" int clothhip_selftest_arith(int32_t device, int32_t op, const double *a, const double *b, double *out, int64_t n) {
+    if (!a || !out || n <= 0) return fail(CLOTHHIP_EINVAL, "bad argument");
+    if (clothhip_device_count() <= 0) return fail(CLOTHHIP_ENODEV, "no HIP device visible");
+    HIPCHECK(hipSetDevice(device));
+    double *da = nullptr, *db = nullptr, *dout = nullptr;
+    HIPCHECK(hipMalloc(&da, n * 8));
+    HIPCHECK(hipMalloc(&dout, n * 8));
+    if (b) { HIPCHECK(hipMalloc(&db, n * 8)); HIPCHECK(hipMemcpy(db, b, n * 8, hipMemcpyHostToDevice)); }
+    HIPCHECK(hipMemcpy(da, a, n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_selftest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, op, da, db, dout, (long long)n);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipDeviceSynchronize());
+    HIPCHECK(hipMemcpy(out, dout, n * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(da); (void)hipFree(dout); if (db) (void)hipFree(db);
+    return 0;
+}

@@ -1,0 +1,170 @@
+/*
+ * clothhip.h -- C ABI of libclothhip.so, the MI355X (gfx950) cloth stepper.
+ *
+ * Drop-in boundary for the hot path of DanielTakeshi/gym-cloth: the Python object API of the three
+ * Cython modules gym_cloth/physics/{cloth,point,gripper}.pyx that ClothEnv imports at
+ * gym_cloth/envs/cloth_env.py:25-27.  The reference has no FFI layer of its own; these entry points
+ * are what a ctypes binding for that path binds (INTEGRATION.md shows the stub).  Every entry point
+ * names the reference interface it replaces (file:line relative to the reference root).
+ *
+ * Conventions
+ *   - plain C types only; host arrays are caller-owned, passed as pointer + explicit extents, never
+ *     retained after the call returns.
+ *   - E = n_envs of the handle, P = n_side*n_side points, S = clothhip_num_springs() springs.
+ *   - host position arrays are [E][P][3] doubles (x,y,z interleaved) = E stacked Cloth.allpts_arr
+ *     (cloth.pyx:395); the device keeps SoA [E][3][Ppad] in the handle's precision.
+ *   - every call returns 0 on success or a negative CLOTHHIP_E* code; clothhip_last_error() gives a
+ *     thread-local message.  No C++ exception and no abort() crosses the ABI.
+ *   - calls on one handle are not re-entrant.  Calls enqueue on the handle's HIP stream and
+ *     synchronise before returning unless the name ends in _async.
+ *   - there is NO CPU fallback: without a HIP device clothhip_create fails with CLOTHHIP_ENODEV.
+ */
+#ifndef CLOTHHIP_H
+#define CLOTHHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLOTHHIP_ABI_VERSION 1
+
+enum {
+    CLOTHHIP_OK = 0,
+    CLOTHHIP_EINVAL = -1,   /* bad argument (ValueError / AssertionError in the reference, cloth.pyx:85,91,132) */
+    CLOTHHIP_ENODEV = -2,   /* no usable HIP device */
+    CLOTHHIP_EHIP = -3,     /* a HIP runtime call failed; message has the hipError string */
+    CLOTHHIP_ENOMEM = -4,
+    CLOTHHIP_ESTATE = -5    /* call not valid in the handle's current state */
+};
+
+enum { CLOTHHIP_F64 = 0, CLOTHHIP_F32 = 1 };
+
+/* Physics constants: the keys Cloth.__init__/Cloth.update read from the cfg dict
+ * (cloth.pyx:53-56, :175-186) plus the Cloth() constructor defaults (cloth.pyx:24-26) and the
+ * Gripper constructor arguments (gripper.pyx:10; cloth_env.py:752-753). */
+typedef struct ClothParams {
+    int32_t n_side;            /* cloth.num_width_points == cloth.num_height_points (asserted, cloth.pyx:91) */
+    int32_t frames_per_sec;    /* cfg frames_per_sec */
+    int32_t simulation_steps;  /* cfg simulation_steps */
+    int32_t _pad;
+    double width, height;      /* cfg cloth.width / cloth.height */
+    double density, ks, damping, thickness, plane_friction, tear_thresh;  /* cfg cloth.* */
+    double gravity;            /* Cloth(gravity=-9.8) */
+    double minimum_z;          /* Cloth(minimum_z=0)  */
+    double grip_radius;        /* cfg env.grip_radius (default Gripper.grip_radius) */
+} ClothParams;
+
+/* One pick-and-place schedule = the hot loop of ClothEnv.step + ClothEnv._pull
+ * (cloth_env.py:352-367, :472-515):
+ *   for i in [0, n_total):
+ *       i <  n_up_end       : gripper.adjust(0, 0, dz_up)
+ *       i <  n_uprest_end   : -
+ *       i <  n_pull_end     : gripper.adjust(dx_pull, dy_pull, dz_pull)   (dz_pull = 0 in the reference)
+ *       i <  n_griprest_end : -
+ *       else                : gripper.release()
+ *       cloth.update()
+ *       if break_on_tear and cloth.have_tear: break
+ * The n_* are the integer ceilings of the reference's cumulative (possibly fractional: tier 3 draws a
+ * float iters_up, cloth_env.py:960) phase boundaries, so `i < boundary` is unchanged.
+ * A raw `for _ in range(n): cloth.update()` is {0,0,0,n,n}, break_on_tear=0. */
+typedef struct ClothSchedule {
+    int32_t n_up_end, n_uprest_end, n_pull_end, n_griprest_end, n_total;
+    int32_t break_on_tear;
+    int32_t active;            /* 0: this env is skipped entirely (cloth_env.py:490-493 "nothing grabbed") */
+    int32_t _pad;
+    double dz_up;              /* 0.0025 in the reference (cloth_env.py:359) */
+    double dx_pull, dy_pull;   /* x_dir_r, y_dir_r (cloth_env.py:455-456) */
+    double dz_pull;            /* 0 in the reference (cloth_env.py:363); lets clothhip_update pass any delta */
+} ClothSchedule;
+
+typedef struct clothhip_handle clothhip_handle;
+
+const char *clothhip_last_error(void);
+int clothhip_abi_version(void);
+/* number of visible HIP devices (0 if none / runtime unusable); never fails */
+int clothhip_device_count(void);
+
+/* Replaces Cloth(...) + Gripper(...) construction for a batch of E independent cloths
+ * (cloth.pyx:23-167, gripper.pyx:10-21; cloth_env.py:737-753). State starts as the flat tier-1 grid. */
+int clothhip_create(const ClothParams *params, int32_t n_envs, int32_t device, int32_t precision,
+                    clothhip_handle **out);
+int clothhip_destroy(clothhip_handle *h);
+int clothhip_num_points(const clothhip_handle *h);
+int clothhip_num_springs(const clothhip_handle *h);
+int clothhip_num_envs(const clothhip_handle *h);
+int clothhip_precision(const clothhip_handle *h);
+
+/* Host-side restatement of the grid/spring construction of Cloth.__init__ (cloth.pyx:92-146, :411-417),
+ * in double, for one cloth: fills pos[P][3] and rest[S]. tier 1/3 = flat grid, tier 2 = vertical sheet
+ * with the P np_random.rand() draws passed in rand_draws (r-major order). Pure host function. */
+int clothhip_init_grid(const ClothParams *params, int32_t tier, int32_t init_side,
+                       const double *rand_draws, double *pos, double *rest);
+/* Spring list (ptA index, ptB index, type 0/1/2 = STRUCTURAL/SHEARING/BENDING) in reference list order. */
+int clothhip_spring_topology(const ClothParams *params, int32_t *a, int32_t *b, uint8_t *type);
+
+/* State upload/download for envs [env0, env0+n): the replacement for writing/reading
+ * pts[i].x/.y/.z/.px/.py/.pz/.pinned (point.pyx:34-48; read at cloth_env.py:196-200, :629, :854-937).
+ * Any pointer may be NULL (= leave untouched / do not fetch).  rest is [n][S] (Spring.rest_length);
+ * rest_shared != 0 means rest is a single [S] table used by ALL envs of the handle (tier 1/3).
+ * pinned != 0 marks the point pinned and a member of gripper.grabbed_pts. set_state clears the tear flag
+ * of the envs it touches when `pos` is given. */
+int clothhip_set_state(clothhip_handle *h, int32_t env0, int32_t n, const double *pos, const double *prev,
+                       const uint8_t *pinned, const double *rest, int32_t rest_shared);
+int clothhip_get_state(clothhip_handle *h, int32_t env0, int32_t n, double *pos, double *prev,
+                       uint8_t *pinned);
+/* Cloth.have_tear (cloth.pyx:390-392) for every env: tear[E] (0/1). set: overwrite (Cloth() is rebuilt
+ * per reset in the reference, which clears it). */
+int clothhip_get_tear(clothhip_handle *h, uint8_t *tear);
+int clothhip_set_tear(clothhip_handle *h, const uint8_t *tear);
+
+/* Gripper.grab_top(x, y) (gripper.pyx:23-42) for every active env: xy[E][2]; radius[E] or NULL
+ * (= params.grip_radius; cloth_env.py:436-442 mutates it for force_grab); active[E] or NULL (= all).
+ * n_grabbed[E] receives the number of points appended to grabbed_pts by THIS call (0 = nothing grabbed). */
+int clothhip_grab_top(clothhip_handle *h, const double *xy, const double *radius, const uint8_t *active,
+                      int32_t *n_grabbed);
+/* Gripper.grab(x, y) (gripper.pyx:44-53) */
+int clothhip_grab(clothhip_handle *h, const double *xy, const double *radius, const uint8_t *active,
+                  int32_t *n_grabbed);
+/* Gripper.release() (gripper.pyx:68-73) */
+int clothhip_release(clothhip_handle *h, const uint8_t *active);
+/* pt.pinned = True from outside the gripper (point.pyx:48 is a plain writable attribute): idx[n] point
+ * indices of env `env`; the points are pinned but NOT members of grabbed_pts (adjust does not move them). */
+int clothhip_pin_points(clothhip_handle *h, int32_t env, const int32_t *idx, int32_t n);
+
+/* The hot path. Runs sched[e] for every env e (see ClothSchedule) entirely on the device:
+ * n_total x { Gripper.adjust / release ; Cloth.update (cloth.pyx:169-214) ; tear break }.
+ * executed[E] (may be NULL) receives the number of update() calls each env performed. */
+int clothhip_run(clothhip_handle *h, const ClothSchedule *sched, int32_t *executed);
+int clothhip_run_async(clothhip_handle *h, const ClothSchedule *sched);
+/* wait for the handle's stream; after an _async call also fetches executed[E] (may be NULL) */
+int clothhip_sync(clothhip_handle *h, int32_t *executed);
+
+/* Convenience: n x Cloth.update() on every env (cloth_env.py:902-903, :948-949, :980-981), optionally
+ * preceded each time by Gripper.adjust(delta) when delta != NULL ([3] doubles, same for all envs). */
+int clothhip_update(clothhip_handle *h, int32_t n_sub, const double *delta);
+
+/* Device-resident observation path for the multi-GPU driver: writes the '1d' observation
+ * (cloth_env.py:196-200: [x0,y0,z0,x1,...] per env) of every env as float32 into a DEVICE buffer
+ * d_out[E][3P] (e.g. a torch/RCCL gather buffer). Asynchronous on the handle's stream. */
+int clothhip_write_obs_f32_device(clothhip_handle *h, void *d_out);
+/* Same, schedules read from a DEVICE array of ClothSchedule[E] (e.g. after an RCCL broadcast). */
+int clothhip_run_device_sched_async(clothhip_handle *h, const void *d_sched);
+/* the handle's hipStream_t as an opaque pointer (for event timing / stream ordering by the caller) */
+void *clothhip_stream(clothhip_handle *h);
+
+/* Timing of the last clothhip_run/_async/_update launch measured with HIP events recorded on the
+ * handle's stream around the stepper kernel: milliseconds, or a negative value if none. */
+double clothhip_last_kernel_ms(clothhip_handle *h);
+
+/* Arithmetic self-test used by the parity tests: evaluates out[i] = op(a[i], b[i]) in double ON THE
+ * DEVICE with the same compiler flags as the stepper (op 0: a/b, 1: sqrt(a), 2: a*b+c unfused = (a*b)+b,
+ * 3: floor(a/b)).  Lets tests assert IEEE-correct rounding of the device's sqrt/div bit-for-bit. */
+int clothhip_selftest_arith(int32_t device, int32_t op, const double *a, const double *b, double *out,
+                            int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -38,6 +38,9 @@ struct OracleCloth {
     int32_t *thead, *ttail;        /* -1 = empty slot */
     int32_t *next;                 /* chain in ascending point index */
     int32_t *slot_of;              /* table slot of each point (from build_spatial_map) */
+    /* debug census of the last update(): springs corrected by the strain limiter, points moved by
+     * self-collision (used to characterise workloads; not part of the reference's state) */
+    int stat_strain, stat_collide;
 };
 
 /* cloth.pyx:17-18  math.sqrt(x*x + y*y + z*z), association ((x*x + y*y) + z*z) */
@@ -273,6 +276,7 @@ static void self_collide(OracleCloth *c, int i, int simulation_steps, double thi
         }
     }
     if (n != 0) {                                                 /* :336 */
+        c->stat_collide++;
         double nf = (double)n;
         double cx = tx / nf / simulation_steps;                   /* :338 */
         double cy = ty / nf / simulation_steps;
@@ -308,6 +312,7 @@ static void limit_spring_changes(OracleCloth *c, double tear_thresh) {
         double len = fastnorm(c->x[a] - c->x[b], c->y[a] - c->y[b], c->z[a] - c->z[b]);   /* :270 */
         if (len > c->rest[s] * tear_thresh) c->tear = 1;                                  /* :272 */
         if (len > (c->rest[s] * 1.1)) {                                                   /* :275 */
+            c->stat_strain++;
             double dirx = (c->x[a] - c->x[b]) / len;                                      /* :276 */
             double diry = (c->y[a] - c->y[b]) / len;
             double dirz = (c->z[a] - c->z[b]) / len;
@@ -332,6 +337,7 @@ static void update_once(OracleCloth *c) {
     double mass = p->density / c->N / c->N;                       /* :178 */
     double mass_times_g = mass * p->gravity;                      /* :179 */
     double delta_t = 1.0 / p->frames_per_sec / simulation_steps;  /* :180 */
+    c->stat_strain = 0; c->stat_collide = 0;
     reset_gravity(c, mass_times_g);                               /* :189 */
     hookes(c, p->ks);                                             /* :192 */
     verlet(c, mass, delta_t, p->damping);                         /* :195 */
@@ -343,6 +349,10 @@ static void update_once(OracleCloth *c) {
 
 void oracle_update(OracleCloth *c, int n) {
     for (int k = 0; k < n; k++) update_once(c);
+}
+
+void oracle_last_stats(const OracleCloth *c, int32_t *n_strain, int32_t *n_collide) {
+    *n_strain = c->stat_strain; *n_collide = c->stat_collide;
 }
 
 void oracle_cell_census(const OracleCloth *c, int32_t *n_cells, int32_t *max_occ) {

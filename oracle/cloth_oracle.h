@@ -65,6 +65,8 @@ int oracle_have_tear(const OracleCloth *c);                                   /*
 void oracle_set_tear(OracleCloth *c, int tear);
 /* census of the spatial map left by the last update (number of cells, max occupancy) */
 void oracle_cell_census(const OracleCloth *c, int32_t *n_cells, int32_t *max_occ);
+/* debug: #springs corrected by the strain limiter / #points moved by self-collision in the last update */
+void oracle_last_stats(const OracleCloth *c, int32_t *n_strain, int32_t *n_collide);
 
 /* The per-action hot loop of ClothEnv.step + _pull (cloth_env.py:352-367, :495-515):
  *   for i in [0, n_total): phase(i) -> adjust / nothing / release ; update ; break on tear.

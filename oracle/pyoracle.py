@@ -64,6 +64,7 @@ def lib():
         L.oracle_have_tear.argtypes = [vp]
         L.oracle_set_tear.argtypes = [vp, C.c_int]
         L.oracle_cell_census.argtypes = [vp, i32p, i32p]
+        L.oracle_last_stats.argtypes = [vp, i32p, i32p]
         L.oracle_run_schedule.argtypes = [vp] + [C.c_int] * 5 + [C.c_double] * 3 + [C.c_int]
         L.oracle_batch_run_schedule.argtypes = [C.POINTER(vp), C.c_int, i32p, dp, C.c_int, i32p, C.c_int]
         L.oracle_batch_update.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int]
@@ -185,6 +186,11 @@ class OracleCloth(object):
     def cell_census(self):
         a = C.c_int32(); b = C.c_int32()
         self._L.oracle_cell_census(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def last_stats(self):
+        a = C.c_int32(); b = C.c_int32()
+        self._L.oracle_last_stats(self._h, C.byref(a), C.byref(b))
         return a.value, b.value
 
     def run_schedule(self, sched, dz_up, dx, dy, break_on_tear=True):
