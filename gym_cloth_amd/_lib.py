@@ -68,6 +68,8 @@ SYMBOLS = [
     ("clothhip_run_async", C.c_int, [_vp, _vp]),
     ("clothhip_sync", C.c_int, [_vp, _i32p]),
     ("clothhip_update", C.c_int, [_vp, C.c_int32, _dp]),
+    ("clothhip_metrics", C.c_int, [_vp, _dp, _dp, _u8p, _u8p]),
+    ("clothhip_hull_area", C.c_double, [_dp, C.c_int32]),
     ("clothhip_write_obs_f32_device", C.c_int, [_vp, _vp]),
     ("clothhip_run_device_sched_async", C.c_int, [_vp, _vp]),
     ("clothhip_stream", _vp, [_vp]),

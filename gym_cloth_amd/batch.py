@@ -117,6 +117,14 @@ class ClothBatch(object):
         t = np.ascontiguousarray(np.broadcast_to(np.asarray(v, dtype=np.uint8), (self.E,)))
         check(self._L.clothhip_set_tear(self._h, _lib.u8p(t)))
 
+    def metrics(self):
+        """(coverage[E], variance_inv[E], out_of_bounds[E], tear[E]) as ClothEnv computes them
+        (cloth_env.py:1020-1098)."""
+        cov = np.empty(self.E); vinv = np.empty(self.E)
+        oob = np.empty(self.E, dtype=np.uint8); tear = np.empty(self.E, dtype=np.uint8)
+        check(self._L.clothhip_metrics(self._h, _lib.dp(cov), _lib.dp(vinv), _lib.u8p(oob), _lib.u8p(tear)))
+        return cov, vinv, oob.astype(bool), tear.astype(bool)
+
     # ---- gripper ---------------------------------------------------------------------------------------
     def _grab(self, fn, xy, radius, active):
         xy = np.ascontiguousarray(np.broadcast_to(np.asarray(xy, dtype=np.float64), (self.E, 2)))

@@ -2,11 +2,14 @@
 // Host side only orchestrates: tables, uploads, launches. All physics runs in cloth_kernels.hpp.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "cloth_kernels.hpp"
@@ -489,6 +492,67 @@ extern "C" int clothhip_update(clothhip_handle *h, int32_t n_sub, const double *
         }
     }
     return clothhip_run(h, s.data(), nullptr);
+}
+
+// ---- metrics (host, double): cloth_env.py:1020-1098 ------------------------------------------------------
+// Convex-hull area by Andrew's monotone chain + shoelace. Collinear and duplicate points (plenty after the
+// clip to [0,1]^2) are dropped from the chain; they do not change the area.
+extern "C" double clothhip_hull_area(const double *xy, int32_t n) {
+    if (!xy || n < 3) return 0.0;
+    std::vector<std::pair<double, double>> p(n);
+    for (int i = 0; i < n; i++) p[i] = {xy[2 * i], xy[2 * i + 1]};
+    std::sort(p.begin(), p.end());
+    p.erase(std::unique(p.begin(), p.end()), p.end());
+    const int m = (int)p.size();
+    if (m < 3) return 0.0;
+    auto cross = [](const std::pair<double, double> &o, const std::pair<double, double> &a, const std::pair<double, double> &b) {
+        return (a.first - o.first) * (b.second - o.second) - (a.second - o.second) * (b.first - o.first);
+    };
+    std::vector<std::pair<double, double>> hull(2 * m);
+    int k = 0;
+    for (int i = 0; i < m; i++) { while (k >= 2 && cross(hull[k - 2], hull[k - 1], p[i]) <= 0) k--; hull[k++] = p[i]; }
+    for (int i = m - 2, t = k + 1; i >= 0; i--) { while (k >= t && cross(hull[k - 2], hull[k - 1], p[i]) <= 0) k--; hull[k++] = p[i]; }
+    k--;   // last point == first point
+    if (k < 3) return 0.0;
+    double a2 = 0.0;
+    for (int i = 0; i < k; i++) {
+        const auto &u = hull[i], &v = hull[(i + 1) % k];
+        a2 += (u.first - hull[0].first) * (v.second - hull[0].second) - (v.first - hull[0].first) * (u.second - hull[0].second);
+    }
+    return 0.5 * std::fabs(a2);
+}
+
+extern "C" int clothhip_metrics(clothhip_handle *h, double *coverage, double *variance_inv, uint8_t *oob, uint8_t *tear) {
+    if (!h) return fail(CLOTHHIP_EINVAL, "handle is NULL");
+    if (tear) if (int rc = clothhip_get_tear(h, tear)) return rc;
+    if (!coverage && !variance_inv && !oob) return 0;
+    std::vector<double> pos((size_t)h->E * h->P * 3);
+    if (int rc = clothhip_get_state(h, 0, h->E, pos.data(), nullptr, nullptr)) return rc;
+    const int P = h->P;
+    std::vector<double> xy((size_t)P * 2);
+    for (int e = 0; e < h->E; e++) {
+        const double *q = pos.data() + (size_t)e * P * 3;
+        double mnx = q[0], mxx = q[0], mny = q[1], mxy = q[1], mnz = q[2], mxz = q[2], sum = 0.0;
+        for (int i = 0; i < P; i++) {
+            const double x = q[3 * i], y = q[3 * i + 1], z = q[3 * i + 2];
+            mnx = std::min(mnx, x); mxx = std::max(mxx, x); mny = std::min(mny, y); mxy = std::max(mxy, y);
+            mnz = std::min(mnz, z); mxz = std::max(mxz, z); sum += z;
+            xy[2 * i] = std::min(std::max(x, 0.0), 1.0); xy[2 * i + 1] = std::min(std::max(y, 0.0), 1.0);   // cloth_env.py:629
+        }
+        if (coverage) coverage[e] = clothhip_hull_area(xy.data(), P);
+        if (variance_inv) {
+            const double mean = sum / P;
+            double acc = 0.0;
+            for (int i = 0; i < P; i++) { const double d = q[3 * i + 2] - mean; acc += d * d; }
+            const double var = acc / P;                                          // np.var (population variance)
+            variance_inv[e] = var < 0.000001 ? 1000.0 : 0.001 / var;             // cloth_env.py:1081-1084
+        }
+        if (oob) {
+            const double slack = 0.25, bx = 1.0, by = 1.0, bz = 1.0;           // cloth_env.py:1031-1036
+            oob[e] = (mxx >= bx + slack || mnx < -slack || mxy >= by + slack || mny < -slack || mxz >= bz || mnz < 0) ? 1 : 0;
+        }
+    }
+    return 0;
 }
 
 extern "C" int clothhip_write_obs_f32_device(clothhip_handle *h, void *d_out) {

@@ -1,0 +1,568 @@
+"""Host side of the drop-in: the gym `ClothEnv.step()/reset()` surface of the reference
+(gym_cloth/envs/cloth_env.py) driving the HIP stepper, vectorised over E independent cloths.
+
+ClothVecEnv  E envs on one GPU (new: the reference is one env per process, analysis/README.md:8-13)
+ClothEnv     the reference's single-env API (cloth_env.py:55) = a ClothVecEnv with E = 1
+
+What is mirrored here is exactly what sits between the gym API and the physics hot path:
+  action clipping / un-clipping / direction / iters_pull        cloth_env.py:396-470
+  phase schedule + per-iteration adjust -> update -> tear?      cloth_env.py:352-367, :472-515
+  reset procedures of the three tiers and their RNG sequence    cloth_env.py:717-987, cloth.pyx:75,101
+  reward / terminal / out-of-bounds / coverage / variance       cloth_env.py:536-715, :1020-1098
+Blender observations, the OpenGL viewer, logging-to-file and pickle I/O are out of scope;
+obs_type is forced to the '1d' observation (cloth_env.py:196-200).
+"""
+import copy
+
+import numpy as np
+import yaml
+
+from . import seeding
+from .batch import ClothBatch, make_schedules
+
+_REWARD_THRESHOLDS = {           # cloth_env.py:42-50
+    'coverage': 0.92, 'coverage-delta': 0.92, 'height': 0.85, 'height-delta': 0.85,
+    'variance': 2, 'variance-delta': 2, 'folding-number': 0,
+}
+_EPS = 1e-5                      # cloth_env.py:52
+
+
+class Box(object):
+    """Minimal stand-in for gym.spaces.Box (gym is not a dependency of the hot path)."""
+
+    def __init__(self, low, high, dtype=np.float64):
+        self.low = np.asarray(low, dtype=dtype)
+        self.high = np.asarray(high, dtype=dtype)
+        self.shape = self.low.shape
+        self.dtype = dtype
+        self.np_random = np.random.RandomState()
+
+    def seed(self, seed=None):
+        self.np_random.seed(seed)
+
+    def sample(self):
+        return self.np_random.uniform(low=self.low, high=self.high)
+
+    def contains(self, x):
+        x = np.asarray(x)
+        return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
+
+
+def load_cfg(cfg):
+    if isinstance(cfg, dict):
+        return copy.deepcopy(cfg)
+    with open(cfg, 'r') as fh:                       # cloth_env.py:87-88
+        return yaml.safe_load(fh)
+
+
+class ClothVecEnv(object):
+    metadata = {'render.modes': ['human']}
+
+    def __init__(self, cfg_file, n_envs=1, device=0, precision='f32', consume_domrand_draws=True):
+        cfg = load_cfg(cfg_file)
+        self.cfg, self.cfg_file = cfg, cfg_file
+        e = cfg['env']
+        self.max_actions = e['max_actions']
+        self.iters_up = e['iters_up']
+        self.iters_up_rest = e['iters_up_rest']
+        self.iters_pull_max = e['iters_pull_max']
+        self.iters_grip_rest = e['iters_grip_rest']
+        self.iters_rest = e['iters_rest']
+        self.reduce_factor = e['reduce_factor']
+        self.grip_radius = e['grip_radius']
+        self._init_type = cfg['init']['type']
+        self._clip_act_space = e['clip_act_space']
+        self._delta_actions = e['delta_actions']
+        self._force_grab = e['force_grab']
+        self._radius_inc = 0.02
+        self.bounds = (1, 1, 1)
+        self.reward_type = e['reward_type']
+        assert 'coverage' in self.reward_type                       # cloth_env.py:130
+        self._neg_living_rew = 0.0
+        self._nogrip_penalty = -0.01
+        self._tear_penalty = 0.0
+        self._oob_penalty = 0.0
+        self._cover_success = 5.
+        self._act_bound_factor = 1.0
+        self._act_pen_limit = 3.0
+        self._slack = 0.25
+        self.num_w = cfg['cloth']['num_width_points']
+        self.num_h = cfg['cloth']['num_height_points']
+        self.num_points = self.num_w * self.num_h
+        self.obslow = np.ones((3 * self.num_points,)) * -100
+        self.obshigh = np.ones((3 * self.num_points,)) * 100
+        self.observation_space = Box(self.obslow, self.obshigh)
+        b0, b1 = self.bounds[0], self.bounds[1]
+        if self._clip_act_space:                                     # cloth_env.py:162-181
+            self.action_space = Box([-1., -1., -1., -1.], [1., 1., 1., 1.])
+        elif self._delta_actions:
+            self.action_space = Box([0., 0., -1., -1.], [1., 1., 1., 1.])
+        else:
+            self.action_space = Box([-self._slack, -self._slack, 0.0, -np.pi],
+                                    [b0 + self._slack, b1 + self._slack, 1.0, np.pi])
+        self._wd = self._hd = 224
+        self._consume_domrand = consume_domrand_draws
+
+        self.E = int(n_envs)
+        self.batch = ClothBatch(cfg, n_envs=self.E, device=device, precision=precision)
+        self.P = self.batch.P
+        E = self.E
+        self.np_randoms = [None] * E
+        self.seed(None)
+        self.init_side = np.zeros(E, dtype=bool)
+        self.num_steps = np.zeros(E, dtype=np.int64)
+        self.num_sim_steps = np.zeros(E, dtype=np.int64)
+        self.have_tear = np.zeros(E, dtype=bool)
+        self._prev_reward = np.zeros(E)
+        self._start_coverage = np.zeros(E)
+        self._start_variance_inv = np.zeros(E)
+        self._current_coverage = np.zeros(E)
+        self._iters_up_env = np.full(E, float(self.iters_up))       # tier 3 overrides it per env during reset
+        self.last_executed = np.zeros(E, dtype=np.int64)
+        self.last_grabbed = np.zeros(E, dtype=np.int64)
+        self.last_iters_pull = np.zeros(E, dtype=np.int64)
+        self.total_substeps = 0                                      # executed update() calls, all envs
+
+    def close(self):
+        self.batch.close()
+
+    # ------------------------------------------------------------------------------------------------
+    def seed(self, seed=None):
+        """cloth_env.py:332-341, one RandomState per env. `seed` may be None, an int (env e gets
+        seed + e) or a sequence of E ints."""
+        if seed is None or isinstance(seed, (int, np.integer)):
+            seeds = [None if seed is None else int(seed) + e for e in range(self.E)]
+        else:
+            seeds = list(seed)
+            assert len(seeds) == self.E
+        out = []
+        for e, s in enumerate(seeds):
+            self.np_randoms[e], s2 = seeding.np_random(s)
+            out.append(s2)
+        return out
+
+    @property
+    def state(self):
+        """'1d' observation of every env, [E, 3P] (cloth_env.py:196-200)."""
+        return self.batch.positions().reshape(self.E, 3 * self.P)
+
+    # ---- action decoding (cloth_env.py:396-475) -------------------------------------------------------
+    def decode_actions(self, actions, iters_up=None):
+        """-> dict(x, y, x_dir_r, y_dir_r, iters_pull, bounds[E,5])."""
+        a = np.asarray(actions, dtype=np.float64).reshape(self.E, 4)
+        low, high = self.action_space.low, self.action_space.high
+        a = np.maximum(np.minimum(a, high[None, :]), low[None, :])                     # :402-415
+        x_coord, y_coord, c2, c3 = a[:, 0], a[:, 1], a[:, 2], a[:, 3]
+        if self._clip_act_space:                                                        # :417-426
+            x_coord = (x_coord / 2.0) + 0.5
+            y_coord = (y_coord / 2.0) + 0.5
+            if not self._delta_actions:
+                c2 = (c2 / 2.0) + 0.5
+                c3 = c3 * np.pi
+        if self._delta_actions:                                                         # :448-453
+            total_length = np.sqrt((c2) ** 2 + (c3) ** 2)
+            x_dir = c2 / (total_length + _EPS)
+            y_dir = c3 / (total_length + _EPS)
+        else:
+            x_dir = np.cos(c3)
+            y_dir = np.sin(c3)
+        x_dir_r = x_dir * self.reduce_factor                                            # :455-456
+        y_dir_r = y_dir * self.reduce_factor
+        if self._delta_actions:                                                         # :460-468
+            step = np.sqrt((x_dir_r) ** 2 + (y_dir_r) ** 2)
+            cur = np.zeros(self.E)
+            ii = np.zeros(self.E, dtype=np.int64)
+            alive = np.ones(self.E, dtype=bool)
+            guard = 0
+            while alive.any():
+                cur = cur + step
+                alive &= ~(cur >= total_length)
+                ii[alive] += 1
+                guard += 1
+                if guard > 1000000:
+                    raise FloatingPointError("iters_pull does not terminate (non-finite action?)")
+            iters_pull = ii
+        else:
+            iters_pull = (self.iters_pull_max * c2).astype(np.int64)                    # :470
+        iu = self._iters_up_env if iters_up is None else iters_up
+        b1 = iu
+        b2 = iu + self.iters_up_rest
+        b3 = iu + self.iters_up_rest + iters_pull
+        b4 = iu + self.iters_up_rest + iters_pull + self.iters_grip_rest
+        b5 = iu + self.iters_up_rest + iters_pull + self.iters_grip_rest + self.iters_rest
+        bounds = np.ceil(np.stack([b1, b2, b3, b4, b5], axis=1)).astype(np.int64)       # `i < b` == `i < ceil(b)`
+        return dict(x=x_coord, y=y_coord, x_dir_r=x_dir_r, y_dir_r=y_dir_r, iters_pull=iters_pull,
+                    bounds=bounds)
+
+    # ---- one action for every (active) env ----------------------------------------------------------------
+    def step(self, actions, initialize=False, active=None):
+        """ClothEnv.step (cloth_env.py:369-534) for all envs at once.
+        Returns (obs[E,3P], rew[E], done[E], info dict of arrays); with initialize=True returns None."""
+        E = self.E
+        act_mask = np.ones(E, dtype=bool) if active is None else np.asarray(active, dtype=bool).copy()
+        d = self.decode_actions(actions)
+        xy = np.stack([d['x'], d['y']], axis=1)
+        n_grab = self.batch.grab_top(xy, active=act_mask).astype(np.int64)              # :431
+        if self._force_grab:                                                            # :434-444
+            radius = np.full(E, float(self.grip_radius))
+            need = act_mask & (n_grab == 0)
+            while need.any():
+                radius[need] += self._radius_inc
+                n2 = self.batch.grab_top(xy, radius=radius, active=need)
+                n_grab[need] = n2[need]
+                need = need & (n_grab == 0)
+        exit_early = act_mask & (n_grab == 0)                                           # :490-493
+        run_mask = act_mask & ~exit_early
+        s = make_schedules(E, break_on_tear=1, dz_up=0.0025)                            # :359
+        b = d['bounds']
+        s['n_up_end'], s['n_uprest_end'], s['n_pull_end'] = b[:, 0], b[:, 1], b[:, 2]
+        s['n_griprest_end'], s['n_total'] = b[:, 3], b[:, 4]
+        s['dx_pull'], s['dy_pull'] = d['x_dir_r'], d['y_dir_r']
+        s['active'] = run_mask
+        executed = self.batch.run(s).astype(np.int64)
+        executed[~run_mask] = 0
+        self.total_substeps += int(executed.sum())
+        self.last_executed, self.last_grabbed, self.last_iters_pull = executed, n_grab, d['iters_pull']
+        cov, vinv, oob, tear = self.batch.metrics()
+        self.have_tear |= (run_mask & tear)                                             # :511-514
+        if initialize:                                                                  # :517-518
+            return None
+        self.num_sim_steps[act_mask] += executed[act_mask]
+        self.num_steps[act_mask] += 1
+        rew = self._reward(actions, exit_early, cov, vinv, oob, act_mask)
+        term = self._terminal(oob, act_mask)
+        info = {
+            'num_steps': self.num_steps.copy(), 'num_sim_steps': self.num_sim_steps.copy(),
+            'actual_coverage': self._current_coverage.copy(), 'start_coverage': self._start_coverage.copy(),
+            'variance_inv': vinv, 'start_variance_inv': self._start_variance_inv.copy(),
+            'have_tear': self.have_tear.copy(), 'out_of_bounds': oob,
+        }
+        return self.state, rew, term, info
+
+    # ---- reward / terminal (cloth_env.py:536-715) ------------------------------------------------------------
+    def _height_fraction(self):
+        z = self.batch.positions()[:, :, 2]
+        return np.sum(z < self.cfg['cloth']['thickness'] / 2.0, axis=1) / float(self.P)
+
+    def _reward(self, actions, exit_early, cov, vinv, oob, mask):
+        E = self.E
+        rew = np.zeros(E)
+        rew += np.where(self.have_tear, self._tear_penalty, np.where(oob, self._oob_penalty, 0.0))   # :557-562
+        rew += np.where(exit_early, self._nogrip_penalty, 0.0)                                       # :563-565
+        if not self._clip_act_space:                                                                 # :579-593
+            a = np.asarray(actions, dtype=np.float64).reshape(E, 4)
+            low, high = self.action_space.low, self.action_space.high
+            diff = np.where(a < low, low - a, np.where(a > high, a - high, 0.0))
+            pen = -np.minimum(diff ** 2, self._act_pen_limit) * self._act_bound_factor
+            rew += pen.sum(axis=1)
+        self._current_coverage = np.where(mask, cov, self._current_coverage)                         # :647
+        rew += np.where(cov > _REWARD_THRESHOLDS['coverage'], self._cover_success, 0.0)              # :648-650
+        rew += self._neg_living_rew
+
+        def delta(val):
+            diff = val - self._prev_reward
+            self._prev_reward = np.where(mask, val, self._prev_reward)
+            return diff
+        rt = self.reward_type                                                                        # :656-679
+        if rt == 'coverage':
+            rew += cov
+        elif rt == 'coverage-delta':
+            rew += delta(cov)
+        elif rt == 'height':
+            rew += self._height_fraction()
+        elif rt == 'height-delta':
+            rew += delta(self._height_fraction())
+        elif rt == 'variance':
+            rew += vinv
+        elif rt == 'variance-delta':
+            rew += delta(vinv)
+        elif rt == 'folding-number':
+            raise NotImplementedError()
+        else:
+            raise ValueError(rt)
+        return np.where(mask, rew, 0.0)
+
+    def _terminal(self, oob, mask):
+        done = (self.num_steps >= self.max_actions) | self.have_tear | oob                           # :692-703
+        done |= self._current_coverage > _REWARD_THRESHOLDS[self.reward_type]                        # :706-710
+        return done & mask
+
+    def _compute_coverage(self):
+        return self.batch.metrics()[0]
+
+    def _compute_variance(self):
+        return self.batch.metrics()[1]
+
+    def _out_of_bounds(self):
+        return self.batch.metrics()[2]
+
+    def _convert_action_to_clip_space(self, a):                     # cloth_env.py:1207-1215, vectorised
+        a = np.asarray(a, dtype=np.float64)
+        if not self._clip_act_space:
+            return a
+        out = a.copy()
+        out[..., 0] = (a[..., 0] - 0.5) * 2
+        out[..., 1] = (a[..., 1] - 0.5) * 2
+        if not self._delta_actions:
+            out[..., 2] = (a[..., 2] - 0.5) * 2
+            out[..., 3] = a[..., 3] / np.pi
+        return out
+
+    def get_random_action(self, atype='over_xy_plane'):
+        """cloth_env.py:989-1018; [E,4]. NB the reference samples from the action space's own, unseeded RNG."""
+        if atype == 'over_xy_plane':
+            return np.stack([self.action_space.sample() for _ in range(self.E)])
+        raise ValueError(atype)
+
+    # ---- reset (cloth_env.py:717-987; cloth.pyx:75, :94-130) -------------------------------------------------
+    def _update_masked(self, n, mask):
+        s = make_schedules(self.E, n_griprest_end=n, n_total=n, break_on_tear=0)
+        s['active'] = mask
+        ex = self.batch.run(s)
+        self.total_substeps += int(ex[mask].sum())
+
+    def reset(self, mask=None):
+        """Reset the envs selected by `mask` (default all) and return the '1d' observation of ALL envs."""
+        E, P = self.E, self.P
+        m = np.ones(E, dtype=bool) if mask is None else np.asarray(mask, dtype=bool)
+        idx = np.nonzero(m)[0]
+        tier = {'tier1': 1, 'tier2': 2, 'tier3': 3}.get(self._init_type)
+        if tier is None:
+            raise ValueError(self._init_type)                         # cloth.pyx:131-132
+        if not self._delta_actions:
+            raise NotImplementedError()                               # cloth_env.py:862, :917, :968
+        # ---- Cloth(...) construction: RNG draws in the reference's order (cloth.pyx:75, :101) --------------
+        pos0, rest0 = self.batch.init_grid(1)
+        pos_all = np.empty((len(idx), P, 3))
+        rest_all = np.empty((len(idx), self.batch.S)) if tier == 2 else None
+        for k, e in enumerate(idx):
+            rng = self.np_randoms[e]
+            self.init_side[e] = rng.rand() > 0.5
+            if tier == 2:
+                draws = rng.rand(P)                                   # one rand() per point, r-major
+                pos_all[k], rest_all[k] = self.batch.init_grid(2, self.init_side[e], draws)
+            else:
+                pos_all[k] = pos0
+        zeros_pin = np.zeros((1, P), dtype=np.uint8)
+        if len(idx) == E:                                             # whole batch: one upload
+            self.batch.set_state(pos_all, pos_all, np.zeros((E, P), dtype=np.uint8),
+                                 rest_all if tier == 2 else rest0, rest_shared=(tier != 2))
+        else:
+            for k, e in enumerate(idx):
+                self.batch.set_state(pos_all[k][None], pos_all[k][None], zeros_pin,
+                                     rest_all[k][None] if tier == 2 else None, env0=int(e), n=1,
+                                     rest_shared=False)
+        t = self.batch.tear
+        t[m] = False
+        self.batch.tear = t
+        self.num_steps[m] = 0
+        self.num_sim_steps[m] = 0
+        self.have_tear[m] = False
+        self._iters_up_env[m] = float(self.iters_up)
+        self._reset_actions(m, idx, tier)
+        cov, vinv, _, _ = self.batch.metrics()                        # cloth_env.py:780-782
+        self._prev_reward = np.where(m, cov, self._prev_reward)
+        self._start_coverage = np.where(m, cov, self._start_coverage)
+        self._start_variance_inv = np.where(m, vinv, self._start_variance_inv)
+        self._current_coverage = np.where(m, 0.0, self._current_coverage)
+        if self._consume_domrand:                                     # cloth_env.py:786-789 advance the env RNG
+            for e in idx:
+                rng = self.np_randoms[e]
+                rng.uniform(low=40, high=50)
+                rng.uniform(low=0.7, high=1.3)
+                lim = rng.uniform(low=-15.0, high=15.0)
+                rng.uniform(low=-lim, high=lim, size=(self._wd, self._hd, 3))
+        return self.state
+
+    @staticmethod
+    def _randval_minabs(rng, low, high, minabs=None):                 # cloth_env.py:824-832
+        val = rng.uniform(low=low, high=high)
+        if minabs is not None:
+            assert minabs > 0, minabs
+            assert low < -minabs or high > minabs
+            while np.abs(val) < minabs:
+                val = rng.uniform(low=low, high=high)
+        return val
+
+    @staticmethod
+    def _prevent_oob(val, dval, lower=0.0, upper=1.0):                # cloth_env.py:834-840
+        if val + dval < lower:
+            dval = lower - val
+        elif val + dval > upper:
+            dval = upper - val
+        return dval
+
+    def _reset_actions(self, m, idx, tier):
+        E = self.E
+        acts = np.zeros((E, 4))
+        if tier == 1:                                                 # cloth_env.py:843-891
+            lim = 0.20
+            for pull in range(3):
+                if pull < 2:
+                    who = idx
+                else:
+                    cov = self.batch.metrics()[0]
+                    who = np.array([e for e in idx if cov[e] >= 0.90], dtype=np.int64)
+                    if len(who) == 0:
+                        break
+                pos = self.batch.positions()
+                sel = np.zeros(E, dtype=bool)
+                for e in who:
+                    rng = self.np_randoms[e]
+                    p = pos[e, rng.randint(self.P)]
+                    dx0 = self._randval_minabs(rng, -lim, lim, 0.08)
+                    dy0 = self._randval_minabs(rng, -lim, lim, 0.08)
+                    dx0 = self._prevent_oob(p[0], dx0)
+                    dy0 = self._prevent_oob(p[1], dy0)
+                    acts[e] = (p[0], p[1], dx0, dy0)
+                    sel[e] = True
+                self.step(self._convert_action_to_clip_space(acts), initialize=True, active=sel)
+        elif tier == 2:                                               # cloth_env.py:893-949
+            self._update_masked(1500, m)
+            pos = self.batch.positions()
+            choice = {}
+            sel = np.zeros(E, dtype=bool)
+            for e in idx:
+                rng = self.np_randoms[e]
+                side = 1 if self.init_side[e] else -1
+                pi = -25 if rng.rand() < 0.5 else -1
+                choice[e] = pi
+                p0 = pos[e, pi]
+                dx0 = rng.uniform(0.30, 0.50) * side
+                dy0 = rng.uniform(0.30, 0.60) if pi == -25 else rng.uniform(-0.60, -0.30)
+                acts[e] = (p0[0], p0[1], dx0, dy0)
+                sel[e] = True
+            self.step(self._convert_action_to_clip_space(acts), initialize=True, active=sel)
+            pos = self.batch.positions()
+            for e in idx:
+                rng = self.np_randoms[e]
+                side = 1 if self.init_side[e] else -1
+                if choice[e] == -25:
+                    p1 = pos[e, -19]
+                    dx1 = rng.uniform(0.30, 0.60) * side
+                    dy1 = rng.uniform(-0.30, -0.60)
+                else:
+                    p1 = pos[e, -7]
+                    dx1 = rng.uniform(0.30, 0.60) * side
+                    dy1 = rng.uniform(0.30, 0.60)
+                acts[e] = (p1[0], p1[1], dx1, dy1)
+            self.step(self._convert_action_to_clip_space(acts), initialize=True, active=sel)
+            self._update_masked(500, m)
+        elif tier == 3:                                               # cloth_env.py:951-982
+            lim = 0.25
+            sel = np.zeros(E, dtype=bool)
+            for e in idx:
+                rng = self.np_randoms[e]
+                self._iters_up_env[e] = rng.uniform(low=200, high=280)
+                p0x = self._randval_minabs(rng, 0.30, 0.70)
+                p0y = self._randval_minabs(rng, 0.30, 0.70)
+                dx0 = self._randval_minabs(rng, -lim, lim, 0.10)
+                dy0 = self._randval_minabs(rng, -lim, lim, 0.10)
+                dx0 = self._prevent_oob(p0x, dx0)
+                dy0 = self._prevent_oob(p0y, dy0)
+                acts[e] = (p0x, p0y, dx0, dy0)
+                sel[e] = True
+            self.step(self._convert_action_to_clip_space(acts), initialize=True, active=sel)
+            self._update_masked(800, m)
+            self._iters_up_env[m] = float(self.iters_up)
+
+
+class ClothEnv(object):
+    """The reference's single-environment API (cloth_env.py:55): same constructor signature, seed/reset/
+    step/state/get_random_action, same return types (scalars, dict of scalars)."""
+    metadata = {'render.modes': ['human']}
+
+    def __init__(self, cfg_file, subrank=None, start_state_path=None, device=0, precision='f32'):
+        self._vec = ClothVecEnv(cfg_file, n_envs=1, device=device, precision=precision)
+        v = self._vec
+        self.cfg, self.cfg_file = v.cfg, cfg_file
+        self._logger_idx = subrank
+        self._start_state = None
+        if start_state_path is not None:                              # npz instead of the reference's pickle
+            with np.load(start_state_path) as d:
+                self._start_state = {k: d[k] for k in d.files}
+        for k in ('max_actions', 'iters_up', 'iters_up_rest', 'iters_pull_max', 'iters_grip_rest', 'iters_rest',
+                  'reduce_factor', 'grip_radius', 'bounds', 'reward_type', 'num_w', 'num_h', 'num_points',
+                  'observation_space', 'action_space', 'obslow', 'obshigh'):
+            setattr(self, k, getattr(v, k))
+        from .physics import Cloth, Gripper
+        self.cloth = Cloth(batch=v.batch, env=0, owner=v)
+        self.gripper = Gripper(self.cloth, self.grip_radius, self.cfg['cloth']['height'],
+                               self.cfg['cloth']['thickness'])
+
+    def close(self):
+        self._vec.close()
+
+    @property
+    def np_random(self):
+        return self._vec.np_randoms[0]
+
+    def seed(self, seed=None):
+        return self._vec.seed([seed])
+
+    @property
+    def state(self):
+        return self._vec.state[0]
+
+    @property
+    def num_steps(self):
+        return int(self._vec.num_steps[0])
+
+    @property
+    def num_sim_steps(self):
+        return int(self._vec.num_sim_steps[0])
+
+    @property
+    def have_tear(self):
+        return bool(self._vec.have_tear[0])
+
+    def reset(self):
+        self.cloth._invalidate()
+        if self._start_state is not None:                             # cloth_env.py:736-741, :771-772
+            s = self._start_state
+            v = self._vec
+            v.batch.set_state(s['pos'][None], s['prev'][None], s['pinned'][None],
+                              s['rest'] if 'rest' in s else None)
+            v.batch.tear = [False]
+            v.num_steps[:] = 0; v.num_sim_steps[:] = 0; v.have_tear[:] = False
+            cov, vinv, _, _ = v.batch.metrics()
+            v._prev_reward[:] = cov; v._start_coverage[:] = cov; v._start_variance_inv[:] = vinv
+            return self.state
+        obs = self._vec.reset()[0]
+        self.cloth.init_side = bool(self._vec.init_side[0])
+        return obs
+
+    def step(self, action, initialize=False):
+        self.cloth._invalidate()
+        out = self._vec.step(np.asarray(action, dtype=np.float64)[None], initialize=initialize)
+        if out is None:
+            return None
+        obs, rew, done, info = out
+        info1 = {k: (v[0].item() if hasattr(v[0], 'item') else v[0]) for k, v in info.items()}
+        return obs[0], float(rew[0]), bool(done[0]), info1
+
+    def get_random_action(self, atype='over_xy_plane'):
+        if atype == 'over_xy_plane':
+            return self.action_space.sample()
+        raise ValueError(atype)
+
+    def save_state(self, cloth_file):
+        """cloth_env.py:343-350 (npz of SoA arrays instead of a pickle of Python objects)."""
+        pos, prev, pin = self._vec.batch.get_state()
+        np.savez(cloth_file, pos=pos[0], prev=prev[0], pinned=pin[0])
+
+    def _compute_coverage(self):
+        return float(self._vec._compute_coverage()[0])
+
+    def _compute_variance(self):
+        return float(self._vec._compute_variance()[0])
+
+    def _out_of_bounds(self):
+        return bool(self._vec._out_of_bounds()[0])
+
+    def _convert_action_to_clip_space(self, a):
+        return tuple(self._vec._convert_action_to_clip_space(np.asarray(a, dtype=np.float64)))
+
+    def render(self, *a, **k):
+        """The OpenGL viewer / Blender renderer are out of scope (components 7, 13)."""
+        return None

@@ -1,0 +1,224 @@
+"""Single-cloth façade with the reference's object API (gym_cloth/physics/{cloth,point,gripper}.pyx):
+`Cloth.update()`, `.pts[i].x/.y/.z/.px/.py/.pz/.pinned/.orig_*`, `.allpts_arr`, `.have_tear`, `.init_side`,
+`Gripper.grab_top/grab/adjust/release/grabbed_pts/grip_radius`.
+
+The particle state lives on the GPU (one env of a ClothBatch).  Attribute reads go through a host mirror
+that is refreshed lazily after device work; attribute writes mark the mirror dirty and are flushed before
+the next device call.  This path exists for drop-in compatibility with code that pokes at `env.cloth.pts`
+(policies, cloth_env.py:854-937, examples/analytic.py:105-125); the throughput path is ClothBatch.run.
+"""
+import numpy as np
+
+from .batch import ClothBatch
+
+
+class Point(object):
+    """View of one particle (point.pyx:17-51)."""
+    __slots__ = ("_c", "_i")
+
+    def __init__(self, cloth, i):
+        self._c, self._i = cloth, i
+
+    def _get(self, arr, ax):
+        return float(getattr(self._c._host(), arr)[self._i, ax])
+
+    def _set(self, arr, ax, v):
+        getattr(self._c._host(), arr)[self._i, ax] = v
+        self._c._dirty = True
+
+    x = property(lambda s: s._get("pos", 0), lambda s, v: s._set("pos", 0, v))
+    y = property(lambda s: s._get("pos", 1), lambda s, v: s._set("pos", 1, v))
+    z = property(lambda s: s._get("pos", 2), lambda s, v: s._set("pos", 2, v))
+    px = property(lambda s: s._get("prev", 0), lambda s, v: s._set("prev", 0, v))
+    py = property(lambda s: s._get("prev", 1), lambda s, v: s._set("prev", 1, v))
+    pz = property(lambda s: s._get("prev", 2), lambda s, v: s._set("prev", 2, v))
+    orig_x = property(lambda s: float(s._c._orig[s._i, 0]))
+    orig_y = property(lambda s: float(s._c._orig[s._i, 1]))
+    orig_z = property(lambda s: float(s._c._orig[s._i, 2]))
+    identity_0 = property(lambda s: float(s._i // s._c.width))
+    identity_1 = property(lambda s: float(s._i % s._c.width))
+
+    @property
+    def pinned(self):
+        return bool(self._c._host().pinned[self._i])
+
+    @pinned.setter
+    def pinned(self, v):
+        h = self._c._host()
+        if v and not h.pinned[self._i]:
+            self._c._flush()
+            self._c.batch.pin_points(self._c.env, [self._i])      # pinned, not a member of grabbed_pts
+            self._c._invalidate()
+        elif not v and h.pinned[self._i]:
+            h.pinned[self._i] = 0
+            self._c._dirty = True
+
+    def __repr__(self):
+        return "({:.3f}, {:.3f}, {:.3f})".format(self.x, self.y, self.z)     # point.pyx:53-55
+
+
+class _Mirror(object):
+    __slots__ = ("pos", "prev", "pinned")
+
+
+class Cloth(object):
+    """cloth.pyx:21. Construct either like the reference, Cloth(params=cfg, random_state=rng), which owns a
+    one-env ClothBatch, or as a view of env `env` of an existing batch."""
+
+    def __init__(self, gravity=-9.8, bounds=(1, 1, 1), minimum_z=0, params=None, render=False,
+                 render_port=5556, random_state=None, state=None, batch=None, env=0, owner=None,
+                 device=0, precision="f64"):
+        if render:
+            raise ValueError("render=True (ZeroMQ viewer feed, cloth.pyx:377-388) is out of scope")
+        self._owner = owner
+        if batch is None:
+            if params is None:
+                raise ValueError("params (cfg dict) is required")
+            pin_cond = params['cloth'].get('pin_cond', 'default')
+            if pin_cond not in ("y=0", "x=0,y=0", "y=0,x=0", "default"):
+                raise ValueError(pin_cond)                                  # cloth.pyx:85
+            if params['cloth'].get('color_pts', 'None') not in ('None', 'circle0', 'diag0', 'diag1'):
+                raise ValueError(params['cloth']['color_pts'])              # cloth.pyx:161
+            batch = ClothBatch(params, n_envs=1, device=device, precision=precision, gravity=gravity,
+                               minimum_z=float(minimum_z))
+            self.params = params
+            if random_state is None:
+                from . import seeding
+                random_state, _ = seeding.np_random(params['seed'])         # cloth.pyx:67-73
+            self.np_random = random_state
+            self.init_type = params['init']['type']
+            self.init_side = bool(random_state.rand() > 0.5)                # cloth.pyx:75
+            tier = {'tier1': 1, 'tier2': 2, 'tier3': 3}.get(self.init_type)
+            if tier is None:
+                raise ValueError(self.init_type)                            # cloth.pyx:131-132
+            if state is not None:
+                batch.set_state(state['pos'][None], state['prev'][None], state['pinned'][None],
+                                state.get('rest'))
+            else:
+                draws = random_state.rand(batch.P) if tier == 2 else None
+                pos, rest = batch.init_grid(tier, self.init_side, draws)
+                batch.set_state(pos[None], pos[None], np.zeros((1, batch.P), dtype=np.uint8), rest)
+        else:
+            self.params = batch.cfg
+            self.init_side = False
+        self.batch, self.env = batch, int(env)
+        self.width = self.height = batch.N
+        self.dx = batch.params.width * 1.0 / (batch.N - 1)
+        self.dy = batch.params.height * 1.0 / (batch.N - 1)
+        self.bounds, self.minimum_z, self.gravity = bounds, minimum_z, gravity
+        self.render = False
+        self.iter = 0
+        self._mirror, self._dirty = None, False
+        self._orig = batch.positions(self.env, 1)[0].copy()
+        self._pts = [Point(self, i) for i in range(batch.P)]
+
+    # ---- host mirror ---------------------------------------------------------------------------------
+    def _host(self):
+        if self._mirror is None:
+            m = _Mirror()
+            pos, prev, pin = self.batch.get_state(self.env, 1)
+            m.pos, m.prev, m.pinned = pos[0], prev[0], pin[0]
+            self._mirror = m
+        return self._mirror
+
+    def _flush(self):
+        if self._dirty and self._mirror is not None:
+            m = self._mirror
+            # NB set_state marks pinned points as grabbed; keep device-side pin bookkeeping when unchanged
+            self.batch.set_state(m.pos[None], m.prev[None], None, None, env0=self.env, n=1)
+        self._dirty = False
+
+    def _invalidate(self):
+        self._mirror, self._dirty = None, False
+
+    # ---- reference API -----------------------------------------------------------------------------------
+    @property
+    def pts(self):
+        return self._pts
+
+    def update(self):
+        """Cloth.update (cloth.pyx:169-214) on this cloth only."""
+        self._flush()
+        if self.batch.E == 1:
+            self.batch.update(1)
+        else:
+            from .batch import make_schedules
+            s = make_schedules(self.batch.E, n_griprest_end=1, n_total=1)
+            s['active'][self.env] = 1
+            self.batch.run(s)
+        self._invalidate()
+        self.iter += 1
+
+    @property
+    def have_tear(self):
+        return bool(self.batch.tear[self.env])
+
+    @property
+    def allpts_arr(self):
+        return self._host().pos.copy()
+
+    @property
+    def pinnedpts_arr(self):
+        h = self._host()
+        return h.pos[h.pinned.astype(bool)].copy()
+
+    def stop_render(self):
+        pass
+
+
+class Gripper(object):
+    """gripper.pyx:8. Acts on one env of the batch through the device kernels."""
+
+    def __init__(self, cloth, grip_radius, height, thickness):
+        self.cloth, self.grip_radius = cloth, grip_radius
+        self.height, self.thickness = height, thickness
+        self._grabbed = []
+
+    def _mask(self):
+        m = np.zeros(self.cloth.batch.E, dtype=np.uint8)
+        m[self.cloth.env] = 1
+        return m
+
+    def _after_grab(self, before):
+        self.cloth._invalidate()
+        after = self.cloth._host().pinned.astype(bool)
+        new = np.nonzero(after & ~before)[0]
+        self._grabbed.extend(self.cloth.pts[i] for i in new)
+
+    @property
+    def grabbed_pts(self):
+        return self._grabbed
+
+    def grab_top(self, x, y):
+        c = self.cloth
+        c._flush()
+        before = c._host().pinned.astype(bool)
+        b = c.batch
+        b.grab_top(np.broadcast_to([x, y], (b.E, 2)), radius=np.full(b.E, float(self.grip_radius)),
+                   active=self._mask())
+        self._after_grab(before)
+
+    def grab(self, x, y):
+        c = self.cloth
+        c._flush()
+        before = c._host().pinned.astype(bool)
+        b = c.batch
+        b.grab(np.broadcast_to([x, y], (b.E, 2)), radius=np.full(b.E, float(self.grip_radius)),
+               active=self._mask())
+        self._after_grab(before)
+
+    def adjust(self, x, y, z):
+        """gripper.pyx:55-66 on the host mirror (compatibility path; ClothBatch.run fuses it on the device)."""
+        h = self.cloth._host()
+        for pt in self._grabbed:
+            i = pt._i
+            h.prev[i] = h.pos[i]
+            h.pos[i] = np.array([x, y, z]) + h.pos[i]
+        if self._grabbed:
+            self.cloth._dirty = True
+
+    def release(self):
+        self.cloth._flush()
+        self.cloth.batch.release(active=self._mask())
+        self.cloth._invalidate()
+        self._grabbed = []

@@ -145,6 +145,18 @@ int clothhip_sync(clothhip_handle *h, int32_t *executed);
  * preceded each time by Gripper.adjust(delta) when delta != NULL ([3] doubles, same for all envs). */
 int clothhip_update(clothhip_handle *h, int32_t n_sub, const double *delta);
 
+/* Per-env quantities ClothEnv derives from the particle positions after every action:
+ *   coverage[E]      area of the 2-D convex hull of (clip(x,0,1), clip(y,0,1))  (cloth_env.py:628-638, :1086-1098;
+ *                    the reference calls scipy.spatial.ConvexHull(points).volume; 0.0 for a degenerate hull)
+ *   variance_inv[E]  1000 if var(z) < 1e-6 else 0.001/var(z)                     (cloth_env.py:1075-1084)
+ *   oob[E]           out-of-bounds test with slack 0.25 on x,y and [0,1) on z    (cloth_env.py:1020-1045)
+ *   tear[E]          Cloth.have_tear
+ * Any pointer may be NULL. */
+int clothhip_metrics(clothhip_handle *h, double *coverage, double *variance_inv, uint8_t *oob, uint8_t *tear);
+/* the same hull-area routine on caller-supplied points xy[n][2] (pure host function; used by tests to pin it
+ * against scipy's Qhull on the golden states) */
+double clothhip_hull_area(const double *xy, int32_t n);
+
 /* Device-resident observation path for the multi-GPU driver: writes the '1d' observation
  * (cloth_env.py:196-200: [x0,y0,z0,x1,...] per env) of every env as float32 into a DEVICE buffer
  * d_out[E][3P] (e.g. a torch/RCCL gather buffer). Asynchronous on the handle's stream. */

@@ -1,0 +1,119 @@
+"""GPU tests of the env layer (ClothEnv / ClothVecEnv over the HIP stepper) against env-level goldens
+captured from the real reference's ClothEnv (tests/golden/make_golden.py::env_fixture)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def base_cfg(tier, seed):
+    return {
+        "cloth": {"damping": 2.0, "density": 200.0, "ks": 10000.0, "width": 1, "height": 1,
+                  "num_width_points": 25, "num_height_points": 25, "thickness": 0.02, "pin_cond": "y=0",
+                  "color_pts": "diag1", "plane_friction": 1.0, "tear_thresh": 2.0},
+        "frames_per_sec": 30, "simulation_steps": 30,
+        "env": {"max_actions": 10, "max_z_threshold": 5, "iters_up": 50, "iters_up_rest": 80,
+                "iters_pull_max": 400, "iters_grip_rest": 300, "iters_rest": 1000, "updates_per_move": 1,
+                "reduce_factor": 0.002, "grip_radius": 0.003, "reward_type": "coverage-delta",
+                "force_grab": False, "clip_act_space": True, "delta_actions": True, "obs_type": "1d",
+                "oracle_reveal": "False", "use_depth": "False", "use_dom_rand": "True", "use_rgbd": "True"},
+        "init": {"type": tier, "debug_matplotlib": False, "render_opengl": False},
+        "log": {"level": "info", "file": "logs/x.log"}, "seed": seed}
+
+
+@pytest.mark.parametrize("fixture,tier,seed", [
+    ("g_env_tier1_1337.npz", "tier1", 1337), ("g_env_tier2_1337.npz", "tier2", 1337),
+    ("g_env_tier2_1338.npz", "tier2", 1338), ("g_env_tier3_1337.npz", "tier3", 1337),
+    ("g_env_tier3_1339.npz", "tier3", 1339)])
+def test_reset_matches_reference_f64(fixture, tier, seed, oracle_lib):
+    """ClothEnv.seed(s); reset() in fp64 reproduces the reference's reset bit for bit: RNG sequence, scripted
+    reset actions, number of update() calls, post-reset particle state, start coverage / variance."""
+    from gym_cloth_amd.envs import ClothEnv
+    g = oracle_lib.load_golden(fixture)
+    env = ClothEnv(base_cfg(tier, seed), precision="f64")
+    env.seed(seed)
+    v = env._vec
+    calls = []
+    orig_step = v.step
+
+    def spy(actions, initialize=False, active=None):
+        out = orig_step(actions, initialize=initialize, active=active)
+        calls.append((np.array(actions)[0].copy(), int(v.last_executed[0])))
+        return out
+    v.step = spy
+    obs = env.reset()
+    nreset = int(g["n_reset_calls"])
+    assert len(calls) == nreset
+    for k in range(nreset):
+        assert np.array_equal(calls[k][0], g["act"][k]), (k, calls[k][0], g["act"][k])
+        assert calls[k][1] == int(g["act_n_updates"][k])
+    pos, prev, pin = v.batch.get_state()
+    assert bool(v.init_side[0]) == bool(g["init_side"])
+    assert np.array_equal(pos[0], g["post_pos"]) and np.array_equal(prev[0], g["post_prev"])
+    assert np.array_equal(obs, g["reset_obs"])
+    assert abs(v._start_coverage[0] - float(g["start_coverage"])) <= 1e-12
+    assert abs(v._start_variance_inv[0] - float(g["start_variance_inv"])) <= 1e-9 * float(g["start_variance_inv"])
+    env.close()
+
+
+def test_tier1_episode_matches_reference_f64(oracle_lib):
+    """The reference's oracle-corner episode (seed 1337, tier 1): replaying its action through ClothEnv.step in
+    fp64 gives the same substep count, bit-identical final particles, and the same reward/done/info."""
+    from gym_cloth_amd.envs import ClothEnv
+    g = oracle_lib.load_golden("g_env_tier1_1337.npz")
+    env = ClothEnv(base_cfg("tier1", 1337), precision="f64")
+    env.seed(1337)
+    env.reset()
+    nreset = int(g["n_reset_calls"])
+    for k in range(nreset, len(g["act"])):
+        obs, rew, done, info = env.step(g["act"][k])
+        j = k - nreset
+        assert np.array_equal(obs.reshape(-1, 3), g["act_pos1"][k])
+        assert abs(rew - g["rew"][j]) <= 1e-12
+        assert done == bool(g["done"][j])
+        ref = g["info"][j]
+        assert info["num_sim_steps"] == ref["num_sim_steps"] and info["num_steps"] == ref["num_steps"]
+        assert abs(info["actual_coverage"] - ref["actual_coverage"]) <= 1e-12
+        assert info["have_tear"] == ref["have_tear"] and info["out_of_bounds"] == ref["out_of_bounds"]
+        assert abs(info["variance_inv"] - ref["variance_inv"]) <= 1e-9 * ref["variance_inv"]
+    env.close()
+
+
+def test_tier1_episode_outcome_f32(oracle_lib):
+    """fp32: long-horizon agreement is stated on outcomes (SURVEY 7-H2 iii): same substep counts, coverage
+    within 2e-2 of the reference after reset (~3100 substeps) and after the episode action."""
+    from gym_cloth_amd.envs import ClothEnv
+    g = oracle_lib.load_golden("g_env_tier1_1337.npz")
+    env = ClothEnv(base_cfg("tier1", 1337), precision="f32")
+    env.seed(1337)
+    env.reset()
+    assert abs(env._vec._start_coverage[0] - float(g["start_coverage"])) <= 2e-2
+    k = int(g["n_reset_calls"])
+    obs, rew, done, info = env.step(g["act"][k])
+    ref = g["info"][0]
+    assert info["num_sim_steps"] == ref["num_sim_steps"]
+    assert abs(info["actual_coverage"] - ref["actual_coverage"]) <= 2e-2
+    assert done == bool(g["done"][0])
+    env.close()
+
+
+def test_physics_facade_matches_oracle(oracle_lib):
+    """The reference-shaped object API (Cloth.update / pts[i].x / Gripper.*) over the device state."""
+    from gym_cloth_amd.physics import Cloth, Gripper
+    cfg = base_cfg("tier1", 3)
+    c = Cloth(params=cfg, random_state=np.random.RandomState(3), precision="f64")
+    gr = Gripper(c, cfg["env"]["grip_radius"], cfg["cloth"]["height"], cfg["cloth"]["thickness"])
+    gcfg = oracle_lib.load_golden("g_traj_lift_pull_25.npz")["cfg"]
+    oc = oracle_lib.OracleCloth(gcfg)
+    gr.grab_top(0.5, 0.5); oc.grab_top(0.5, 0.5)
+    assert sorted(p._i for p in gr.grabbed_pts) == sorted(oc.grabbed.tolist()) == [287, 311, 312, 313, 337]
+    for _ in range(5):
+        gr.adjust(0.0, 0.0, 0.0025); c.update()
+        oc.adjust(0.0, 0.0, 0.0025); oc.update(1)
+    assert np.array_equal(c.allpts_arr, oc.get_state()[0])
+    assert c.pts[312].pinned and c.pts[312].z == oc.get_state()[0][312, 2]
+    gr.release(); oc.release()
+    c.update(); oc.update(1)
+    assert np.array_equal(c.allpts_arr, oc.get_state()[0]) and not c.have_tear
