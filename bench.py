@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- cloth-substeps/s of the HIP stepper on BASELINE.json's batched workload.
+
+Workload (BASELINE.json configs[2], SURVEY.md 8d "C3"; weak-scaled to configs[3]'s 512 envs per GPU):
+  E = 512 cloths of 25x25 per GPU, tier-1 start (flat grid + two scripted reset pulls drawn per env as in
+  cloth_env.py:851-877 from RandomState(1000+e)), then one random pick-and-place action per env per step,
+  a ~ U(-1,1)^4 in clip space from RandomState(2000+e), delta actions.
+A "step" = ClothVecEnv.step over the whole batch = Gripper.grab_top + the fused schedule kernel
+(~1430 + iters_pull substeps per env, cloth_env.py:472-515) + metrics.  State is resident in HBM; the timed
+region contains no state upload.  value = executed Cloth.update()-equivalents (all envs, all ranks) / wall time.
+
+Multi-GPU (one process per GPU, torch.distributed 'nccl' = RCCL over xGMI): env blocks are sharded, rank 0's
+action table is broadcast every step and per-env results are all-gathered; there is no other collective
+because cloths never interact.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def bench_cfg(n_side, thickness):
+    return {
+        "cloth": {"damping": 2.0, "density": 200.0, "ks": 10000.0, "width": 1, "height": 1,
+                  "num_width_points": n_side, "num_height_points": n_side, "thickness": thickness,
+                  "pin_cond": "y=0", "color_pts": "None", "plane_friction": 1.0, "tear_thresh": 2.0},
+        "frames_per_sec": 30, "simulation_steps": 30,
+        "env": {"max_actions": 10, "max_z_threshold": 5, "iters_up": 50, "iters_up_rest": 80,
+                "iters_pull_max": 400, "iters_grip_rest": 300, "iters_rest": 1000, "updates_per_move": 1,
+                "reduce_factor": 0.002, "grip_radius": 0.003, "reward_type": "coverage-delta",
+                "force_grab": False, "clip_act_space": True, "delta_actions": True, "obs_type": "1d",
+                "oracle_reveal": "False", "use_depth": "False", "use_dom_rand": "False", "use_rgbd": "False"},
+        "init": {"type": "tier1", "debug_matplotlib": False, "render_opengl": False},
+        "log": {"level": "info", "file": "logs/bench.log"}, "seed": 1000}
+
+
+def cpu_baseline(cfg, acts0, budget_s=15.0):
+    """The CPU oracle (oracle/, exact-order fp64 C port of the reference) timed on this box's host cores on a
+    bounded sample of the same workload: flat cloths + the first timed action of the first n envs."""
+    from oracle import pyoracle
+    pyoracle.build()
+    cores = len(os.sched_getaffinity(0))
+    threads = min(cores, pyoracle.lib().oracle_max_threads())
+    c = cfg["cloth"]
+    ocfg = {"n_side": c["num_width_points"], "width": c["width"], "height": c["height"], "density": c["density"],
+            "ks": c["ks"], "damping": c["damping"], "thickness": c["thickness"],
+            "plane_friction": c["plane_friction"], "tear_thresh": c["tear_thresh"],
+            "frames_per_sec": cfg["frames_per_sec"], "simulation_steps": cfg["simulation_steps"],
+            "gravity": -9.8, "minimum_z": 0.0, "grip_radius": cfg["env"]["grip_radius"]}
+    # ~70 us per 25x25 substep per core -> size the sample for ~budget_s of wall time
+    per_sub = 70e-6 * (c["num_width_points"] ** 2) / 625.0
+    n = int(max(threads, min(len(acts0), budget_s * threads / (1600 * per_sub))))
+    n = max(threads, (n // threads) * threads)
+    n = min(n, len(acts0))
+    from gym_cloth_amd.envs import _EPS
+    cloths, sched, delta = [], np.zeros((n, 5), dtype=np.int32), np.zeros((n, 3))
+    e = cfg["env"]
+    for k in range(n):
+        oc = pyoracle.OracleCloth(ocfg)
+        a = np.clip(acts0[k], -1, 1)
+        x, y = a[0] / 2 + 0.5, a[1] / 2 + 0.5
+        L = np.sqrt(a[2] ** 2 + a[3] ** 2)
+        xr, yr = a[2] / (L + _EPS) * e["reduce_factor"], a[3] / (L + _EPS) * e["reduce_factor"]
+        step, cur, ii = np.sqrt(xr ** 2 + yr ** 2), 0.0, 0
+        while True:
+            cur += step
+            if cur >= L:
+                break
+            ii += 1
+        ng = oc.grab_top(x, y)
+        b = np.cumsum([e["iters_up"], e["iters_up_rest"], ii, e["iters_grip_rest"], e["iters_rest"]])
+        sched[k] = b if ng > 0 else 0
+        delta[k] = (0.0025, xr, yr)
+        cloths.append(oc)
+    t0 = time.perf_counter()
+    ex = pyoracle.batch_run_schedule(cloths, sched, delta, True, threads)
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()                                # single-core figure on a small slice
+    n1 = min(2, n)
+    ex1 = pyoracle.batch_run_schedule([pyoracle.OracleCloth(ocfg) for _ in range(n1)],
+                                      np.tile([0, 0, 0, 400, 400], (n1, 1)), np.zeros((n1, 3)), False, 1)
+    dt1 = time.perf_counter() - t1
+    return {"value": float(ex.sum() / dt), "unit": "cloth-substeps/s", "cores": int(threads), "kind": "port",
+            "sample": "%d flat %dx%d cloths x first bench action (%d substeps total), OpenMP one cloth per thread"
+                      % (n, c["num_width_points"], c["num_width_points"], int(ex.sum())),
+            "single_core_value": float(ex1.sum() / dt1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--envs", type=int, default=512, help="cloths per GPU")
+    ap.add_argument("--n-side", type=int, default=25)
+    ap.add_argument("--thickness", type=float, default=None)
+    ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--gather-obs", action="store_true", help="all-gather the '1d' observations every step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from gym_cloth_amd.envs import ClothVecEnv
+
+    E = args.envs
+    thickness = args.thickness if args.thickness is not None else (0.02 if args.n_side <= 25 else 0.0095)
+    cfg = bench_cfg(args.n_side, thickness)
+    env = ClothVecEnv(cfg, n_envs=E, device=local_rank, precision=args.precision, consume_domrand_draws=False)
+    g0 = rank * E                                            # first global env index of this rank
+    for e in range(E):                                       # reset draws from RandomState(1000+e)
+        env.np_randoms[e] = np.random.RandomState(1000 + g0 + e)
+    env.reset()
+    total_steps = args.warmup + args.steps
+    P = env.P
+    if rank == 0:                                            # actions for ALL envs of the job, RandomState(2000+e)
+        acts_all = np.stack([np.random.RandomState(2000 + e).uniform(-1, 1, size=(total_steps, 4))
+                             for e in range(world * E)], axis=1)          # [steps, world*E, 4]
+    else:
+        acts_all = None
+
+    if dist is not None:
+        import torch
+        dev = torch.device("cuda", local_rank)
+        act_buf = torch.empty((world * E, 4), dtype=torch.float64, device=dev)
+        res_loc = torch.empty((E, 4), dtype=torch.float64, device=dev)
+        res_all = torch.empty((world * E, 4), dtype=torch.float64, device=dev)
+        if args.gather_obs:
+            obs_loc = torch.empty((E, 3 * P), dtype=torch.float32, device=dev)
+            obs_all = torch.empty((world * E, 3 * P), dtype=torch.float32, device=dev)
+
+    def one_step(t):
+        if dist is not None:
+            if rank == 0:
+                act_buf.copy_(torch.from_numpy(acts_all[t]))
+            dist.broadcast(act_buf, src=0)                   # RCCL broadcast of the action table
+            a = act_buf[g0:g0 + E].cpu().numpy()
+        else:
+            a = acts_all[t]
+        obs, rew, done, info = env.step(a)
+        kms = env.batch.last_kernel_ms
+        if dist is not None:
+            res_loc.copy_(torch.from_numpy(np.stack([rew, done.astype(np.float64), info["actual_coverage"],
+                                                     env.last_executed.astype(np.float64)], axis=1)))
+            dist.all_gather_into_tensor(res_all, res_loc)    # RCCL gather of per-env results
+            if args.gather_obs:
+                env.batch.write_obs_f32_device(obs_loc.data_ptr())
+                env.batch.sync(False)
+                dist.all_gather_into_tensor(obs_all, obs_loc)
+        return int(env.last_executed.sum()), kms
+
+    def fence():
+        env.batch.sync(False)
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for t in range(args.warmup):
+        one_step(t)
+    fence()
+    t0 = time.perf_counter()
+    n_sub, k_ms, k_sub = 0, 0.0, 0
+    for t in range(args.warmup, total_steps):
+        s, kms = one_step(t)
+        n_sub += s
+        k_ms += kms
+        k_sub += s
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        ns = torch.tensor([n_sub], dtype=torch.float64, device=dev)
+        dist.all_reduce(ns, op=dist.ReduceOp.SUM)
+        n_sub_all = float(ns.item())
+    else:
+        n_sub_all = float(n_sub)
+
+    if rank == 0:
+        b_alg = 49 * P                                        # algorithmic bytes per cloth-substep (fp32)
+        ach = (k_sub * b_alg / 1e9) / (k_ms / 1e3) if k_ms > 0 else 0.0
+        out = {
+            "metric": "cloth substeps/sec (25x25 grid, batched envs)" if args.n_side == 25 else
+                      "cloth substeps/sec (%dx%d grid, batched envs)" % (args.n_side, args.n_side),
+            "value": n_sub_all / dt, "unit": "cloth-substeps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "%d batched %dx%d cloths per GPU, tier-1 start, random pick-and-place actions "
+                                   "(BASELINE configs[2]; configs[3] = 8 x this)" % (E, args.n_side, args.n_side),
+                       "envs_per_gpu": E, "n_side": args.n_side, "exact_order": True,
+                       "env_steps_per_s": world * E * args.steps / dt,
+                       "substeps_per_env_step": n_sub_all / (world * E * args.steps)},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_run_schedule", "kernel_ms_avg": k_ms / max(args.steps, 1),
+                         "alg_bytes_per_substep": b_alg},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, acts_all[args.warmup])
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    env.close()
+
+
+if __name__ == "__main__":
+    main()
