@@ -47,17 +47,23 @@ template <typename T> struct StepArgs {
     int32_t *executed;       // [E]
     const ClothSchedule *sched;   // [E]
     const uint32_t *gather;  // [HK_SLOTS][Ppad]
-    const uint32_t *lv_ent;  // [S]  ptA | ptB<<16, level order
-    const int32_t *lv_off;   // [n_levels+1]
+    const uint32_t *lv_ent;  // [Spad]  ptA | ptB<<16, level order
+    const uint16_t *lv_off;  // [n_levels+1]
+    const uint32_t *lv_rows; // [n_levels] bitmask of the grid-row groups a level touches
     int32_t n_levels;
-    int32_t N, P, Ppad, S, Spad, Psort;
+    int32_t N, P, Ppad, S, Spad;
+    int32_t HT, ht_bits;     // spatial hash table slots (power of two > P)
+    int32_t lvw_shift;       // lanes per level in the parallel pre-pass = 1 << lvw_shift (16 or 32)
     int32_t rest_stride;     // 0: one shared table
+    int32_t phase_mask;      // debug/ablation: bit0 hooke+verlet, bit1 collide, bit2 plane, bit3 strain, bit4 no-skip
     DevConsts<T> k;
 };
 
-constexpr uint32_t KEY_BIAS = 1u << 19;         // composite sort word = (key+bias) << 12 | point index
 constexpr int KEY_SHIFT = 12;
+constexpr uint32_t KEY_BIAS = 1u << 19;
+constexpr uint32_t KEY_EMPTY = 0xFFFFFFFFu;
 constexpr uint8_t CNT_GRAB_MASK = 0x7F, CNT_EXT_PIN = 0x80;
+enum { PH_HOOKE = 1, PH_COLLIDE = 2, PH_PLANE = 4, PH_STRAIN = 8, PH_NOSKIP = 16 };
 
 template <typename T> __device__ __forceinline__ T dev_sqrt(T x);
 template <> __device__ __forceinline__ double dev_sqrt<double>(double x) { return sqrt(x); }
@@ -65,6 +71,10 @@ template <> __device__ __forceinline__ float dev_sqrt<float>(float x) { return s
 template <typename T> __device__ __forceinline__ T dev_floor(T x);
 template <> __device__ __forceinline__ double dev_floor<double>(double x) { return floor(x); }
 template <> __device__ __forceinline__ float dev_floor<float>(float x) { return floorf(x); }
+// relative slack of the conservative "could this comparison against a sqrt be true" pre-filters
+template <typename T> __device__ __forceinline__ T filt_slack();
+template <> __device__ __forceinline__ double filt_slack<double>() { return 1e-9; }
+template <> __device__ __forceinline__ float filt_slack<float>() { return 1e-5f; }
 
 // cloth.pyx:17-18, association ((x*x + y*y) + z*z)
 template <typename T> __device__ __forceinline__ T fastnorm(T x, T y, T z) { return dev_sqrt<T>(x * x + y * y + z * z); }
@@ -84,50 +94,119 @@ template <typename T> __device__ __forceinline__ uint32_t cell_key(const DevCons
 }
 
 // LDS carve-up (dynamic shared memory), all offsets in bytes, 16-byte aligned
-template <typename T> struct LdsLayout {
-    int bufA, bufB, cnt, sortw, misc, total;
-    __host__ __device__ LdsLayout(int Ppad, int Psort) {
+struct LdsLayout {
+    int cur, cnt, ent, rest, off, rows, flag, hkey, hco, memb, slot, misc, total;
+    __host__ __device__ LdsLayout(int tsz, int Ppad, int Spad, int nL, int HT, bool tab_lds) {
         int o = 0;
-        bufA = o; o += 3 * Ppad * (int)sizeof(T);
-        bufB = o; o += 3 * Ppad * (int)sizeof(T);
-        cnt = o; o += (Ppad + 15) / 16 * 16;
-        sortw = o; o += Psort * 4;
-        misc = o; o += 64;
+        auto take = [&](int bytes) { int r = o; o += (bytes + 15) / 16 * 16; return r; };
+        cur = take(3 * Ppad * tsz);
+        cnt = take(Ppad);
+        ent = take(tab_lds ? Spad * 4 : 0);
+        rest = take(tab_lds ? Spad * tsz : 0);
+        off = take(tab_lds ? (nL + 1) * 2 : 0);
+        rows = take(tab_lds ? nL * 4 : 0);
+        flag = take(nL + 64);
+        hkey = take(HT * 4);
+        hco = take(HT * 4);          // (fill cursor << 16) | member count
+        memb = take(Ppad * 2);
+        slot = take(Ppad * 2);
+        misc = take(256);
         total = o;
     }
 };
 
-template <typename T, int NT>
+// One spring of the strain limiter, exactly as cloth.pyx:265-296 evaluates it. Returns true if a correction
+// was applied. `tear` is OR-ed.
+template <typename T>
+__device__ __forceinline__ bool strain_spring(T *cur, const uint8_t *cnt, int Ppad, uint32_t en, T r,
+                                              const DevConsts<T> &k, int &tear) {
+    const int a = (int)(en & 0xFFFFu), b = (int)(en >> 16);
+    const bool pa = cnt[a] != 0, pb = cnt[b] != 0;
+    if (pa && pb) return false;                                                         // :268
+    const T xa = cur[a], ya = cur[Ppad + a], za = cur[2 * Ppad + a];
+    const T xb = cur[b], yb = cur[Ppad + b], zb = cur[2 * Ppad + b];
+    const T dx = xa - xb, dy = ya - yb, dz = za - zb;
+    const T len2 = dx * dx + dy * dy + dz * dz;
+    const T t11 = r * k.c11, tt = r * k.tear_thresh;
+    const T tmin = t11 < tt ? t11 : tt;
+    if (!(len2 > tmin * tmin * ((T)1 - filt_slack<T>()))) return false;   // certainly neither tear nor stretch
+    const T len = dev_sqrt<T>(len2);                                                    // :270
+    if (len > tt) tear = 1;                                                             // :272
+    if (!(len > t11)) return false;                                                     // :275
+    const T ux = dx / len, uy = dy / len, uz = dz / len;                                // :276-278
+    const T extra = len - t11;                                                          // :279
+    if (pa) {
+        cur[b] = xb + ux * extra; cur[Ppad + b] = yb + uy * extra; cur[2 * Ppad + b] = zb + uz * extra;
+    } else if (pb) {
+        cur[a] = xa - ux * extra; cur[Ppad + a] = ya - uy * extra; cur[2 * Ppad + a] = za - uz * extra;
+    } else {
+        const T ed = extra * (T)0.5;
+        cur[a] = xa - ux * ed; cur[Ppad + a] = ya - uy * ed; cur[2 * Ppad + a] = za - uz * ed;
+        cur[b] = xb + ux * ed; cur[Ppad + b] = yb + uy * ed; cur[2 * Ppad + b] = zb + uz * ed;
+    }
+    return true;
+}
+
+// Particle i is owned by thread (i % NT); a thread owns PPT particles i = tid + k*NT. The previous
+// position of a particle is only ever touched by its owner (adjust, Verlet, plane), so it lives in the
+// owner's registers for the whole schedule; only the current positions are shared through LDS.
+template <typename T, int NT, int PPT, bool TAB_LDS>
 __global__ __launch_bounds__(NT) void k_run_schedule(StepArgs<T> A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int e = blockIdx.x;
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
     const ClothSchedule sc = A.sched[e];
     if (!sc.active || sc.n_total <= 0) {
         if (tid == 0) A.executed[e] = 0;
         return;
     }
-    const int P = A.P, Ppad = A.Ppad, Psort = A.Psort;
-    const LdsLayout<T> lay(Ppad, Psort);
-    T *cur = reinterpret_cast<T *>(smem + lay.bufA);
-    T *prv = reinterpret_cast<T *>(smem + lay.bufB);
+    const int P = A.P, Ppad = A.Ppad, nL = A.n_levels, HT = A.HT;
+    const LdsLayout lay((int)sizeof(T), Ppad, A.Spad, nL, HT, TAB_LDS);
+    T *cur = reinterpret_cast<T *>(smem + lay.cur);
     uint8_t *cnt = smem + lay.cnt;
-    uint32_t *sw = reinterpret_cast<uint32_t *>(smem + lay.sortw);
-    volatile int *misc = reinterpret_cast<volatile int *>(smem + lay.misc);   // [0] = tear
-
+    uint8_t *lvflag = smem + lay.flag;
+    uint32_t *hkey = reinterpret_cast<uint32_t *>(smem + lay.hkey);
+    uint32_t *hco = reinterpret_cast<uint32_t *>(smem + lay.hco);
+    uint16_t *memb = reinterpret_cast<uint16_t *>(smem + lay.memb);
+    uint16_t *slot = reinterpret_cast<uint16_t *>(smem + lay.slot);
+    volatile int *misc = reinterpret_cast<volatile int *>(smem + lay.misc);   // [0] tear, [1] strain-active, [8..] scan
     const DevConsts<T> k = A.k;
-    const T *rest = A.rest + (size_t)e * A.rest_stride;
+    const T *g_rest = A.rest + (size_t)e * A.rest_stride;
+    const uint32_t *ent = TAB_LDS ? reinterpret_cast<const uint32_t *>(smem + lay.ent) : A.lv_ent;
+    const T *rest = TAB_LDS ? reinterpret_cast<const T *>(smem + lay.rest) : g_rest;
+    const uint16_t *loff = TAB_LDS ? reinterpret_cast<const uint16_t *>(smem + lay.off) : A.lv_off;
+    const uint32_t *lrows = TAB_LDS ? reinterpret_cast<const uint32_t *>(smem + lay.rows) : A.lv_rows;
+    const int pm = A.phase_mask;
 
-    {   // HBM -> LDS, coalesced
+    T pvx[PPT], pvy[PPT], pvz[PPT];         // previous positions of the owned particles
+    {   // HBM -> LDS / registers, coalesced
         const T *gp = A.pos + (size_t)e * 3 * Ppad, *gq = A.prev + (size_t)e * 3 * Ppad;
-        for (int i = tid; i < 3 * Ppad; i += NT) { cur[i] = gp[i]; prv[i] = gq[i]; }
+        for (int i = tid; i < 3 * Ppad; i += NT) cur[i] = gp[i];
+#pragma unroll
+        for (int q = 0; q < PPT; q++) {
+            const int i = tid + q * NT;
+            const bool ok = i < P;
+            pvx[q] = ok ? gq[i] : (T)0; pvy[q] = ok ? gq[Ppad + i] : (T)0; pvz[q] = ok ? gq[2 * Ppad + i] : (T)0;
+        }
         const uint8_t *gc = A.cnt + (size_t)e * Ppad;
         for (int i = tid; i < Ppad; i += NT) cnt[i] = gc[i];
-        if (tid == 0) misc[0] = A.tear[e];
+        if (TAB_LDS) {
+            uint32_t *d0 = reinterpret_cast<uint32_t *>(smem + lay.ent);
+            T *d1 = reinterpret_cast<T *>(smem + lay.rest);
+            for (int i = tid; i < A.Spad; i += NT) { d0[i] = A.lv_ent[i]; d1[i] = g_rest[i]; }
+            uint16_t *d2 = reinterpret_cast<uint16_t *>(smem + lay.off);
+            uint32_t *d3 = reinterpret_cast<uint32_t *>(smem + lay.rows);
+            for (int i = tid; i <= nL; i += NT) d2[i] = A.lv_off[i];
+            for (int i = tid; i < nL; i += NT) d3[i] = A.lv_rows[i];
+        }
+        for (int h = tid; h < HT; h += NT) { hkey[h] = KEY_EMPTY; hco[h] = 0; }
+        if (tid == 0) { misc[0] = A.tear[e]; misc[1] = 0; }
     }
     __syncthreads();
 
     const T dz_up = (T)sc.dz_up, dxp = (T)sc.dx_pull, dyp = (T)sc.dy_pull, dzp = (T)sc.dz_pull;
+    const int W = 1 << A.lvw_shift;
     int done = 0;
     for (int it = 0; it < sc.n_total; it++) {
         // ---- ClothEnv._pull (cloth_env.py:352-367): adjust / nothing / release -------------------
@@ -138,121 +217,164 @@ __global__ __launch_bounds__(NT) void k_run_schedule(StepArgs<T> A) {
         else if (it < sc.n_griprest_end) { }
         else mode = 2;
         if (mode == 1) {
-            for (int i = tid; i < P; i += NT) {
-                int m = cnt[i] & CNT_GRAB_MASK;
-                for (int q = 0; q < m; q++) {           // gripper.pyx:60-66: p <- x ; x <- delta + x
-                    T x = cur[i], y = cur[Ppad + i], z = cur[2 * Ppad + i];
-                    prv[i] = x; prv[Ppad + i] = y; prv[2 * Ppad + i] = z;
+#pragma unroll
+            for (int q = 0; q < PPT; q++) {
+                const int i = tid + q * NT;
+                if (i >= P) continue;
+                const int m = cnt[i] & CNT_GRAB_MASK;
+                for (int r = 0; r < m; r++) {           // gripper.pyx:60-66: p <- x ; x <- delta + x
+                    const T x = cur[i], y = cur[Ppad + i], z = cur[2 * Ppad + i];
+                    pvx[q] = x; pvy[q] = y; pvz[q] = z;
                     cur[i] = ax + x; cur[Ppad + i] = ay + y; cur[2 * Ppad + i] = az + z;
                 }
             }
+            __syncthreads();
         } else if (mode == 2) {
+            bool any = false;
             for (int i = tid; i < P; i += NT)          // gripper.pyx:68-73
-                if (cnt[i] & CNT_GRAB_MASK) cnt[i] = 0;
+                if (cnt[i] & CNT_GRAB_MASK) { cnt[i] = 0; any = true; }
+            (void)any;
+            __syncthreads();
         }
-        __syncthreads();
 
         // ---- gravity + Hooke gather + Verlet (cloth.pyx:216-256) ----------------------------------
-        // new position goes to the point's slot in `prv` (only its owner reads that slot); the two
-        // buffers then swap roles, which is exactly p <- x ; x <- new for unpinned points.
-        for (int i = tid; i < P; i += NT) {
-            if (cnt[i]) continue;                       // pinned: force irrelevant (cloth.pyx:244)
-            const T x = cur[i], y = cur[Ppad + i], z = cur[2 * Ppad + i];
-            T fx = (T)0 + (T)0, fy = (T)0 + (T)0, fz = (T)0 + k.mg;
+        if (pm & PH_HOOKE) {
+            T nx[PPT], ny[PPT], nz[PPT];
 #pragma unroll
-            for (int s = 0; s < HK_SLOTS; s++) {
-                const uint32_t g = A.gather[s * Ppad + i];
-                if (!(g & HK_VALID)) break;
-                const int j = (int)(g & HK_NBR_MASK);
-                const T r = rest[(g >> HK_POS_SHIFT) & HK_POS_MASK];
-                const T kk = k.ksK[(g & HK_BEND) ? 1 : 0];
-                const T xj = cur[j], yj = cur[Ppad + j], zj = cur[2 * Ppad + j];
-                if (g & HK_ASB) {                       // this point is ptB: d = pb - pa = self - nbr
-                    const T dx = x - xj, dy = y - yj, dz = z - zj;
-                    const T l = fastnorm<T>(dx, dy, dz);
-                    const T fm = kk * (l - r) / l;      // cloth.pyx:232
-                    fx = fx + (-(fm * dx)); fy = fy + (-(fm * dy)); fz = fz + (-(fm * dz));   // :237
-                } else {                                // this point is ptA: d = nbr - self
-                    const T dx = xj - x, dy = yj - y, dz = zj - z;
-                    const T l = fastnorm<T>(dx, dy, dz);
-                    const T fm = kk * (l - r) / l;
-                    fx = fx + fm * dx; fy = fy + fm * dy; fz = fz + fm * dz;                  // :236
+            for (int q = 0; q < PPT; q++) {
+                const int i = tid + q * NT;
+                nx[q] = ny[q] = nz[q] = (T)0;
+                if (i >= P || cnt[i]) continue;             // pinned: Verlet skips it (cloth.pyx:244)
+                const T x = cur[i], y = cur[Ppad + i], z = cur[2 * Ppad + i];
+                T fx = (T)0 + (T)0, fy = (T)0 + (T)0, fz = (T)0 + k.mg;
+                for (int s = 0; s < HK_SLOTS; s++) {
+                    const uint32_t g = A.gather[s * Ppad + i];
+                    if (!(g & HK_VALID)) break;
+                    const int j = (int)(g & HK_NBR_MASK);
+                    const T r = rest[(g >> HK_POS_SHIFT) & HK_POS_MASK];
+                    const T kk = k.ksK[(g & HK_BEND) ? 1 : 0];
+                    const T xj = cur[j], yj = cur[Ppad + j], zj = cur[2 * Ppad + j];
+                    if (g & HK_ASB) {                       // this point is ptB: d = pb - pa = self - nbr
+                        const T dx = x - xj, dy = y - yj, dz = z - zj;
+                        const T l = fastnorm<T>(dx, dy, dz);
+                        const T fm = kk * (l - r) / l;      // cloth.pyx:232
+                        fx = fx + (-(fm * dx)); fy = fy + (-(fm * dy)); fz = fz + (-(fm * dz));   // :237
+                    } else {                                // this point is ptA: d = nbr - self
+                        const T dx = xj - x, dy = yj - y, dz = zj - z;
+                        const T l = fastnorm<T>(dx, dy, dz);
+                        const T fm = kk * (l - r) / l;
+                        fx = fx + fm * dx; fy = fy + fm * dy; fz = fz + fm * dz;                  // :236
+                    }
                 }
+                nx[q] = x + (k.damp * (x - pvx[q])) + (fx * k.dsm);                               // :249
+                ny[q] = y + (k.damp * (y - pvy[q])) + (fy * k.dsm);
+                nz[q] = z + (k.damp * (z - pvz[q])) + (fz * k.dsm);
+                pvx[q] = x; pvy[q] = y; pvz[q] = z;                                               // :256
             }
-            const T px = prv[i], py = prv[Ppad + i], pz = prv[2 * Ppad + i];
-            prv[i] = x + (k.damp * (x - px)) + (fx * k.dsm);                                  // :249
-            prv[Ppad + i] = y + (k.damp * (y - py)) + (fy * k.dsm);
-            prv[2 * Ppad + i] = z + (k.damp * (z - pz)) + (fz * k.dsm);
-        }
-        __syncthreads();
-        { T *t = cur; cur = prv; prv = t; }
-
-        // ---- pinned fix-up (they did not move: undo the swap) + cell keys (cloth.pyx:298-311) ------
-        for (int i = tid; i < Psort; i += NT) {
-            uint32_t w = 0xFFFFFFFFu;
-            if (i < P) {
-                if (cnt[i]) {
-                    T a0 = cur[i], a1 = cur[Ppad + i], a2 = cur[2 * Ppad + i];
-                    cur[i] = prv[i]; cur[Ppad + i] = prv[Ppad + i]; cur[2 * Ppad + i] = prv[2 * Ppad + i];
-                    prv[i] = a0; prv[Ppad + i] = a1; prv[2 * Ppad + i] = a2;
-                }
-                w = (cell_key<T>(k, cur[i], cur[Ppad + i], cur[2 * Ppad + i]) << KEY_SHIFT) | (uint32_t)i;
-            }
-            sw[i] = w;
-        }
-        __syncthreads();
-
-        // ---- bitonic sort of (key, index): cells become contiguous runs in ascending point index ---
-        for (int kk = 2; kk <= Psort; kk <<= 1) {
-            for (int j = kk >> 1; j > 0; j >>= 1) {
-                for (int t = tid; t < (Psort >> 1); t += NT) {
-                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                    const int l = i | j;
-                    const uint32_t a = sw[i], b = sw[l];
-                    const bool up = ((i & kk) == 0);
-                    if ((a > b) == up) { sw[i] = b; sw[l] = a; }
-                }
-                __syncthreads();
+            __syncthreads();                                // every neighbour read of the old positions is done
+#pragma unroll
+            for (int q = 0; q < PPT; q++) {
+                const int i = tid + q * NT;
+                if (i >= P || cnt[i]) continue;
+                cur[i] = nx[q]; cur[Ppad + i] = ny[q]; cur[2 * Ppad + i] = nz[q];                 // :255
             }
         }
 
-        // ---- self-collision (cloth.pyx:313-343) + plane (cloth.pyx:345-370), one lane per cell -------
-        for (int q = tid; q < P; q += NT) {
-            const uint32_t w0 = sw[q];
-            const uint32_t key = w0 >> KEY_SHIFT;
-            if (q > 0 && (sw[q - 1] >> KEY_SHIFT) == key) continue;     // not the head of its cell
-            int end = q + 1;
-            while (end < P && (sw[end] >> KEY_SHIFT) == key) end++;
-            if (end - q > 1) {
-                for (int a = q; a < end; a++) {                         // ascending point index
-                    const int i = (int)(sw[a] & HK_NBR_MASK);
+        // ---- spatial map (cloth.pyx:298-311): hash table in LDS keyed by the exact cell key, CSR member
+        // lists; the order inside a cell is restored to ascending point index by the cell's lane.
+        if (pm & PH_COLLIDE) {
+#pragma unroll
+            for (int q = 0; q < PPT; q++) {
+                const int i = tid + q * NT;
+                if (i >= P) continue;
+                const uint32_t key = cell_key<T>(k, cur[i], cur[Ppad + i], cur[2 * Ppad + i]);    // own slots: no hazard
+                uint32_t h = (key * 2654435761u) >> (32 - A.ht_bits);
+                while (true) {
+                    const uint32_t old = atomicCAS(&hkey[h], KEY_EMPTY, key);
+                    if (old == KEY_EMPTY || old == key) break;
+                    h = (h + 1) & (uint32_t)(HT - 1);
+                }
+                slot[i] = (uint16_t)h;
+                atomicAdd(&hco[h], 1u);
+            }
+            __syncthreads();
+            // exclusive prefix sum of the slot counts -> fill cursors (each thread owns HT/NT consecutive slots)
+            const int per = HT / NT;
+            uint32_t loc = 0;
+            for (int q = 0; q < per; q++) loc += hco[tid * per + q];
+            uint32_t inc = loc;
+            for (int o = 1; o < 64; o <<= 1) { uint32_t v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+            if (lane == 63) misc[8 + (tid >> 6)] = (int)inc;
+            __syncthreads();
+            uint32_t base = inc - loc;
+            for (int w = 0; w < (tid >> 6); w++) base += (uint32_t)misc[8 + w];
+            for (int q = 0; q < per; q++) {
+                const uint32_t c = hco[tid * per + q];
+                hco[tid * per + q] = (base << 16) | c;
+                base += c;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < PPT; q++) {
+                const int i = tid + q * NT;
+                if (i >= P) continue;
+                const uint32_t old = atomicAdd(&hco[slot[i]], 1u << 16);   // afterwards cursor = END of the cell
+                memb[old >> 16] = (uint16_t)i;
+            }
+            __syncthreads();
+            // ---- self-collision (cloth.pyx:313-343), one lane per cell, Gauss-Seidel in ascending index ----
+            const T thr2 = k.thresh * k.thresh * ((T)1 + filt_slack<T>());
+            for (int h = tid; h < HT; h += NT) {
+                const uint32_t co = hco[h];
+                const int n = (int)(co & 0xFFFFu);
+                hco[h] = 0;                                             // ready for the next substep
+                if (n == 0) continue;
+                hkey[h] = KEY_EMPTY;
+                if (n == 1) continue;
+                uint16_t *m = memb + ((int)(co >> 16) - n);
+                for (int a = 1; a < n; a++) {                           // restore ascending point index
+                    const uint16_t v = m[a];
+                    int b = a - 1;
+                    while (b >= 0 && m[b] > v) { m[b + 1] = m[b]; b--; }
+                    m[b + 1] = v;
+                }
+                for (int a = 0; a < n; a++) {
+                    const int i = (int)m[a];
                     if (cnt[i]) continue;                               // :314
                     const T xi = cur[i], yi = cur[Ppad + i], zi = cur[2 * Ppad + i];
                     T tx = (T)0, ty = (T)0, tz = (T)0;
-                    int n = 0;
-                    for (int b = q; b < end; b++) {
+                    int nh = 0;
+                    for (int b = 0; b < n; b++) {
                         if (b == a) continue;                           // :325
-                        const int j = (int)(sw[b] & HK_NBR_MASK);
+                        const int j = (int)m[b];
                         const T dx = xi - cur[j], dy = yi - cur[Ppad + j], dz = zi - cur[2 * Ppad + j];
-                        const T dist = fastnorm<T>(dx, dy, dz);         // :327
+                        const T d2 = dx * dx + dy * dy + dz * dz;
+                        if (d2 > thr2) continue;                        // certainly dist > thresh
+                        const T dist = dev_sqrt<T>(d2);                 // :327
                         if (dist <= k.thresh) {                         // :330
                             const T factor = (k.thresh - dist) / dist;  // :331
                             tx += dx * factor; ty += dy * factor; tz += dz * factor;
-                            n += 1;
+                            nh += 1;
                         }
                     }
-                    if (n != 0) {                                       // :336-343
-                        const T nf = (T)n;
+                    if (nh != 0) {                                      // :336-343
+                        const T nf = (T)nh;
                         cur[i] = xi + tx / nf / k.sim_steps;
                         cur[Ppad + i] = yi + ty / nf / k.sim_steps;
                         cur[2 * Ppad + i] = zi + tz / nf / k.sim_steps;
                     }
                 }
             }
-            for (int a = q; a < end; a++) {                             // plane, cloth.pyx:356-370
-                const int i = (int)(sw[a] & HK_NBR_MASK);
-                if (cnt[i] || cur[2 * Ppad + i] >= k.min_z) continue;
-                const T px = prv[i], py = prv[Ppad + i], pz = prv[2 * Ppad + i];
+        }
+        __syncthreads();
+
+        // ---- plane (cloth.pyx:345-370), by the owner (it holds the previous position) --------------------
+        if (pm & PH_PLANE) {
+#pragma unroll
+            for (int q = 0; q < PPT; q++) {
+                const int i = tid + q * NT;
+                if (i >= P || cnt[i] || cur[2 * Ppad + i] >= k.min_z) continue;
+                const T px = pvx[q], py = pvy[q], pz = pvz[q];
                 const T t = (k.min_z - pz) * (T)1.0;
                 const T tgx = px + t * (T)(-0.0), tgy = py + t * (T)(-0.0), tgz = pz + t * (T)(-1.0);
                 const T gx = tgx + k.surf_off * (T)0.0, gy = tgy + k.surf_off * (T)0.0, gz = tgz + k.surf_off * (T)1.0;
@@ -261,59 +383,90 @@ __global__ __launch_bounds__(NT) void k_run_schedule(StepArgs<T> A) {
                 cur[Ppad + i] = py + cy * k.one_m_fric;
                 cur[2 * Ppad + i] = pz + cz * k.one_m_fric;
             }
+            __syncthreads();
         }
-        __syncthreads();
 
-        // ---- strain limit + tear (cloth.pyx:258-296): wave 0 walks the dependency levels in order --
-        if (tid < 64) {
-            int tear = 0;
-            int off = A.lv_off[0];
-            for (int L = 0; L < A.n_levels; L++) {
-                const int nxt = A.lv_off[L + 1];
-                const int idx = off + tid;
-                if (idx < nxt) {
-                    const uint32_t en = A.lv_ent[idx];
-                    const int a = (int)(en & 0xFFFFu), b = (int)(en >> 16);
-                    const bool pa = cnt[a] != 0, pb = cnt[b] != 0;
-                    if (!(pa && pb)) {                                                      // :268
-                        const T r = rest[idx];
-                        const T xa = cur[a], ya = cur[Ppad + a], za = cur[2 * Ppad + a];
-                        const T xb = cur[b], yb = cur[Ppad + b], zb = cur[2 * Ppad + b];
-                        const T dx = xa - xb, dy = ya - yb, dz = za - zb;
-                        const T len = fastnorm<T>(dx, dy, dz);                              // :270
-                        if (len > r * k.tear_thresh) tear = 1;                              // :272
-                        if (len > (r * k.c11)) {                                            // :275
-                            const T ux = dx / len, uy = dy / len, uz = dz / len;            // :276-278
-                            const T extra = len - r * k.c11;                                // :279
-                            if (pa) {
-                                cur[b] = xb + ux * extra; cur[Ppad + b] = yb + uy * extra; cur[2 * Ppad + b] = zb + uz * extra;
-                            } else if (pb) {
-                                cur[a] = xa - ux * extra; cur[Ppad + a] = ya - uy * extra; cur[2 * Ppad + a] = za - uz * extra;
-                            } else {
-                                const T ed = extra * (T)0.5;
-                                cur[a] = xa - ux * ed; cur[Ppad + a] = ya - uy * ed; cur[2 * Ppad + a] = za - uz * ed;
-                                cur[b] = xb + ux * ed; cur[Ppad + b] = yb + uy * ed; cur[2 * Ppad + b] = zb + uz * ed;
+        // ---- strain limit + tear (cloth.pyx:258-296) ---------------------------------------------------
+        // (1) all threads: which levels hold a spring that would stretch/tear at the CURRENT positions?
+        //     A spring untouched by earlier corrections of the sweep behaves exactly as evaluated here.
+        // (2) wave 0 walks the dependency levels in order, executing only levels that are flagged or touch a
+        //     grid row already modified by the sweep; everything it skips is provably a no-op.
+        if (pm & PH_STRAIN) {
+            {
+                const int sub = tid & (W - 1), grp = tid >> A.lvw_shift, G = NT >> A.lvw_shift;
+                const int gsh = (lane >> A.lvw_shift) << A.lvw_shift;
+                const unsigned long long gm = (W == 64 ? ~0ull : ((1ull << W) - 1ull)) << gsh;
+                int any_wave = 0;
+                for (int L0 = 0; L0 < nL; L0 += G) {
+                    const int L = L0 + grp;
+                    bool act = false;
+                    if (L < nL) {
+                        const int idx = (int)loff[L] + sub;
+                        if (idx < (int)loff[L + 1]) {
+                            const uint32_t en = ent[idx];
+                            const int a = (int)(en & 0xFFFFu), b = (int)(en >> 16);
+                            if (!(cnt[a] && cnt[b])) {
+                                const T r = rest[idx];
+                                const T dx = cur[a] - cur[b], dy = cur[Ppad + a] - cur[Ppad + b], dz = cur[2 * Ppad + a] - cur[2 * Ppad + b];
+                                const T len2 = dx * dx + dy * dy + dz * dz;
+                                const T t11 = r * k.c11, tt = r * k.tear_thresh;
+                                const T tmin = t11 < tt ? t11 : tt;
+                                act = len2 > tmin * tmin * ((T)1 - filt_slack<T>());
                             }
                         }
                     }
+                    const unsigned long long bal = __ballot(act);
+                    if (sub == 0 && L < nL) lvflag[L] = (bal & gm) ? 1 : 0;
+                    any_wave |= (bal != 0ull);
                 }
-                off = nxt;
-                // the next level's lanes read what this level's lanes wrote: same wave, LDS is in order;
-                // the fence only stops the compiler from moving LDS accesses across the level boundary.
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (any_wave && lane == 0) misc[1] = 1;
             }
-            if (__any(tear) && tid == 0) misc[0] = 1;
+            __syncthreads();
+            if (tid < 64 && (misc[1] || (pm & PH_NOSKIP))) {
+                int tear = 0;
+                uint32_t dirty = (pm & PH_NOSKIP) ? 0xFFFFFFFFu : 0u;
+                for (int L0 = 0; L0 < nL; L0 += 64) {
+                    const int Lm = L0 + lane;
+                    const bool valid = Lm < nL;
+                    const uint32_t myrows = valid ? lrows[Lm] : 0u;
+                    const int myoff = valid ? (int)loff[Lm] : 0, myoff1 = valid ? (int)loff[Lm + 1] : 0;
+                    const unsigned long long amask = __ballot(valid && lvflag[Lm] != 0);
+                    int j = 0;
+                    while (j < 64) {
+                        const unsigned long long rmask = __ballot((myrows & dirty) != 0u);
+                        const unsigned long long need = (amask | rmask) & (~0ull << j);
+                        if (!need) break;
+                        j = __builtin_amdgcn_readfirstlane(__ffsll((long long)need) - 1);
+                        const int o0 = __builtin_amdgcn_readlane(myoff, j), o1 = __builtin_amdgcn_readlane(myoff1, j);
+                        const int idx = o0 + lane;
+                        bool trig = false;
+                        if (idx < o1) trig = strain_spring<T>(cur, cnt, Ppad, ent[idx], rest[idx], k, tear);
+                        if (__any(trig)) dirty |= (uint32_t)__builtin_amdgcn_readlane((int)myrows, j);
+                        j++;
+                        // the next level's lanes read what this level's lanes wrote: same wave, LDS is in order;
+                        // the fences only stop the compiler from moving LDS accesses across the level boundary.
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    }
+                }
+                if (__any(tear) && lane == 0) misc[0] = 1;
+                if (lane == 0) misc[1] = 0;
+            }
+            __syncthreads();
         }
-        __syncthreads();
         done++;
         if (sc.break_on_tear && misc[0]) break;                                            // cloth_env.py:511-514
     }
 
-    {   // LDS -> HBM
+    {   // LDS / registers -> HBM
         T *gp = A.pos + (size_t)e * 3 * Ppad, *gq = A.prev + (size_t)e * 3 * Ppad;
-        for (int i = tid; i < 3 * Ppad; i += NT) { gp[i] = cur[i]; gq[i] = prv[i]; }
+        for (int i = tid; i < 3 * Ppad; i += NT) gp[i] = cur[i];
+#pragma unroll
+        for (int q = 0; q < PPT; q++) {
+            const int i = tid + q * NT;
+            if (i < P) { gq[i] = pvx[q]; gq[Ppad + i] = pvy[q]; gq[2 * Ppad + i] = pvz[q]; }
+        }
         uint8_t *gc = A.cnt + (size_t)e * Ppad;
         for (int i = tid; i < Ppad; i += NT) gc[i] = cnt[i];
         if (tid == 0) { A.tear[e] = misc[0]; A.executed[e] = done; }

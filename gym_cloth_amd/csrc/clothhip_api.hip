@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -36,11 +37,10 @@ static int fail(int code, const char *fmt, ...) {
                         __FILE__, __LINE__);                                                    \
     } while (0)
 
-constexpr int NT_STEP = 256;
 
 struct clothhip_handle {
     ClothParams prm{};
-    int E = 0, N = 0, P = 0, Ppad = 0, S = 0, Spad = 0, Psort = 0, precision = 0, device = 0;
+    int E = 0, N = 0, P = 0, Ppad = 0, S = 0, Spad = 0, precision = 0, device = 0;
     size_t tsz = 8;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -50,12 +50,15 @@ struct clothhip_handle {
     int rest_stride = 0;
     int32_t *d_tear = nullptr, *d_exec = nullptr, *d_ngrab = nullptr;
     ClothSchedule *d_sched = nullptr, *h_sched = nullptr;   // h_sched: pinned staging
-    uint32_t *d_gather = nullptr, *d_lv_ent = nullptr;
-    int32_t *d_lv_off = nullptr;
+    uint32_t *d_gather = nullptr, *d_lv_ent = nullptr, *d_lv_rows = nullptr;
+    uint16_t *d_lv_off = nullptr;
+    int HT = 0, ht_bits = 0, lvw_shift = 4, lds_bytes = 0, phase_mask = 15, nt = 256, ppt = 3;
+    bool tab_lds = false;
     double *d_levels = nullptr, *d_xy = nullptr, *d_radius = nullptr;
     int n_grab_levels = 0;
     Topology topo;
     LevelSchedule lv;
+    std::vector<uint32_t> lv_rows;
     std::vector<unsigned char> stage;   // host staging for layout conversion
     std::vector<double> flat_rest;
 };
@@ -148,13 +151,24 @@ static void free_handle(clothhip_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_pos, h->d_prev, h->d_rest, h->d_cnt, h->d_active, h->d_tear, h->d_exec, h->d_ngrab,
-                    h->d_sched, h->d_gather, h->d_lv_ent, h->d_lv_off, h->d_levels, h->d_xy, h->d_radius};
+                    h->d_sched, h->d_gather, h->d_lv_ent, h->d_lv_off, h->d_lv_rows, h->d_levels, h->d_xy, h->d_radius};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->h_sched) (void)hipHostFree(h->h_sched);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
+}
+
+template <typename T> static const void *stepper_fn_t(const clothhip_handle *h) {
+#define PICK(NT, PPT) (h->tab_lds ? (const void *)k_run_schedule<T, NT, PPT, true> : (const void *)k_run_schedule<T, NT, PPT, false>)
+    if (h->nt == 256) return PICK(256, 3);
+    if (h->ppt == 3) return PICK(1024, 3);
+    return PICK(1024, 4);
+#undef PICK
+}
+static const void *stepper_fn(const clothhip_handle *h) {
+    return h->precision == CLOTHHIP_F64 ? stepper_fn_t<double>(h) : stepper_fn_t<float>(h);
 }
 
 extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_t device, int32_t precision,
@@ -176,7 +190,24 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
     h->topo = build_topology(h->N);
     h->lv = build_levels(h->topo);
     h->S = h->topo.S; h->Spad = (h->S + 63) / 64 * 64;
-    h->Psort = 1; while (h->Psort < h->P) h->Psort <<= 1;
+    // threads per cloth x particles per thread (compile-time variants of the stepper)
+    if (h->P <= 768) { h->nt = 256; h->ppt = 3; } else if (h->P <= 3072) { h->nt = 1024; h->ppt = 3; } else { h->nt = 1024; h->ppt = 4; }
+    h->HT = h->nt; h->ht_bits = 0;
+    while (h->HT <= h->P + h->P / 2) h->HT <<= 1;
+    while ((1 << h->ht_bits) < h->HT) h->ht_bits++;
+    h->lvw_shift = h->lv.max_width <= 16 ? 4 : (h->lv.max_width <= 32 ? 5 : 6);
+    if (h->lv.max_width > 64) { delete h; return fail(CLOTHHIP_EINVAL, "level width %d > 64", h->lv.max_width); }
+    {   // grid-row groups touched by each dependency level (drives the exact level skipping of the strain sweep)
+        const int rs = h->N > 32 ? 1 : 0;
+        h->lv_rows.assign(h->lv.n_levels, 0u);
+        for (int L = 0; L < h->lv.n_levels; L++)
+            for (int p = h->lv.off[L]; p < h->lv.off[L + 1]; p++) {
+                const uint32_t en = h->lv.ent[p];
+                h->lv_rows[L] |= 1u << (((int)(en & 0xFFFFu) / h->N) >> rs);
+                h->lv_rows[L] |= 1u << (((int)(en >> 16) / h->N) >> rs);
+            }
+    }
+    if (const char *pmk = getenv("CLOTHHIP_DEBUG_PHASES")) h->phase_mask = atoi(pmk);
     std::vector<uint32_t> gather = build_gather(h->topo, h->lv, h->Ppad);
     std::vector<double> levels = build_grab_levels(params->height, params->thickness);
     h->n_grab_levels = (int)levels.size();
@@ -206,24 +237,35 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
     HC(hipMalloc(&h->d_sched, E * sizeof(ClothSchedule)));
     HC(hipHostMalloc((void **)&h->h_sched, E * sizeof(ClothSchedule), hipHostMallocDefault));
     HC(hipMalloc(&h->d_gather, gather.size() * 4));
-    HC(hipMalloc(&h->d_lv_ent, (size_t)h->S * 4));
-    HC(hipMalloc(&h->d_lv_off, (size_t)(h->lv.n_levels + 1) * 4));
+    HC(hipMalloc(&h->d_lv_ent, (size_t)h->Spad * 4));
+    HC(hipMalloc(&h->d_lv_off, (size_t)(h->lv.n_levels + 1) * 2));
+    HC(hipMalloc(&h->d_lv_rows, (size_t)h->lv.n_levels * 4));
     HC(hipMalloc(&h->d_levels, (levels.size() + 1) * 8));
     HC(hipMalloc(&h->d_xy, E * 2 * 8));
     HC(hipMalloc(&h->d_radius, E * 8));
     HC(hipMemcpy(h->d_gather, gather.data(), gather.size() * 4, hipMemcpyHostToDevice));
+    HC(hipMemset(h->d_lv_ent, 0, (size_t)h->Spad * 4));
     HC(hipMemcpy(h->d_lv_ent, h->lv.ent.data(), (size_t)h->S * 4, hipMemcpyHostToDevice));
-    HC(hipMemcpy(h->d_lv_off, h->lv.off.data(), (size_t)(h->lv.n_levels + 1) * 4, hipMemcpyHostToDevice));
+    {
+        std::vector<uint16_t> off16(h->lv.off.begin(), h->lv.off.end());
+        HC(hipMemcpy(h->d_lv_off, off16.data(), off16.size() * 2, hipMemcpyHostToDevice));
+    }
+    HC(hipMemcpy(h->d_lv_rows, h->lv_rows.data(), (size_t)h->lv.n_levels * 4, hipMemcpyHostToDevice));
+    HC(hipMemset(h->d_rest, 0, E * h->Spad * h->tsz));
     if (!levels.empty()) HC(hipMemcpy(h->d_levels, levels.data(), levels.size() * 8, hipMemcpyHostToDevice));
     HC(hipMemset(h->d_exec, 0, E * 4));
-    // large dynamic LDS (up to the CU's 160 KiB) for the stepper kernels
+    // large dynamic LDS (up to the CU's 160 KiB) for the stepper kernels; the static tables ride in LDS too
+    // when that still leaves room for two cloths per CU (512 cloths = 2 per CU on 256 CUs)
     {
-        int lds = precision == CLOTHHIP_F64 ? LdsLayout<double>(h->Ppad, h->Psort).total : LdsLayout<float>(h->Ppad, h->Psort).total;
-        if (lds > 160 * 1024) { free_handle(h); return fail(CLOTHHIP_EINVAL, "n_side %d needs %d B of LDS (> 160 KiB)", h->N, lds); }
-        if (precision == CLOTHHIP_F64)
-            HC(hipFuncSetAttribute((const void *)k_run_schedule<double, NT_STEP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        else
-            HC(hipFuncSetAttribute((const void *)k_run_schedule<float, NT_STEP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        const int tsz = (int)h->tsz;
+        const int with_tab = LdsLayout(tsz, h->Ppad, h->Spad, h->lv.n_levels, h->HT, true).total;
+        const int without = LdsLayout(tsz, h->Ppad, h->Spad, h->lv.n_levels, h->HT, false).total;
+        h->tab_lds = with_tab <= 160 * 1024;
+        if (const char *t = getenv("CLOTHHIP_DEBUG_TAB_LDS")) h->tab_lds = atoi(t) != 0 && with_tab <= 160 * 1024;
+        h->lds_bytes = h->tab_lds ? with_tab : without;
+        if (h->lds_bytes > 160 * 1024) { free_handle(h); return fail(CLOTHHIP_EINVAL, "n_side %d needs %d B of LDS (> 160 KiB)", h->N, h->lds_bytes); }
+        const void *fn = stepper_fn(h);
+        HC(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes));
     }
 #undef HC
     // initial state: flat tier-1 grid for every env, shared rest table
@@ -421,16 +463,30 @@ extern "C" int clothhip_pin_points(clothhip_handle *h, int32_t env, const int32_
     return 0;
 }
 
-template <typename T> static void launch_run(clothhip_handle *h, const ClothSchedule *d_sched) {
+template <typename T> static StepArgs<T> make_args(clothhip_handle *h, const ClothSchedule *d_sched) {
     StepArgs<T> a;
     a.pos = (T *)h->d_pos; a.prev = (T *)h->d_prev; a.cnt = h->d_cnt; a.rest = (const T *)h->d_rest;
     a.tear = h->d_tear; a.executed = h->d_exec; a.sched = d_sched;
-    a.gather = h->d_gather; a.lv_ent = h->d_lv_ent; a.lv_off = h->d_lv_off; a.n_levels = h->lv.n_levels;
-    a.N = h->N; a.P = h->P; a.Ppad = h->Ppad; a.S = h->S; a.Spad = h->Spad; a.Psort = h->Psort;
-    a.rest_stride = h->rest_stride;
+    a.gather = h->d_gather; a.lv_ent = h->d_lv_ent; a.lv_off = h->d_lv_off; a.lv_rows = h->d_lv_rows;
+    a.n_levels = h->lv.n_levels;
+    a.N = h->N; a.P = h->P; a.Ppad = h->Ppad; a.S = h->S; a.Spad = h->Spad;
+    a.HT = h->HT; a.ht_bits = h->ht_bits; a.lvw_shift = h->lvw_shift;
+    a.rest_stride = h->rest_stride; a.phase_mask = h->phase_mask;
     a.k = make_consts<T>(h->prm);
-    const int lds = LdsLayout<T>(h->Ppad, h->Psort).total;
-    hipLaunchKernelGGL((k_run_schedule<T, NT_STEP>), dim3(h->E), dim3(NT_STEP), lds, h->stream, a);
+    return a;
+}
+
+template <typename T> static void launch_run(clothhip_handle *h, const ClothSchedule *d_sched) {
+    StepArgs<T> a = make_args<T>(h, d_sched);
+#define LAUNCH(NT, PPT)                                                                                              \
+    do {                                                                                                             \
+        if (h->tab_lds) hipLaunchKernelGGL((k_run_schedule<T, NT, PPT, true>), dim3(h->E), dim3(NT), h->lds_bytes, h->stream, a);  \
+        else hipLaunchKernelGGL((k_run_schedule<T, NT, PPT, false>), dim3(h->E), dim3(NT), h->lds_bytes, h->stream, a);           \
+    } while (0)
+    if (h->nt == 256) LAUNCH(256, 3);
+    else if (h->ppt == 3) LAUNCH(1024, 3);
+    else LAUNCH(1024, 4);
+#undef LAUNCH
 }
 
 static int run_common(clothhip_handle *h, const ClothSchedule *d_sched) {

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmark / phase ablation on harvested reference states (dev tool, GPU only).
+
+  python tools/microbench.py [--envs 512] [--precision f32] [--sub 200]
+Regimes: 'rest' (settled cloth, nothing pinned), 'pull' (mid lateral pull, strain limiter busy),
+'fold' (layers stacked, self-collision busy). Phase masks: bit0 hooke, bit1 collide, bit2 plane,
+bit3 strain, bit4 disable the strain-sweep skipping.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle.pyoracle import load_golden  # noqa: E402  (dev tool: uses the golden fixtures only)
+
+
+def cfg_from_golden(g):
+    c = g["cfg"]
+    return {"cloth": {"num_width_points": c["n_side"], "num_height_points": c["n_side"], "width": c["width"],
+                      "height": c["height"], "density": c["density"], "ks": c["ks"], "damping": c["damping"],
+                      "thickness": c["thickness"], "plane_friction": c["plane_friction"],
+                      "tear_thresh": c["tear_thresh"]},
+            "frames_per_sec": c["frames_per_sec"], "simulation_steps": c["simulation_steps"],
+            "env": {"grip_radius": c["grip_radius"]}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--envs", type=int, default=512)
+    ap.add_argument("--precision", default="f32")
+    ap.add_argument("--sub", type=int, default=200)
+    ap.add_argument("--masks", default="15,31,1,3,7,9")
+    ap.add_argument("--n50", action="store_true")
+    args = ap.parse_args()
+    from gym_cloth_amd import ClothBatch
+    if args.n50:
+        g = load_golden("g_traj_fold_50.npz")
+        regimes = {"fold50-pull": (2, [0.0014142, 0.0014142, 0.0]), "fold50-rest": (6, None)}
+    else:
+        g = load_golden("g_traj_lift_pull_25.npz")
+        regimes = {"rest": (14, None), "pull": (9, [0.0012, 0.0016, 0.0]), "lift": (4, [0.0, 0.0, 0.0025])}
+        gf = load_golden("g_traj_fold_25.npz")
+    for name, (cp, delta) in regimes.items():
+        for mask in [int(m) for m in args.masks.split(",")]:
+            os.environ["CLOTHHIP_DEBUG_PHASES"] = str(mask)
+            b = ClothBatch(cfg_from_golden(g), n_envs=args.envs, precision=args.precision)
+            b.set_state(g["cp_pos"][cp], g["cp_prev"][cp], g["cp_pinned"][cp], g["rest"])
+            b.update(20, delta=delta)
+            b.set_state(g["cp_pos"][cp], g["cp_prev"][cp], g["cp_pinned"][cp], g["rest"])
+            b.update(args.sub, delta=delta)
+            ms = b.last_kernel_ms
+            print("%-12s mask %2d: %8.2f us/substep  (%6.2f M substeps/s at E=%d)" %
+                  (name, mask, ms * 1e3 / args.sub, args.envs * args.sub / ms / 1e3, args.envs), flush=True)
+            b.close()
+    if not args.n50:
+        os.environ["CLOTHHIP_DEBUG_PHASES"] = "15"
+        b = ClothBatch(cfg_from_golden(gf), n_envs=args.envs, precision=args.precision)
+        b.set_state(gf["cp_pos"][6], gf["cp_prev"][6], gf["cp_pinned"][6], gf["rest"])
+        b.update(args.sub)
+        ms = b.last_kernel_ms
+        print("%-12s mask 15: %8.2f us/substep  (%6.2f M substeps/s)" % ("fold-rest", ms * 1e3 / args.sub,
+                                                                        args.envs * args.sub / ms / 1e3))
+
+
+if __name__ == "__main__":
+    main()
