@@ -74,6 +74,7 @@ SYMBOLS = [
     ("clothhip_run_device_sched_async", C.c_int, [_vp, _vp]),
     ("clothhip_stream", _vp, [_vp]),
     ("clothhip_last_kernel_ms", C.c_double, [_vp]),
+    ("clothhip_debug_stats", C.c_int, [_vp, _i32p]),
     ("clothhip_selftest_arith", C.c_int, [C.c_int32, C.c_int32, _dp, _dp, _dp, C.c_int64]),
 ]
 

@@ -177,6 +177,12 @@ class ClothBatch(object):
         d = None if delta is None else np.ascontiguousarray(delta, dtype=np.float64)
         check(self._L.clothhip_update(self._h, int(n), _lib.dp(d)))
 
+    def debug_stats(self):
+        """[E,4]: strain sweeps run, dense sweeps, levels executed, levels that corrected (last run)."""
+        st = np.zeros((self.E, 4), dtype=np.int32)
+        check(self._L.clothhip_debug_stats(self._h, _lib.i32p(st)))
+        return st
+
     @property
     def last_kernel_ms(self):
         return float(self._L.clothhip_last_kernel_ms(self._h))

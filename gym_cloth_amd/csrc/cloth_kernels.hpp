@@ -25,7 +25,7 @@ namespace clothhip {
 
 template <typename T> struct DevConsts {
     T mg;              // mass * gravity                         cloth.pyx:179
-    T ksK[2];          // ks * 1.0, ks * 0.2                     cloth.pyx:225-232
+    T ks_str, ks_bend; // ks * 1.0, ks * 0.2 (no array: a dynamic index would push the struct to scratch)  cloth.pyx:225-232
     T dsm;             // (dt*dt)/mass                           cloth.pyx:240
     T damp;            // 1 - damping/100                        cloth.pyx:241
     T cw, ch, ct;      // hash cell extents w, h, t              cloth.pyx:308-310
@@ -39,42 +39,65 @@ template <typename T> struct DevConsts {
 };
 
 template <typename T> struct StepArgs {
-    T *pos;                  // [E][3][Ppad]
+    T *pos;                  // [E][3][Ppad]   (HBM layout: SoA, coalesced)
     T *prev;                 // [E][3][Ppad]
     uint8_t *cnt;            // [E][Ppad]  bits0..6 multiplicity in grabbed_pts, bit7 pinned from outside
     const T *rest;           // [E or 1][Spad] rest lengths in LEVEL order
     int32_t *tear;           // [E] sticky Cloth.cloth_have_tear
     int32_t *executed;       // [E]
+    int32_t *stats;          // [E][4] or nullptr: sweeps run, dense sweeps, levels executed, levels that corrected
     const ClothSchedule *sched;   // [E]
     const uint32_t *gather;  // [HK_SLOTS][Ppad]
     const uint32_t *lv_ent;  // [Spad]  ptA | ptB<<16, level order
     const uint16_t *lv_off;  // [n_levels+1]
-    const uint32_t *lv_rows; // [n_levels] bitmask of the grid-row groups a level touches
+    const uint16_t *pt_lev;  // [HK_SLOTS][Ppad] dependency level of the k-th incident spring of a point (0xFFFF none)
     int32_t n_levels;
     int32_t N, P, Ppad, S, Spad;
     int32_t HT, ht_bits;     // spatial hash table slots (power of two > P)
     int32_t lvw_shift;       // lanes per level in the parallel pre-pass = 1 << lvw_shift (16 or 32)
     int32_t rest_stride;     // 0: one shared table
+    int32_t dense_thresh;    // pre-pass flagged levels above which the sweep stops tracking and runs every level
     int32_t phase_mask;      // debug/ablation: bit0 hooke+verlet, bit1 collide, bit2 plane, bit3 strain, bit4 no-skip
     DevConsts<T> k;
 };
 
 constexpr int KEY_SHIFT = 12;
 constexpr uint32_t KEY_BIAS = 1u << 19;
+constexpr uint32_t KEY_FLOOR = 4096u;         // stored keys are >= KEY_FLOOR so a slot can later hold a point index (< 4096)
 constexpr uint32_t KEY_EMPTY = 0xFFFFFFFFu;
 constexpr uint8_t CNT_GRAB_MASK = 0x7F, CNT_EXT_PIN = 0x80;
 enum { PH_HOOKE = 1, PH_COLLIDE = 2, PH_PLANE = 4, PH_STRAIN = 8, PH_NOSKIP = 16 };
 
+// double: correctly rounded IEEE sqrt / division (bit parity with the reference's CPython doubles).
+// float : the hardware's 1-ulp v_sqrt_f32 / v_rcp_f32 (the fp32 instantiation is the throughput mode; its
+//         parity is a tolerance, not bits).
 template <typename T> __device__ __forceinline__ T dev_sqrt(T x);
 template <> __device__ __forceinline__ double dev_sqrt<double>(double x) { return sqrt(x); }
-template <> __device__ __forceinline__ float dev_sqrt<float>(float x) { return sqrtf(x); }
+template <> __device__ __forceinline__ float dev_sqrt<float>(float x) { return __builtin_amdgcn_sqrtf(x); }
+template <typename T> __device__ __forceinline__ T dev_div(T a, T b);
+template <> __device__ __forceinline__ double dev_div<double>(double a, double b) { return a / b; }
+template <> __device__ __forceinline__ float dev_div<float>(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 template <typename T> __device__ __forceinline__ T dev_floor(T x);
 template <> __device__ __forceinline__ double dev_floor<double>(double x) { return floor(x); }
 template <> __device__ __forceinline__ float dev_floor<float>(float x) { return floorf(x); }
+// wave-uniform broadcast of lane `l`'s value (l must be wave-uniform)
+__device__ __forceinline__ float bcast(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ double bcast(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
 // relative slack of the conservative "could this comparison against a sqrt be true" pre-filters
 template <typename T> __device__ __forceinline__ T filt_slack();
 template <> __device__ __forceinline__ double filt_slack<double>() { return 1e-9; }
 template <> __device__ __forceinline__ float filt_slack<float>() { return 1e-5f; }
+
+// Particle record in LDS: position + the pin/grab count in the 4th slot, so ONE 16-byte (fp32) LDS read
+// brings everything a phase needs to know about a particle.
+template <typename T> struct __attribute__((aligned(16))) Pt { T x, y, z, w; };
+__device__ __forceinline__ uint32_t w_cnt(float w) { return __float_as_uint(w); }
+__device__ __forceinline__ uint32_t w_cnt(double w) { return (uint32_t)__double2loint(w); }
+template <typename T> __device__ __forceinline__ T w_make(uint32_t c);
+template <> __device__ __forceinline__ float w_make<float>(uint32_t c) { return __uint_as_float(c); }
+template <> __device__ __forceinline__ double w_make<double>(uint32_t c) { return __hiloint2double(0, (int)c); }
 
 // cloth.pyx:17-18, association ((x*x + y*y) + z*z)
 template <typename T> __device__ __forceinline__ T fastnorm(T x, T y, T z) { return dev_sqrt<T>(x * x + y * y + z * z); }
@@ -86,25 +109,25 @@ template <typename T> __device__ __forceinline__ uint32_t cell_key(const DevCons
     fx = fx < -lim ? -lim : (fx > lim ? lim : fx);   // NaN falls through the compares; handled below
     fy = fy < -lim ? -lim : (fy > lim ? lim : fy);
     fz = fz < -lim ? -lim : (fz > lim ? lim : fz);
-    if (!(fx == fx) || !(fy == fy) || !(fz == fz)) return (1u << 20) - 1u;
+    if (!(fx == fx) || !(fy == fy) || !(fz == fz)) return (1u << 20) - 1u + KEY_FLOOR;
     int key = 961 * (int)fx + 31 * (int)fy + (int)fz;
     int kb = key + (int)KEY_BIAS;
     kb = kb < 0 ? 0 : (kb > (1 << 20) - 2 ? (1 << 20) - 2 : kb);
-    return (uint32_t)kb;
+    return (uint32_t)kb + KEY_FLOOR;
 }
 
-// LDS carve-up (dynamic shared memory), all offsets in bytes, 16-byte aligned
+// LDS carve-up (dynamic shared memory), all offsets in bytes, 16-byte aligned.
+// tab: 0 = static tables stay in global memory, 1 = ent/rest/off in LDS, 2 = + per-point level table
 struct LdsLayout {
-    int cur, cnt, ent, rest, off, rows, flag, hkey, hco, memb, slot, misc, total;
-    __host__ __device__ LdsLayout(int tsz, int Ppad, int Spad, int nL, int HT, bool tab_lds) {
+    int cur, ent, rest, off, plev, flag, hkey, hco, memb, slot, misc, total;
+    __host__ __device__ LdsLayout(int tsz, int Ppad, int Spad, int nL, int HT, int tab) {
         int o = 0;
         auto take = [&](int bytes) { int r = o; o += (bytes + 15) / 16 * 16; return r; };
-        cur = take(3 * Ppad * tsz);
-        cnt = take(Ppad);
-        ent = take(tab_lds ? Spad * 4 : 0);
-        rest = take(tab_lds ? Spad * tsz : 0);
-        off = take(tab_lds ? (nL + 1) * 2 : 0);
-        rows = take(tab_lds ? nL * 4 : 0);
+        cur = take(4 * Ppad * tsz);
+        ent = take(tab >= 1 ? Spad * 4 : 0);
+        rest = take(tab >= 1 ? Spad * tsz : 0);
+        off = take(tab >= 1 ? (nL + 1) * 2 : 0);
+        plev = take(tab >= 2 ? HK_SLOTS * Ppad * 2 : 0);
         flag = take(nL + 64);
         hkey = take(HT * 4);
         hco = take(HT * 4);          // (fill cursor << 16) | member count
@@ -115,43 +138,138 @@ struct LdsLayout {
     }
 };
 
-// One spring of the strain limiter, exactly as cloth.pyx:265-296 evaluates it. Returns true if a correction
-// was applied. `tear` is OR-ed.
+// One spring of the strain limiter, exactly as cloth.pyx:265-296 evaluates it. Returns which endpoints were
+// moved (bit0: ptA, bit1: ptB; 0 = no correction). `tear` is OR-ed.
 template <typename T>
-__device__ __forceinline__ bool strain_spring(T *cur, const uint8_t *cnt, int Ppad, uint32_t en, T r,
-                                              const DevConsts<T> &k, int &tear) {
+__device__ __forceinline__ int strain_spring(Pt<T> *cur, uint32_t en, T r, const DevConsts<T> &k, int &tear) {
     const int a = (int)(en & 0xFFFFu), b = (int)(en >> 16);
-    const bool pa = cnt[a] != 0, pb = cnt[b] != 0;
-    if (pa && pb) return false;                                                         // :268
-    const T xa = cur[a], ya = cur[Ppad + a], za = cur[2 * Ppad + a];
-    const T xb = cur[b], yb = cur[Ppad + b], zb = cur[2 * Ppad + b];
-    const T dx = xa - xb, dy = ya - yb, dz = za - zb;
+    const Pt<T> A = cur[a], B = cur[b];                     // two 16-byte LDS reads (positions + pin state)
+    const uint32_t ca = w_cnt(A.w), cb = w_cnt(B.w);
+    const T dx = A.x - B.x, dy = A.y - B.y, dz = A.z - B.z;
     const T len2 = dx * dx + dy * dy + dz * dz;
     const T t11 = r * k.c11, tt = r * k.tear_thresh;
     const T tmin = t11 < tt ? t11 : tt;
-    if (!(len2 > tmin * tmin * ((T)1 - filt_slack<T>()))) return false;   // certainly neither tear nor stretch
+    // both pinned: skipped (:268); below the conservative bound: certainly neither tear nor stretch
+    if (((ca != 0) & (cb != 0)) | !(len2 > tmin * tmin * ((T)1 - filt_slack<T>()))) return 0;
     const T len = dev_sqrt<T>(len2);                                                    // :270
     if (len > tt) tear = 1;                                                             // :272
-    if (!(len > t11)) return false;                                                     // :275
-    const T ux = dx / len, uy = dy / len, uz = dz / len;                                // :276-278
+    if (!(len > t11)) return 0;                                                         // :275
+    const T ux = dev_div<T>(dx, len), uy = dev_div<T>(dy, len), uz = dev_div<T>(dz, len);   // :276-278
     const T extra = len - t11;                                                          // :279
-    if (pa) {
-        cur[b] = xb + ux * extra; cur[Ppad + b] = yb + uy * extra; cur[2 * Ppad + b] = zb + uz * extra;
-    } else if (pb) {
-        cur[a] = xa - ux * extra; cur[Ppad + a] = ya - uy * extra; cur[2 * Ppad + a] = za - uz * extra;
+    if (ca != 0) {
+        cur[b] = Pt<T>{B.x + ux * extra, B.y + uy * extra, B.z + uz * extra, B.w};
+        return 2;
+    } else if (cb != 0) {
+        cur[a] = Pt<T>{A.x - ux * extra, A.y - uy * extra, A.z - uz * extra, A.w};
+        return 1;
     } else {
         const T ed = extra * (T)0.5;
-        cur[a] = xa - ux * ed; cur[Ppad + a] = ya - uy * ed; cur[2 * Ppad + a] = za - uz * ed;
-        cur[b] = xb + ux * ed; cur[Ppad + b] = yb + uy * ed; cur[2 * Ppad + b] = zb + uz * ed;
+        cur[a] = Pt<T>{A.x - ux * ed, A.y - uy * ed, A.z - uz * ed, A.w};
+        cur[b] = Pt<T>{B.x + ux * ed, B.y + uy * ed, B.z + uz * ed, B.w};
+        return 3;
     }
-    return true;
 }
 
-// Particle i is owned by thread (i % NT); a thread owns PPT particles i = tid + k*NT. The previous
-// position of a particle is only ever touched by its owner (adjust, Verlet, plane), so it lives in the
-// owner's registers for the whole schedule; only the current positions are shared through LDS.
-template <typename T, int NT, int PPT, bool TAB_LDS>
-__global__ __launch_bounds__(NT) void k_run_schedule(StepArgs<T> A) {
+// Self-collision of ONE spatial cell (cloth.pyx:313-343) by a whole wave, exact Gauss-Seidel order:
+// lane b holds the cell's b-th member in ascending point index; members are visited serially in that order
+// (a = first..n-1), each against all lanes in parallel; the hits are summed in ascending member order.
+// `first` = smallest member index that can move (from the parallel pre-check); members before it provably
+// do not move. n <= 64.
+template <typename T>
+__device__ __forceinline__ void collide_cell_wave(Pt<T> *cur, uint16_t *m, int n, int first,
+                                                  const DevConsts<T> &k, int lane) {
+    const bool in = lane < n;
+    const int mine = in ? (int)m[lane] : 0x7fff;
+    int rank = 0;
+    for (int t = 0; t < n; t++) rank += (__builtin_amdgcn_readlane(mine, t) < mine) ? 1 : 0;
+    if (in) m[rank] = (uint16_t)mine;                 // every lane has read its entry before any lane writes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int i = in ? (int)m[lane] : 0;
+    const Pt<T> me = cur[i];
+    T x = me.x, y = me.y, z = me.z;
+    const unsigned long long pinmask = __ballot(in && w_cnt(me.w) != 0);
+    const unsigned long long lt = __ballot(in && i < first);
+    const int a0 = __popcll(lt);                      // rank of the first possible mover
+    const T thr2 = k.thresh * k.thresh * ((T)1 + filt_slack<T>());
+    bool moved = false;
+    for (int a = a0; a < n; a++) {
+        if ((pinmask >> a) & 1ull) continue;                                            // :314
+        const T xa = bcast(x, a), ya = bcast(y, a), za = bcast(z, a);
+        const T dx = xa - x, dy = ya - y, dz = za - z;
+        const T d2 = dx * dx + dy * dy + dz * dz;
+        bool hit = in && lane != a && !(d2 > thr2);
+        T fx = (T)0, fy = (T)0, fz = (T)0;
+        if (hit) {
+            const T dist = dev_sqrt<T>(d2);                                             // :327
+            hit = dist <= k.thresh;                                                     // :330
+            const T factor = dev_div<T>(k.thresh - dist, dist);                         // :331
+            fx = dx * factor; fy = dy * factor; fz = dz * factor;
+        }
+        unsigned long long hm = __ballot(hit);
+        if (!hm) continue;
+        T tx = (T)0, ty = (T)0, tz = (T)0;
+        int nh = 0;
+        while (hm) {                                                                    // ascending candidate order
+            const int b = __builtin_amdgcn_readfirstlane(__ffsll((long long)hm) - 1);
+            tx += bcast(fx, b); ty += bcast(fy, b); tz += bcast(fz, b);
+            nh++;
+            hm &= hm - 1ull;
+        }
+        const T nf = (T)nh;                                                             // :336-343
+        const T nxa = xa + dev_div<T>(dev_div<T>(tx, nf), k.sim_steps);
+        const T nya = ya + dev_div<T>(dev_div<T>(ty, nf), k.sim_steps);
+        const T nza = za + dev_div<T>(dev_div<T>(tz, nf), k.sim_steps);
+        if (lane == a) { x = nxa; y = nya; z = nza; moved = true; }
+    }
+    if (moved) cur[i] = Pt<T>{x, y, z, me.w};
+}
+
+// Same, by a single lane (cells with more than 64 members; not expected in practice).
+template <typename T>
+__device__ __forceinline__ void collide_cell_serial(Pt<T> *cur, uint16_t *m, int n, const DevConsts<T> &k) {
+    for (int a = 1; a < n; a++) {                           // restore ascending point index
+        const uint16_t v = m[a];
+        int b = a - 1;
+        while (b >= 0 && m[b] > v) { m[b + 1] = m[b]; b--; }
+        m[b + 1] = v;
+    }
+    const T thr2 = k.thresh * k.thresh * ((T)1 + filt_slack<T>());
+    for (int a = 0; a < n; a++) {
+        const int i = (int)m[a];
+        const Pt<T> I = cur[i];
+        if (w_cnt(I.w)) continue;
+        T tx = (T)0, ty = (T)0, tz = (T)0;
+        int nh = 0;
+        for (int b = 0; b < n; b++) {
+            if (b == a) continue;
+            const Pt<T> J = cur[(int)m[b]];
+            const T dx = I.x - J.x, dy = I.y - J.y, dz = I.z - J.z;
+            const T d2 = dx * dx + dy * dy + dz * dz;
+            if (d2 > thr2) continue;
+            const T dist = dev_sqrt<T>(d2);
+            if (dist <= k.thresh) {
+                const T factor = dev_div<T>(k.thresh - dist, dist);
+                tx += dx * factor; ty += dy * factor; tz += dz * factor;
+                nh += 1;
+            }
+        }
+        if (nh != 0) {
+            const T nf = (T)nh;
+            cur[i] = Pt<T>{I.x + dev_div<T>(dev_div<T>(tx, nf), k.sim_steps), I.y + dev_div<T>(dev_div<T>(ty, nf), k.sim_steps),
+                           I.z + dev_div<T>(dev_div<T>(tz, nf), k.sim_steps), I.w};
+        }
+    }
+}
+
+// Particle i is owned by thread (i % NT); a thread owns PPT particles i = tid + q*NT. The previous position
+// of a particle is only ever touched by its owner (adjust, Verlet, plane), so it lives in the owner's
+// registers for the whole schedule, as do the particle's static gather entries (and, with REST_REG, the rest
+// lengths of its incident springs). Only the current positions are shared, through LDS.
+//   TAB: 0 static tables in global memory, 1 ent/rest/offsets in LDS, 2 also the per-point level table.
+template <typename T, int NT, int PPT, int TAB, bool REST_REG>
+__global__ __launch_bounds__(NT, (NT <= 256 ? 2 : NT / 256)) void k_run_schedule(StepArgs<T> A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int e = blockIdx.x;
     const int tid = threadIdx.x;
@@ -162,43 +280,51 @@ __global__ __launch_bounds__(NT) void k_run_schedule(StepArgs<T> A) {
         return;
     }
     const int P = A.P, Ppad = A.Ppad, nL = A.n_levels, HT = A.HT;
-    const LdsLayout lay((int)sizeof(T), Ppad, A.Spad, nL, HT, TAB_LDS);
-    T *cur = reinterpret_cast<T *>(smem + lay.cur);
-    uint8_t *cnt = smem + lay.cnt;
+    const LdsLayout lay((int)sizeof(T), Ppad, A.Spad, nL, HT, TAB);
+    Pt<T> *cur = reinterpret_cast<Pt<T> *>(smem + lay.cur);
     uint8_t *lvflag = smem + lay.flag;
     uint32_t *hkey = reinterpret_cast<uint32_t *>(smem + lay.hkey);
     uint32_t *hco = reinterpret_cast<uint32_t *>(smem + lay.hco);
     uint16_t *memb = reinterpret_cast<uint16_t *>(smem + lay.memb);
     uint16_t *slot = reinterpret_cast<uint16_t *>(smem + lay.slot);
-    volatile int *misc = reinterpret_cast<volatile int *>(smem + lay.misc);   // [0] tear, [1] strain-active, [8..] scan
-    const DevConsts<T> k = A.k;
+    int *misc = reinterpret_cast<int *>(smem + lay.misc);   // [0] tear, [1] #levels flagged by the pre-pass, [8..] scan
+    const DevConsts<T> &k = A.k;
     const T *g_rest = A.rest + (size_t)e * A.rest_stride;
-    const uint32_t *ent = TAB_LDS ? reinterpret_cast<const uint32_t *>(smem + lay.ent) : A.lv_ent;
-    const T *rest = TAB_LDS ? reinterpret_cast<const T *>(smem + lay.rest) : g_rest;
-    const uint16_t *loff = TAB_LDS ? reinterpret_cast<const uint16_t *>(smem + lay.off) : A.lv_off;
-    const uint32_t *lrows = TAB_LDS ? reinterpret_cast<const uint32_t *>(smem + lay.rows) : A.lv_rows;
+    const uint32_t *ent = TAB >= 1 ? reinterpret_cast<const uint32_t *>(smem + lay.ent) : A.lv_ent;
+    const T *rest = TAB >= 1 ? reinterpret_cast<const T *>(smem + lay.rest) : g_rest;
+    const uint16_t *loff = TAB >= 1 ? reinterpret_cast<const uint16_t *>(smem + lay.off) : A.lv_off;
+    const uint16_t *plev = TAB >= 2 ? reinterpret_cast<const uint16_t *>(smem + lay.plev) : A.pt_lev;
     const int pm = A.phase_mask;
 
     T pvx[PPT], pvy[PPT], pvz[PPT];         // previous positions of the owned particles
+    uint32_t gt[PPT][HK_SLOTS];             // their incident-spring gather entries (static)
+    T rr[REST_REG ? PPT : 1][HK_SLOTS];     // and those springs' rest lengths
     {   // HBM -> LDS / registers, coalesced
         const T *gp = A.pos + (size_t)e * 3 * Ppad, *gq = A.prev + (size_t)e * 3 * Ppad;
-        for (int i = tid; i < 3 * Ppad; i += NT) cur[i] = gp[i];
+        const uint8_t *gc = A.cnt + (size_t)e * Ppad;
+        for (int i = tid; i < Ppad; i += NT)
+            cur[i] = Pt<T>{gp[i], gp[Ppad + i], gp[2 * Ppad + i], w_make<T>(gc[i])};
 #pragma unroll
         for (int q = 0; q < PPT; q++) {
             const int i = tid + q * NT;
             const bool ok = i < P;
             pvx[q] = ok ? gq[i] : (T)0; pvy[q] = ok ? gq[Ppad + i] : (T)0; pvz[q] = ok ? gq[2 * Ppad + i] : (T)0;
+#pragma unroll
+            for (int sl = 0; sl < HK_SLOTS; sl++) {
+                gt[q][sl] = ok ? A.gather[sl * Ppad + i] : 0u;
+                if (REST_REG) rr[q][sl] = g_rest[(gt[q][sl] >> HK_POS_SHIFT) & HK_POS_MASK];
+            }
         }
-        const uint8_t *gc = A.cnt + (size_t)e * Ppad;
-        for (int i = tid; i < Ppad; i += NT) cnt[i] = gc[i];
-        if (TAB_LDS) {
+        if (TAB >= 1) {
             uint32_t *d0 = reinterpret_cast<uint32_t *>(smem + lay.ent);
             T *d1 = reinterpret_cast<T *>(smem + lay.rest);
             for (int i = tid; i < A.Spad; i += NT) { d0[i] = A.lv_ent[i]; d1[i] = g_rest[i]; }
             uint16_t *d2 = reinterpret_cast<uint16_t *>(smem + lay.off);
-            uint32_t *d3 = reinterpret_cast<uint32_t *>(smem + lay.rows);
             for (int i = tid; i <= nL; i += NT) d2[i] = A.lv_off[i];
-            for (int i = tid; i < nL; i += NT) d3[i] = A.lv_rows[i];
+        }
+        if (TAB >= 2) {
+            uint16_t *d4 = reinterpret_cast<uint16_t *>(smem + lay.plev);
+            for (int i = tid; i < HK_SLOTS * Ppad; i += NT) d4[i] = A.pt_lev[i];
         }
         for (int h = tid; h < HT; h += NT) { hkey[h] = KEY_EMPTY; hco[h] = 0; }
         if (tid == 0) { misc[0] = A.tear[e]; misc[1] = 0; }
@@ -208,6 +334,7 @@ __global__ __launch_bounds__(NT) void k_run_schedule(StepArgs<T> A) {
     const T dz_up = (T)sc.dz_up, dxp = (T)sc.dx_pull, dyp = (T)sc.dy_pull, dzp = (T)sc.dz_pull;
     const int W = 1 << A.lvw_shift;
     int done = 0;
+    int st_sweeps = 0, st_dense = 0, st_levels = 0, st_trig = 0;      // wave 0 only (uniform)
     for (int it = 0; it < sc.n_total; it++) {
         // ---- ClothEnv._pull (cloth_env.py:352-367): adjust / nothing / release -------------------
         int mode = 0; T ax = 0, ay = 0, az = 0;
@@ -221,73 +348,81 @@ __global__ __launch_bounds__(NT) void k_run_schedule(StepArgs<T> A) {
             for (int q = 0; q < PPT; q++) {
                 const int i = tid + q * NT;
                 if (i >= P) continue;
-                const int m = cnt[i] & CNT_GRAB_MASK;
-                for (int r = 0; r < m; r++) {           // gripper.pyx:60-66: p <- x ; x <- delta + x
-                    const T x = cur[i], y = cur[Ppad + i], z = cur[2 * Ppad + i];
-                    pvx[q] = x; pvy[q] = y; pvz[q] = z;
-                    cur[i] = ax + x; cur[Ppad + i] = ay + y; cur[2 * Ppad + i] = az + z;
+                Pt<T> c = cur[i];
+                const int m = (int)(w_cnt(c.w) & CNT_GRAB_MASK);
+                if (m) {
+                    for (int r = 0; r < m; r++) {       // gripper.pyx:60-66: p <- x ; x <- delta + x
+                        pvx[q] = c.x; pvy[q] = c.y; pvz[q] = c.z;
+                        c.x = ax + c.x; c.y = ay + c.y; c.z = az + c.z;
+                    }
+                    cur[i] = c;
                 }
             }
             __syncthreads();
-        } else if (mode == 2) {
-            bool any = false;
-            for (int i = tid; i < P; i += NT)          // gripper.pyx:68-73
-                if (cnt[i] & CNT_GRAB_MASK) { cnt[i] = 0; any = true; }
-            (void)any;
+        } else if (mode == 2 && it == sc.n_griprest_end) {      // release() is idempotent: only its first call acts
+#pragma unroll
+            for (int q = 0; q < PPT; q++) {
+                const int i = tid + q * NT;
+                if (i >= P) continue;
+                const uint32_t c = w_cnt(cur[i].w);
+                if (c & CNT_GRAB_MASK) cur[i].w = w_make<T>(0u);    // gripper.pyx:68-73
+            }
             __syncthreads();
         }
 
         // ---- gravity + Hooke gather + Verlet (cloth.pyx:216-256) ----------------------------------
         if (pm & PH_HOOKE) {
+            // Per particle: f = (0,0,m*g) + sum over its incident springs in ascending list index of fm * (nbr - self).
+            // (For the spring's ptB the reference adds -(fm * (self - nbr)), which is the same IEEE value.)
+            // Branch-free: absent slots (grid border) and pinned particles are computed and discarded.
             T nx[PPT], ny[PPT], nz[PPT];
+            uint32_t wme[PPT];
 #pragma unroll
             for (int q = 0; q < PPT; q++) {
-                const int i = tid + q * NT;
-                nx[q] = ny[q] = nz[q] = (T)0;
-                if (i >= P || cnt[i]) continue;             // pinned: Verlet skips it (cloth.pyx:244)
-                const T x = cur[i], y = cur[Ppad + i], z = cur[2 * Ppad + i];
-                T fx = (T)0 + (T)0, fy = (T)0 + (T)0, fz = (T)0 + k.mg;
-                for (int s = 0; s < HK_SLOTS; s++) {
-                    const uint32_t g = A.gather[s * Ppad + i];
-                    if (!(g & HK_VALID)) break;
-                    const int j = (int)(g & HK_NBR_MASK);
-                    const T r = rest[(g >> HK_POS_SHIFT) & HK_POS_MASK];
-                    const T kk = k.ksK[(g & HK_BEND) ? 1 : 0];
-                    const T xj = cur[j], yj = cur[Ppad + j], zj = cur[2 * Ppad + j];
-                    if (g & HK_ASB) {                       // this point is ptB: d = pb - pa = self - nbr
-                        const T dx = x - xj, dy = y - yj, dz = z - zj;
-                        const T l = fastnorm<T>(dx, dy, dz);
-                        const T fm = kk * (l - r) / l;      // cloth.pyx:232
-                        fx = fx + (-(fm * dx)); fy = fy + (-(fm * dy)); fz = fz + (-(fm * dz));   // :237
-                    } else {                                // this point is ptA: d = nbr - self
-                        const T dx = xj - x, dy = yj - y, dz = zj - z;
-                        const T l = fastnorm<T>(dx, dy, dz);
-                        const T fm = kk * (l - r) / l;
-                        fx = fx + fm * dx; fy = fy + fm * dy; fz = fz + fm * dz;                  // :236
+                nx[q] = ny[q] = nz[q] = (T)0; wme[q] = 1u;
+                // a real branch per particle: each particle's 12 springs form their own scheduling region, which
+                // keeps the register allocator from interleaving all PPT*12 spring evaluations at once
+                if (tid + q * NT < P) {
+                    const Pt<T> me = cur[tid + q * NT];
+                    wme[q] = w_cnt(me.w);
+                    T fx = (T)0 + (T)0, fy = (T)0 + (T)0, fz = (T)0 + k.mg;
+#pragma unroll
+                    for (int sl = 0; sl < HK_SLOTS; sl++) {
+                        uint32_t g = gt[q][sl];
+                        asm volatile("" : "+v"(g));         // opaque: keeps the address math inside the substep loop
+                        const Pt<T> nb = cur[g & HK_NBR_MASK];
+                        const T r = REST_REG ? rr[REST_REG ? q : 0][sl] : rest[(g >> HK_POS_SHIFT) & HK_POS_MASK];
+                        const T kk = (g & HK_BEND) ? k.ks_bend : k.ks_str;
+                        const T dx = nb.x - me.x, dy = nb.y - me.y, dz = nb.z - me.z;
+                        const T l = fastnorm<T>(dx, dy, dz);                                      // :231
+                        const T fm = dev_div<T>(kk * (l - r), l);                                 // :232
+                        const bool valid = (g & HK_VALID) != 0u;
+                        fx = valid ? fx + fm * dx : fx; fy = valid ? fy + fm * dy : fy; fz = valid ? fz + fm * dz : fz;   // :236-237
                     }
+                    nx[q] = me.x + (k.damp * (me.x - pvx[q])) + (fx * k.dsm);                     // :249
+                    ny[q] = me.y + (k.damp * (me.y - pvy[q])) + (fy * k.dsm);
+                    nz[q] = me.z + (k.damp * (me.z - pvz[q])) + (fz * k.dsm);
+                    if (wme[q] == 0) { pvx[q] = me.x; pvy[q] = me.y; pvz[q] = me.z; }             // :256
                 }
-                nx[q] = x + (k.damp * (x - pvx[q])) + (fx * k.dsm);                               // :249
-                ny[q] = y + (k.damp * (y - pvy[q])) + (fy * k.dsm);
-                nz[q] = z + (k.damp * (z - pvz[q])) + (fz * k.dsm);
-                pvx[q] = x; pvy[q] = y; pvz[q] = z;                                               // :256
             }
             __syncthreads();                                // every neighbour read of the old positions is done
 #pragma unroll
             for (int q = 0; q < PPT; q++) {
                 const int i = tid + q * NT;
-                if (i >= P || cnt[i]) continue;
-                cur[i] = nx[q]; cur[Ppad + i] = ny[q]; cur[2 * Ppad + i] = nz[q];                 // :255
+                if (wme[q]) continue;                       // pinned (or no particle): Verlet skips it (cloth.pyx:244)
+                cur[i] = Pt<T>{nx[q], ny[q], nz[q], w_make<T>(0u)};                               // :255
             }
         }
 
         // ---- spatial map (cloth.pyx:298-311): hash table in LDS keyed by the exact cell key, CSR member
-        // lists; the order inside a cell is restored to ascending point index by the cell's lane.
+        // lists; the order inside a cell is restored to ascending point index by the cell's wave.
         if (pm & PH_COLLIDE) {
 #pragma unroll
             for (int q = 0; q < PPT; q++) {
                 const int i = tid + q * NT;
                 if (i >= P) continue;
-                const uint32_t key = cell_key<T>(k, cur[i], cur[Ppad + i], cur[2 * Ppad + i]);    // own slots: no hazard
+                const Pt<T> me = cur[i];                                                          // own slot: no hazard
+                const uint32_t key = cell_key<T>(k, me.x, me.y, me.z);
                 uint32_t h = (key * 2654435761u) >> (32 - A.ht_bits);
                 while (true) {
                     const uint32_t old = atomicCAS(&hkey[h], KEY_EMPTY, key);
@@ -322,81 +457,85 @@ __global__ __launch_bounds__(NT) void k_run_schedule(StepArgs<T> A) {
                 memb[old >> 16] = (uint16_t)i;
             }
             __syncthreads();
-            // ---- self-collision (cloth.pyx:313-343), one lane per cell, Gauss-Seidel in ascending index ----
+            // ---- self-collision (cloth.pyx:313-343) ------------------------------------------------------
+            // (1) every particle, in parallel: can it move at all (any same-cell candidate within 2*thickness
+            //     at the CURRENT positions)? the smallest such index per cell is the first mover; everything
+            //     before it provably stays put. The key word of the slot is recycled to hold that index.
             const T thr2 = k.thresh * k.thresh * ((T)1 + filt_slack<T>());
-            for (int h = tid; h < HT; h += NT) {
-                const uint32_t co = hco[h];
+#pragma unroll
+            for (int q = 0; q < PPT; q++) {
+                const int i = tid + q * NT;
+                if (i >= P) continue;
+                const int sl = (int)slot[i];
+                const uint32_t co = hco[sl];
                 const int n = (int)(co & 0xFFFFu);
-                hco[h] = 0;                                             // ready for the next substep
-                if (n == 0) continue;
-                hkey[h] = KEY_EMPTY;
-                if (n == 1) continue;
-                uint16_t *m = memb + ((int)(co >> 16) - n);
-                for (int a = 1; a < n; a++) {                           // restore ascending point index
-                    const uint16_t v = m[a];
-                    int b = a - 1;
-                    while (b >= 0 && m[b] > v) { m[b + 1] = m[b]; b--; }
-                    m[b + 1] = v;
+                if (n < 2) continue;
+                const Pt<T> me = cur[i];
+                if (w_cnt(me.w)) continue;
+                const uint16_t *m = memb + ((int)(co >> 16) - n);
+                bool hit = false;
+                for (int b = 0; b < n; b++) {
+                    const int j = (int)m[b];
+                    const Pt<T> o = cur[j];
+                    const T dx = me.x - o.x, dy = me.y - o.y, dz = me.z - o.z;
+                    hit |= (j != i) && !(dx * dx + dy * dy + dz * dz > thr2);
                 }
-                for (int a = 0; a < n; a++) {
-                    const int i = (int)m[a];
-                    if (cnt[i]) continue;                               // :314
-                    const T xi = cur[i], yi = cur[Ppad + i], zi = cur[2 * Ppad + i];
-                    T tx = (T)0, ty = (T)0, tz = (T)0;
-                    int nh = 0;
-                    for (int b = 0; b < n; b++) {
-                        if (b == a) continue;                           // :325
-                        const int j = (int)m[b];
-                        const T dx = xi - cur[j], dy = yi - cur[Ppad + j], dz = zi - cur[2 * Ppad + j];
-                        const T d2 = dx * dx + dy * dy + dz * dz;
-                        if (d2 > thr2) continue;                        // certainly dist > thresh
-                        const T dist = dev_sqrt<T>(d2);                 // :327
-                        if (dist <= k.thresh) {                         // :330
-                            const T factor = (k.thresh - dist) / dist;  // :331
-                            tx += dx * factor; ty += dy * factor; tz += dz * factor;
-                            nh += 1;
-                        }
-                    }
-                    if (nh != 0) {                                      // :336-343
-                        const T nf = (T)nh;
-                        cur[i] = xi + tx / nf / k.sim_steps;
-                        cur[Ppad + i] = yi + ty / nf / k.sim_steps;
-                        cur[2 * Ppad + i] = zi + tz / nf / k.sim_steps;
+                if (hit) atomicMin(&hkey[sl], (uint32_t)i);
+            }
+            __syncthreads();
+            // (2) one wave per cell that has a mover: exact Gauss-Seidel sweep from the first mover on
+            {
+                const int wave = tid >> 6, nw = NT >> 6;
+                for (int h0 = wave * 64; h0 < HT; h0 += nw * 64) {
+                    unsigned long long am = __ballot(hkey[h0 + lane] < KEY_FLOOR);
+                    while (am) {
+                        const int b = __builtin_amdgcn_readfirstlane(__ffsll((long long)am) - 1);
+                        am &= am - 1ull;
+                        const uint32_t co = hco[h0 + b];
+                        const int n = (int)(co & 0xFFFFu);
+                        uint16_t *m = memb + ((int)(co >> 16) - n);
+                        const int first = (int)hkey[h0 + b];
+                        if (n <= 64) collide_cell_wave<T>(cur, m, n, first, k, lane);
+                        else if (lane == 0) collide_cell_serial<T>(cur, m, n, k);
                     }
                 }
             }
+            __syncthreads();
+            for (int h = tid; h < HT; h += NT) { hkey[h] = KEY_EMPTY; hco[h] = 0; }     // ready for the next substep
+        } else {
+            __syncthreads();
         }
-        __syncthreads();
 
         // ---- plane (cloth.pyx:345-370), by the owner (it holds the previous position) --------------------
         if (pm & PH_PLANE) {
 #pragma unroll
             for (int q = 0; q < PPT; q++) {
                 const int i = tid + q * NT;
-                if (i >= P || cnt[i] || cur[2 * Ppad + i] >= k.min_z) continue;
+                if (i >= P) continue;
+                const Pt<T> me = cur[i];
+                if (w_cnt(me.w) || me.z >= k.min_z) continue;
                 const T px = pvx[q], py = pvy[q], pz = pvz[q];
                 const T t = (k.min_z - pz) * (T)1.0;
                 const T tgx = px + t * (T)(-0.0), tgy = py + t * (T)(-0.0), tgz = pz + t * (T)(-1.0);
                 const T gx = tgx + k.surf_off * (T)0.0, gy = tgy + k.surf_off * (T)0.0, gz = tgz + k.surf_off * (T)1.0;
                 const T cx = gx - px, cy = gy - py, cz = gz - pz;
-                cur[i] = px + cx * k.one_m_fric;
-                cur[Ppad + i] = py + cy * k.one_m_fric;
-                cur[2 * Ppad + i] = pz + cz * k.one_m_fric;
+                cur[i] = Pt<T>{px + cx * k.one_m_fric, py + cy * k.one_m_fric, pz + cz * k.one_m_fric, me.w};
             }
-            __syncthreads();
         }
+        __syncthreads();
 
         // ---- strain limit + tear (cloth.pyx:258-296) ---------------------------------------------------
         // (1) all threads: which levels hold a spring that would stretch/tear at the CURRENT positions?
         //     A spring untouched by earlier corrections of the sweep behaves exactly as evaluated here.
-        // (2) wave 0 walks the dependency levels in order, executing only levels that are flagged or touch a
-        //     grid row already modified by the sweep; everything it skips is provably a no-op.
+        // (2) wave 0 walks the dependency levels in order. It runs a level only if the pre-pass flagged it or
+        //     an earlier correction of this sweep moved a particle one of its springs is attached to (the
+        //     correction marks exactly those levels); everything it skips is provably a no-op.
         if (pm & PH_STRAIN) {
             {
                 const int sub = tid & (W - 1), grp = tid >> A.lvw_shift, G = NT >> A.lvw_shift;
                 const int gsh = (lane >> A.lvw_shift) << A.lvw_shift;
                 const unsigned long long gm = (W == 64 ? ~0ull : ((1ull << W) - 1ull)) << gsh;
-                int any_wave = 0;
+                int nflag = 0;
                 for (int L0 = 0; L0 < nL; L0 += G) {
                     const int L = L0 + grp;
                     bool act = false;
@@ -404,45 +543,71 @@ __global__ __launch_bounds__(NT) void k_run_schedule(StepArgs<T> A) {
                         const int idx = (int)loff[L] + sub;
                         if (idx < (int)loff[L + 1]) {
                             const uint32_t en = ent[idx];
-                            const int a = (int)(en & 0xFFFFu), b = (int)(en >> 16);
-                            if (!(cnt[a] && cnt[b])) {
-                                const T r = rest[idx];
-                                const T dx = cur[a] - cur[b], dy = cur[Ppad + a] - cur[Ppad + b], dz = cur[2 * Ppad + a] - cur[2 * Ppad + b];
-                                const T len2 = dx * dx + dy * dy + dz * dz;
-                                const T t11 = r * k.c11, tt = r * k.tear_thresh;
-                                const T tmin = t11 < tt ? t11 : tt;
-                                act = len2 > tmin * tmin * ((T)1 - filt_slack<T>());
-                            }
+                            const T r = rest[idx];
+                            const Pt<T> a = cur[en & 0xFFFFu], b = cur[en >> 16];
+                            const T dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+                            const T len2 = dx * dx + dy * dy + dz * dz;
+                            const T t11 = r * k.c11, tt = r * k.tear_thresh;
+                            const T tmin = t11 < tt ? t11 : tt;
+                            act = !((w_cnt(a.w) != 0) & (w_cnt(b.w) != 0)) & (len2 > tmin * tmin * ((T)1 - filt_slack<T>()));
                         }
                     }
                     const unsigned long long bal = __ballot(act);
-                    if (sub == 0 && L < nL) lvflag[L] = (bal & gm) ? 1 : 0;
-                    any_wave |= (bal != 0ull);
+                    const bool gact = (bal & gm) != 0ull;
+                    if (sub == 0 && L < nL) lvflag[L] = gact ? 1 : 0;
+                    nflag += __popcll(__ballot(gact && sub == 0));
                 }
-                if (any_wave && lane == 0) misc[1] = 1;
+                if (nflag && lane == 0) atomicAdd(&misc[1], nflag);
             }
             __syncthreads();
             if (tid < 64 && (misc[1] || (pm & PH_NOSKIP))) {
                 int tear = 0;
-                uint32_t dirty = (pm & PH_NOSKIP) ? 0xFFFFFFFFu : 0u;
+                // dense: so many levels are flagged that tracking costs more than it saves -> run every level.
+                // sparse: a correction marks exactly the later levels that hold a spring of a moved particle.
+                const bool dense = (pm & PH_NOSKIP) || misc[1] > A.dense_thresh;
+                st_sweeps++; st_dense += dense ? 1 : 0;
                 for (int L0 = 0; L0 < nL; L0 += 64) {
                     const int Lm = L0 + lane;
                     const bool valid = Lm < nL;
-                    const uint32_t myrows = valid ? lrows[Lm] : 0u;
                     const int myoff = valid ? (int)loff[Lm] : 0, myoff1 = valid ? (int)loff[Lm + 1] : 0;
-                    const unsigned long long amask = __ballot(valid && lvflag[Lm] != 0);
-                    int j = 0;
-                    while (j < 64) {
-                        const unsigned long long rmask = __ballot((myrows & dirty) != 0u);
-                        const unsigned long long need = (amask | rmask) & (~0ull << j);
-                        if (!need) break;
-                        j = __builtin_amdgcn_readfirstlane(__ffsll((long long)need) - 1);
+                    unsigned long long need = __ballot(valid && (dense || lvflag[Lm] != 0));
+                    int pf_j = -1;
+                    uint32_t pf_en = 0u; T pf_r = (T)0;
+                    while (need) {
+                        const int j = __ffsll((long long)need) - 1;
+                        need &= need - 1ull;
                         const int o0 = __builtin_amdgcn_readlane(myoff, j), o1 = __builtin_amdgcn_readlane(myoff1, j);
                         const int idx = o0 + lane;
-                        bool trig = false;
-                        if (idx < o1) trig = strain_spring<T>(cur, cnt, Ppad, ent[idx], rest[idx], k, tear);
-                        if (__any(trig)) dirty |= (uint32_t)__builtin_amdgcn_readlane((int)myrows, j);
-                        j++;
+                        const bool on = idx < o1;
+                        uint32_t en = pf_en; T r = pf_r;
+                        if (j != pf_j && on) { en = ent[idx]; r = rest[idx]; }
+                        // speculative fetch of the next level's springs (hit whenever levels run back to back)
+                        pf_j = j + 1;
+                        if (pf_j < 64) {
+                            const int idn = o1 + lane;          // level j+1 starts where level j ends
+                            const int o2 = __builtin_amdgcn_readlane(myoff1, pf_j);
+                            if (idn < o2) { pf_en = ent[idn]; pf_r = rest[idn]; }
+                        }
+                        int moved = 0;
+                        if (on) moved = strain_spring<T>(cur, en, r, k, tear);
+                        st_levels++; st_trig += __any(moved) ? 1 : 0;
+                        if (!dense && __any(moved)) {
+                            if (moved) {
+                                const int Lcur = L0 + j;
+                                const int pa_ = (int)(en & 0xFFFFu), pb_ = (int)(en >> 16);
+#pragma unroll 1
+                                for (int sl = 0; sl < HK_SLOTS; sl++) {
+                                    const int la = (int)plev[sl * Ppad + pa_], lb = (int)plev[sl * Ppad + pb_];
+                                    if ((moved & 1) && la != 0xFFFF && la > Lcur) lvflag[la] = 1;
+                                    if ((moved & 2) && lb != 0xFFFF && lb > Lcur) lvflag[lb] = 1;
+                                }
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                            // refresh the rest of this chunk from the flags (later chunks read them when they start)
+                            need |= __ballot(valid && lvflag[Lm] != 0) & ~((2ull << j) - 1ull);
+                        }
                         // the next level's lanes read what this level's lanes wrote: same wave, LDS is in order;
                         // the fences only stop the compiler from moving LDS accesses across the level boundary.
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -460,16 +625,22 @@ __global__ __launch_bounds__(NT) void k_run_schedule(StepArgs<T> A) {
     }
 
     {   // LDS / registers -> HBM
+        __syncthreads();
         T *gp = A.pos + (size_t)e * 3 * Ppad, *gq = A.prev + (size_t)e * 3 * Ppad;
-        for (int i = tid; i < 3 * Ppad; i += NT) gp[i] = cur[i];
+        uint8_t *gc = A.cnt + (size_t)e * Ppad;
+        for (int i = tid; i < Ppad; i += NT) {
+            const Pt<T> c = cur[i];
+            gp[i] = c.x; gp[Ppad + i] = c.y; gp[2 * Ppad + i] = c.z; gc[i] = (uint8_t)w_cnt(c.w);
+        }
 #pragma unroll
         for (int q = 0; q < PPT; q++) {
             const int i = tid + q * NT;
             if (i < P) { gq[i] = pvx[q]; gq[Ppad + i] = pvy[q]; gq[2 * Ppad + i] = pvz[q]; }
         }
-        uint8_t *gc = A.cnt + (size_t)e * Ppad;
-        for (int i = tid; i < Ppad; i += NT) gc[i] = cnt[i];
-        if (tid == 0) { A.tear[e] = misc[0]; A.executed[e] = done; }
+        if (tid == 0) {
+            A.tear[e] = misc[0]; A.executed[e] = done;
+            if (A.stats) { A.stats[4 * e] = st_sweeps; A.stats[4 * e + 1] = st_dense; A.stats[4 * e + 2] = st_levels; A.stats[4 * e + 3] = st_trig; }
+        }
     }
 }
 

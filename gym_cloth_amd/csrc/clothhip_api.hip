@@ -48,17 +48,18 @@ struct clothhip_handle {
     void *d_pos = nullptr, *d_prev = nullptr, *d_rest = nullptr;
     uint8_t *d_cnt = nullptr, *d_active = nullptr;
     int rest_stride = 0;
-    int32_t *d_tear = nullptr, *d_exec = nullptr, *d_ngrab = nullptr;
+    int32_t *d_tear = nullptr, *d_exec = nullptr, *d_ngrab = nullptr, *d_stats = nullptr;
     ClothSchedule *d_sched = nullptr, *h_sched = nullptr;   // h_sched: pinned staging
-    uint32_t *d_gather = nullptr, *d_lv_ent = nullptr, *d_lv_rows = nullptr;
-    uint16_t *d_lv_off = nullptr;
+    uint32_t *d_gather = nullptr, *d_lv_ent = nullptr;
+    uint16_t *d_lv_off = nullptr, *d_pt_lev = nullptr;
+    int dense_thresh = 48;
     int HT = 0, ht_bits = 0, lvw_shift = 4, lds_bytes = 0, phase_mask = 15, nt = 256, ppt = 3;
-    bool tab_lds = false;
+    int tab = 0;            // static tables resident in LDS: 0 none, 1 springs/rest/offsets, 2 + per-point levels
+    bool rest_reg = false;
     double *d_levels = nullptr, *d_xy = nullptr, *d_radius = nullptr;
     int n_grab_levels = 0;
     Topology topo;
     LevelSchedule lv;
-    std::vector<uint32_t> lv_rows;
     std::vector<unsigned char> stage;   // host staging for layout conversion
     std::vector<double> flat_rest;
 };
@@ -133,7 +134,7 @@ template <typename T> static DevConsts<T> make_consts(const ClothParams &p) {
     const double w = 3 * dx, h = 3 * dy, t = (w > h) ? w : h;           // :308-310
     DevConsts<T> k;
     k.mg = (T)(mass * p.gravity);
-    k.ksK[0] = (T)(p.ks * 1.0); k.ksK[1] = (T)(p.ks * 0.2);
+    k.ks_str = (T)(p.ks * 1.0); k.ks_bend = (T)(p.ks * 0.2);
     k.dsm = (T)((delta_t * delta_t) / mass);
     k.damp = (T)(1.0 - p.damping / 100.0);
     k.cw = (T)w; k.ch = (T)h; k.ct = (T)t;
@@ -150,8 +151,8 @@ template <typename T> static DevConsts<T> make_consts(const ClothParams &p) {
 static void free_handle(clothhip_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    void *ptrs[] = {h->d_pos, h->d_prev, h->d_rest, h->d_cnt, h->d_active, h->d_tear, h->d_exec, h->d_ngrab,
-                    h->d_sched, h->d_gather, h->d_lv_ent, h->d_lv_off, h->d_lv_rows, h->d_levels, h->d_xy, h->d_radius};
+    void *ptrs[] = {h->d_pos, h->d_prev, h->d_rest, h->d_cnt, h->d_active, h->d_tear, h->d_exec, h->d_ngrab, h->d_stats,
+                    h->d_sched, h->d_gather, h->d_lv_ent, h->d_lv_off, h->d_pt_lev, h->d_levels, h->d_xy, h->d_radius};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->h_sched) (void)hipHostFree(h->h_sched);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -160,16 +161,7 @@ static void free_handle(clothhip_handle *h) {
     delete h;
 }
 
-template <typename T> static const void *stepper_fn_t(const clothhip_handle *h) {
-#define PICK(NT, PPT) (h->tab_lds ? (const void *)k_run_schedule<T, NT, PPT, true> : (const void *)k_run_schedule<T, NT, PPT, false>)
-    if (h->nt == 256) return PICK(256, 3);
-    if (h->ppt == 3) return PICK(1024, 3);
-    return PICK(1024, 4);
-#undef PICK
-}
-static const void *stepper_fn(const clothhip_handle *h) {
-    return h->precision == CLOTHHIP_F64 ? stepper_fn_t<double>(h) : stepper_fn_t<float>(h);
-}
+static const void *stepper_fn(const clothhip_handle *h);
 
 extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_t device, int32_t precision,
                                clothhip_handle **out) {
@@ -197,16 +189,6 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
     while ((1 << h->ht_bits) < h->HT) h->ht_bits++;
     h->lvw_shift = h->lv.max_width <= 16 ? 4 : (h->lv.max_width <= 32 ? 5 : 6);
     if (h->lv.max_width > 64) { delete h; return fail(CLOTHHIP_EINVAL, "level width %d > 64", h->lv.max_width); }
-    {   // grid-row groups touched by each dependency level (drives the exact level skipping of the strain sweep)
-        const int rs = h->N > 32 ? 1 : 0;
-        h->lv_rows.assign(h->lv.n_levels, 0u);
-        for (int L = 0; L < h->lv.n_levels; L++)
-            for (int p = h->lv.off[L]; p < h->lv.off[L + 1]; p++) {
-                const uint32_t en = h->lv.ent[p];
-                h->lv_rows[L] |= 1u << (((int)(en & 0xFFFFu) / h->N) >> rs);
-                h->lv_rows[L] |= 1u << (((int)(en >> 16) / h->N) >> rs);
-            }
-    }
     if (const char *pmk = getenv("CLOTHHIP_DEBUG_PHASES")) h->phase_mask = atoi(pmk);
     std::vector<uint32_t> gather = build_gather(h->topo, h->lv, h->Ppad);
     std::vector<double> levels = build_grab_levels(params->height, params->thickness);
@@ -234,12 +216,14 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
     HC(hipMalloc(&h->d_tear, E * 4));
     HC(hipMalloc(&h->d_exec, E * 4));
     HC(hipMalloc(&h->d_ngrab, E * 4));
+    HC(hipMalloc(&h->d_stats, E * 16));
+    HC(hipMemset(h->d_stats, 0, E * 16));
     HC(hipMalloc(&h->d_sched, E * sizeof(ClothSchedule)));
     HC(hipHostMalloc((void **)&h->h_sched, E * sizeof(ClothSchedule), hipHostMallocDefault));
     HC(hipMalloc(&h->d_gather, gather.size() * 4));
     HC(hipMalloc(&h->d_lv_ent, (size_t)h->Spad * 4));
     HC(hipMalloc(&h->d_lv_off, (size_t)(h->lv.n_levels + 1) * 2));
-    HC(hipMalloc(&h->d_lv_rows, (size_t)h->lv.n_levels * 4));
+    HC(hipMalloc(&h->d_pt_lev, (size_t)HK_SLOTS * h->Ppad * 2));
     HC(hipMalloc(&h->d_levels, (levels.size() + 1) * 8));
     HC(hipMalloc(&h->d_xy, E * 2 * 8));
     HC(hipMalloc(&h->d_radius, E * 8));
@@ -250,21 +234,38 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
         std::vector<uint16_t> off16(h->lv.off.begin(), h->lv.off.end());
         HC(hipMemcpy(h->d_lv_off, off16.data(), off16.size() * 2, hipMemcpyHostToDevice));
     }
-    HC(hipMemcpy(h->d_lv_rows, h->lv_rows.data(), (size_t)h->lv.n_levels * 4, hipMemcpyHostToDevice));
+    {   // dependency level of every incident spring of every point (for the exact pending-level marking)
+        std::vector<int> lvl_of_pos(h->S);
+        for (int L = 0; L < h->lv.n_levels; L++)
+            for (int p = h->lv.off[L]; p < h->lv.off[L + 1]; p++) lvl_of_pos[p] = L;
+        std::vector<uint16_t> pl((size_t)HK_SLOTS * h->Ppad, (uint16_t)0xFFFF);
+        for (int sl = 0; sl < HK_SLOTS; sl++)
+            for (int i = 0; i < h->P; i++) {
+                const uint32_t g = gather[(size_t)sl * h->Ppad + i];
+                if (g & HK_VALID) pl[(size_t)sl * h->Ppad + i] = (uint16_t)lvl_of_pos[(g >> HK_POS_SHIFT) & HK_POS_MASK];
+            }
+        HC(hipMemcpy(h->d_pt_lev, pl.data(), pl.size() * 2, hipMemcpyHostToDevice));
+    }
+    if (const char *dt = getenv("CLOTHHIP_DEBUG_DENSE")) h->dense_thresh = atoi(dt);
     HC(hipMemset(h->d_rest, 0, E * h->Spad * h->tsz));
     if (!levels.empty()) HC(hipMemcpy(h->d_levels, levels.data(), levels.size() * 8, hipMemcpyHostToDevice));
     HC(hipMemset(h->d_exec, 0, E * 4));
-    // large dynamic LDS (up to the CU's 160 KiB) for the stepper kernels; the static tables ride in LDS too
-    // when that still leaves room for two cloths per CU (512 cloths = 2 per CU on 256 CUs)
+    // large dynamic LDS (up to the CU's 160 KiB) for the stepper kernels. The static tables ride in LDS too
+    // as long as TWO cloths still fit per CU (512 cloths = 2 per CU on the 256 CUs of an MI355X).
     {
         const int tsz = (int)h->tsz;
-        const int with_tab = LdsLayout(tsz, h->Ppad, h->Spad, h->lv.n_levels, h->HT, true).total;
-        const int without = LdsLayout(tsz, h->Ppad, h->Spad, h->lv.n_levels, h->HT, false).total;
-        h->tab_lds = with_tab <= 160 * 1024;
-        if (const char *t = getenv("CLOTHHIP_DEBUG_TAB_LDS")) h->tab_lds = atoi(t) != 0 && with_tab <= 160 * 1024;
-        h->lds_bytes = h->tab_lds ? with_tab : without;
+        // 256-thread variants: two cloths per CU (<= 80 KiB each); 1024-thread variants own the CU (<= 160 KiB)
+        const int budget = h->nt == 256 ? 80 * 1024 : 160 * 1024;
+        const int tmax = h->nt == 256 ? 2 : (h->ppt == 3 ? 1 : 0);
+        h->tab = 0;
+        for (int t = tmax; t >= 1; t--)
+            if (LdsLayout(tsz, h->Ppad, h->Spad, h->lv.n_levels, h->HT, t).total <= budget) { h->tab = t; break; }
+        if (const char *t = getenv("CLOTHHIP_DEBUG_TAB_LDS")) h->tab = std::min(h->tab, atoi(t));
+        h->rest_reg = (h->nt == 256 && precision == CLOTHHIP_F32 && h->tab == 2);
+        h->lds_bytes = LdsLayout(tsz, h->Ppad, h->Spad, h->lv.n_levels, h->HT, h->tab).total;
         if (h->lds_bytes > 160 * 1024) { free_handle(h); return fail(CLOTHHIP_EINVAL, "n_side %d needs %d B of LDS (> 160 KiB)", h->N, h->lds_bytes); }
         const void *fn = stepper_fn(h);
+        if (!fn) { free_handle(h); return fail(CLOTHHIP_EINVAL, "no stepper variant for n_side %d", h->N); }
         HC(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes));
     }
 #undef HC
@@ -466,8 +467,8 @@ extern "C" int clothhip_pin_points(clothhip_handle *h, int32_t env, const int32_
 template <typename T> static StepArgs<T> make_args(clothhip_handle *h, const ClothSchedule *d_sched) {
     StepArgs<T> a;
     a.pos = (T *)h->d_pos; a.prev = (T *)h->d_prev; a.cnt = h->d_cnt; a.rest = (const T *)h->d_rest;
-    a.tear = h->d_tear; a.executed = h->d_exec; a.sched = d_sched;
-    a.gather = h->d_gather; a.lv_ent = h->d_lv_ent; a.lv_off = h->d_lv_off; a.lv_rows = h->d_lv_rows;
+    a.tear = h->d_tear; a.executed = h->d_exec; a.stats = h->d_stats; a.sched = d_sched;
+    a.gather = h->d_gather; a.lv_ent = h->d_lv_ent; a.lv_off = h->d_lv_off; a.pt_lev = h->d_pt_lev; a.dense_thresh = h->dense_thresh;
     a.n_levels = h->lv.n_levels;
     a.N = h->N; a.P = h->P; a.Ppad = h->Ppad; a.S = h->S; a.Spad = h->Spad;
     a.HT = h->HT; a.ht_bits = h->ht_bits; a.lvw_shift = h->lvw_shift;
@@ -476,17 +477,31 @@ template <typename T> static StepArgs<T> make_args(clothhip_handle *h, const Clo
     return a;
 }
 
+// compile-time variants: (threads per cloth, particles per thread) x tables-in-LDS level x rest-in-registers
+#define CLOTH_VARIANTS(X, T)                                              \
+    X(T, 256, 3, 2, true) X(T, 256, 3, 2, false) X(T, 256, 3, 1, false) X(T, 256, 3, 0, false)   \
+    X(T, 1024, 3, 0, false) X(T, 1024, 3, 1, false) X(T, 1024, 4, 0, false)
+
+template <typename T> static const void *stepper_fn_t(const clothhip_handle *h) {
+#define X(T_, NT, PPT, TAB, RR) \
+    if (h->nt == NT && h->ppt == PPT && h->tab == TAB && h->rest_reg == RR) return (const void *)k_run_schedule<T_, NT, PPT, TAB, RR>;
+    CLOTH_VARIANTS(X, T)
+#undef X
+    return nullptr;
+}
+static const void *stepper_fn(const clothhip_handle *h) {
+    return h->precision == CLOTHHIP_F64 ? stepper_fn_t<double>(h) : stepper_fn_t<float>(h);
+}
+
 template <typename T> static void launch_run(clothhip_handle *h, const ClothSchedule *d_sched) {
     StepArgs<T> a = make_args<T>(h, d_sched);
-#define LAUNCH(NT, PPT)                                                                                              \
-    do {                                                                                                             \
-        if (h->tab_lds) hipLaunchKernelGGL((k_run_schedule<T, NT, PPT, true>), dim3(h->E), dim3(NT), h->lds_bytes, h->stream, a);  \
-        else hipLaunchKernelGGL((k_run_schedule<T, NT, PPT, false>), dim3(h->E), dim3(NT), h->lds_bytes, h->stream, a);           \
-    } while (0)
-    if (h->nt == 256) LAUNCH(256, 3);
-    else if (h->ppt == 3) LAUNCH(1024, 3);
-    else LAUNCH(1024, 4);
-#undef LAUNCH
+#define X(T_, NT, PPT, TAB, RR)                                                                         \
+    if (h->nt == NT && h->ppt == PPT && h->tab == TAB && h->rest_reg == RR) {                           \
+        hipLaunchKernelGGL((k_run_schedule<T_, NT, PPT, TAB, RR>), dim3(h->E), dim3(NT), h->lds_bytes, h->stream, a); \
+        return;                                                                                         \
+    }
+    CLOTH_VARIANTS(X, T)
+#undef X
 }
 
 static int run_common(clothhip_handle *h, const ClothSchedule *d_sched) {
@@ -619,6 +634,14 @@ extern "C" int clothhip_write_obs_f32_device(clothhip_handle *h, void *d_out) {
     else
         hipLaunchKernelGGL(k_write_obs<float>, dim3(h->E), dim3(256), 0, h->stream, (const float *)h->d_pos, (float *)d_out, h->P, h->Ppad);
     HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int clothhip_debug_stats(clothhip_handle *h, int32_t *stats) {
+    if (!h || !stats) return fail(CLOTHHIP_EINVAL, "NULL argument");
+    HIPCHECK(hipSetDevice(h->device));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    HIPCHECK(hipMemcpy(stats, h->d_stats, (size_t)h->E * 16, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -170,6 +170,10 @@ void *clothhip_stream(clothhip_handle *h);
  * handle's stream around the stepper kernel: milliseconds, or a negative value if none. */
 double clothhip_last_kernel_ms(clothhip_handle *h);
 
+/* Diagnostics of the last clothhip_run*: stats[E][4] = {strain sweeps run, of which dense, dependency levels
+ * executed, levels in which a correction was applied}. Not part of the reference surface. */
+int clothhip_debug_stats(clothhip_handle *h, int32_t *stats);
+
 /* Arithmetic self-test used by the parity tests: evaluates out[i] = op(a[i], b[i]) in double ON THE
  * DEVICE with the same compiler flags as the stepper (op 0: a/b, 1: sqrt(a), 2: a*b+c unfused = (a*b)+b,
  * 3: floor(a/b)).  Lets tests assert IEEE-correct rounding of the device's sqrt/div bit-for-bit. */

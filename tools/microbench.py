@@ -40,19 +40,26 @@ def main():
         regimes = {"fold50-pull": (2, [0.0014142, 0.0014142, 0.0]), "fold50-rest": (6, None)}
     else:
         g = load_golden("g_traj_lift_pull_25.npz")
-        regimes = {"rest": (14, None), "pull": (9, [0.0012, 0.0016, 0.0]), "lift": (4, [0.0, 0.0, 0.0025])}
+        regimes = {"settled": ("env", None), "rest": (14, None), "pull": (9, [0.0012, 0.0016, 0.0]),
+                   "lift": (4, [0.0, 0.0, 0.0025])}
         gf = load_golden("g_traj_fold_25.npz")
+        ge = load_golden("g_env_tier1_1337.npz")
     for name, (cp, delta) in regimes.items():
         for mask in [int(m) for m in args.masks.split(",")]:
             os.environ["CLOTHHIP_DEBUG_PHASES"] = str(mask)
             b = ClothBatch(cfg_from_golden(g), n_envs=args.envs, precision=args.precision)
-            b.set_state(g["cp_pos"][cp], g["cp_prev"][cp], g["cp_pinned"][cp], g["rest"])
+            if cp == "env":
+                st = (ge["post_pos"], ge["post_prev"], ge["post_pinned"], ge["rest"])
+            else:
+                st = (g["cp_pos"][cp], g["cp_prev"][cp], g["cp_pinned"][cp], g["rest"])
+            b.set_state(*st)
             b.update(20, delta=delta)
-            b.set_state(g["cp_pos"][cp], g["cp_prev"][cp], g["cp_pinned"][cp], g["rest"])
+            b.set_state(*st)
             b.update(args.sub, delta=delta)
             ms = b.last_kernel_ms
-            print("%-12s mask %2d: %8.2f us/substep  (%6.2f M substeps/s at E=%d)" %
-                  (name, mask, ms * 1e3 / args.sub, args.envs * args.sub / ms / 1e3, args.envs), flush=True)
+            st = b.debug_stats()[0] / float(args.sub)
+            print("%-12s mask %2d: %8.2f us/substep  (%6.2f M substeps/s at E=%d)  per substep: sweeps %.2f dense %.2f levels %.1f corrected %.1f" %
+                  (name, mask, ms * 1e3 / args.sub, args.envs * args.sub / ms / 1e3, args.envs, st[0], st[1], st[2], st[3]), flush=True)
             b.close()
     if not args.n50:
         os.environ["CLOTHHIP_DEBUG_PHASES"] = "15"
