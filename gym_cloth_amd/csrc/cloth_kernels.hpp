@@ -45,7 +45,8 @@ template <typename T> struct StepArgs {
     const T *rest;           // [E or 1][Spad] rest lengths in LEVEL order
     int32_t *tear;           // [E] sticky Cloth.cloth_have_tear
     int32_t *executed;       // [E]
-    int32_t *stats;          // [E][4] or nullptr: sweeps run, dense sweeps, levels executed, levels that corrected
+    int32_t *stats;          // [E][16] or nullptr: [0..3] sweeps run, dense sweeps, levels executed, levels that corrected;
+                             // [4..15] with PH_TIME: shader cycles/64 spent per phase (wave 0's view)
     const ClothSchedule *sched;   // [E]
     const uint32_t *gather;  // [HK_SLOTS][Ppad]
     const uint32_t *lv_ent;  // [Spad]  ptA | ptB<<16, level order
@@ -66,7 +67,7 @@ constexpr uint32_t KEY_BIAS = 1u << 19;
 constexpr uint32_t KEY_FLOOR = 4096u;         // stored keys are >= KEY_FLOOR so a slot can later hold a point index (< 4096)
 constexpr uint32_t KEY_EMPTY = 0xFFFFFFFFu;
 constexpr uint8_t CNT_GRAB_MASK = 0x7F, CNT_EXT_PIN = 0x80;
-enum { PH_HOOKE = 1, PH_COLLIDE = 2, PH_PLANE = 4, PH_STRAIN = 8, PH_NOSKIP = 16 };
+enum { PH_HOOKE = 1, PH_COLLIDE = 2, PH_PLANE = 4, PH_STRAIN = 8, PH_NOSKIP = 16, PH_TIME = 32 };
 
 // double: correctly rounded IEEE sqrt / division (bit parity with the reference's CPython doubles).
 // float : the hardware's 1-ulp v_sqrt_f32 / v_rcp_f32 (the fp32 instantiation is the throughput mode; its
@@ -119,7 +120,7 @@ template <typename T> __device__ __forceinline__ uint32_t cell_key(const DevCons
 // LDS carve-up (dynamic shared memory), all offsets in bytes, 16-byte aligned.
 // tab: 0 = static tables stay in global memory, 1 = ent/rest/off in LDS, 2 = + per-point level table
 struct LdsLayout {
-    int cur, ent, rest, off, plev, flag, hkey, hco, memb, slot, misc, total;
+    int cur, ent, rest, off, plev, flag, abits, hkey, hco, memb, slot, misc, total;
     __host__ __device__ LdsLayout(int tsz, int Ppad, int Spad, int nL, int HT, int tab) {
         int o = 0;
         auto take = [&](int bytes) { int r = o; o += (bytes + 15) / 16 * 16; return r; };
@@ -128,7 +129,8 @@ struct LdsLayout {
         rest = take(tab >= 1 ? Spad * tsz : 0);
         off = take(tab >= 1 ? (nL + 1) * 2 : 0);
         plev = take(tab >= 2 ? HK_SLOTS * Ppad * 2 : 0);
-        flag = take(nL + 64);
+        flag = take(nL + 64);        // pending-level marks of the running sweep (all zero between sweeps)
+        abits = take((Spad / 64 + 2) * 8);   // pre-pass: one bit per spring (level order)
         hkey = take(HT * 4);
         hco = take(HT * 4);          // (fill cursor << 16) | member count
         memb = take(Ppad * 2);
@@ -176,7 +178,7 @@ __device__ __forceinline__ int strain_spring(Pt<T> *cur, uint32_t en, T r, const
 // `first` = smallest member index that can move (from the parallel pre-check); members before it provably
 // do not move. n <= 64.
 template <typename T>
-__device__ __forceinline__ void collide_cell_wave(Pt<T> *cur, uint16_t *m, int n, int first,
+__device__ __forceinline__ void collide_cell_wave(Pt<T> *cur, uint16_t *m, const uint16_t *slot, int n, int first,
                                                   const DevConsts<T> &k, int lane) {
     const bool in = lane < n;
     const int mine = in ? (int)m[lane] : 0x7fff;
@@ -189,13 +191,15 @@ __device__ __forceinline__ void collide_cell_wave(Pt<T> *cur, uint16_t *m, int n
     const int i = in ? (int)m[lane] : 0;
     const Pt<T> me = cur[i];
     T x = me.x, y = me.y, z = me.z;
-    const unsigned long long pinmask = __ballot(in && w_cnt(me.w) != 0);
-    const unsigned long long lt = __ballot(in && i < first);
-    const int a0 = __popcll(lt);                      // rank of the first possible mover
+    // members to visit: candidates (a neighbour close enough that it could come within range even after both
+    // moved by the per-substep maximum) that are not pinned, from the first real mover on. Everyone else
+    // provably collects no hit (cloth.pyx:330 never true) and is skipped without changing the result.
+    unsigned long long todo = __ballot(in && (slot[i] & 0x8000u) != 0 && w_cnt(me.w) == 0 && i >= first);
     const T thr2 = k.thresh * k.thresh * ((T)1 + filt_slack<T>());
     bool moved = false;
-    for (int a = a0; a < n; a++) {
-        if ((pinmask >> a) & 1ull) continue;                                            // :314
+    while (todo) {
+        const int a = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+        todo &= todo - 1ull;
         const T xa = bcast(x, a), ya = bcast(y, a), za = bcast(z, a);
         const T dx = xa - x, dy = ya - y, dz = za - z;
         const T d2 = dx * dx + dy * dy + dz * dz;
@@ -327,14 +331,25 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 2 : NT / 256)) void k_run_schedule
             for (int i = tid; i < HK_SLOTS * Ppad; i += NT) d4[i] = A.pt_lev[i];
         }
         for (int h = tid; h < HT; h += NT) { hkey[h] = KEY_EMPTY; hco[h] = 0; }
+        for (int i = tid; i < nL + 64; i += NT) lvflag[i] = 0;
         if (tid == 0) { misc[0] = A.tear[e]; misc[1] = 0; }
     }
     __syncthreads();
 
     const T dz_up = (T)sc.dz_up, dxp = (T)sc.dx_pull, dyp = (T)sc.dy_pull, dzp = (T)sc.dz_pull;
-    const int W = 1 << A.lvw_shift;
     int done = 0;
     int st_sweeps = 0, st_dense = 0, st_levels = 0, st_trig = 0;      // wave 0 only (uniform)
+    unsigned long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+    const bool timing = (pm & PH_TIME) != 0;
+#define TSTAMP(slot_)                                                          \
+    if (timing) {                                                              \
+        unsigned long long tn_;                                                \
+        __builtin_amdgcn_sched_barrier(0);                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tn_)::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                     \
+        tph[slot_] += tn_ - tlast; tlast = tn_;                                \
+    }
+    if (timing) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory"); }
     for (int it = 0; it < sc.n_total; it++) {
         // ---- ClothEnv._pull (cloth_env.py:352-367): adjust / nothing / release -------------------
         int mode = 0; T ax = 0, ay = 0, az = 0;
@@ -370,6 +385,7 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 2 : NT / 256)) void k_run_schedule
             __syncthreads();
         }
 
+        TSTAMP(0)
         // ---- gravity + Hooke gather + Verlet (cloth.pyx:216-256) ----------------------------------
         if (pm & PH_HOOKE) {
             // Per particle: f = (0,0,m*g) + sum over its incident springs in ascending list index of fm * (nbr - self).
@@ -414,25 +430,43 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 2 : NT / 256)) void k_run_schedule
             }
         }
 
+        TSTAMP(1)
         // ---- spatial map (cloth.pyx:298-311): hash table in LDS keyed by the exact cell key, CSR member
         // lists; the order inside a cell is restored to ascending point index by the cell's wave.
         if (pm & PH_COLLIDE) {
+            Pt<T> cme[PPT];
+            uint32_t ckey[PPT], ch[PPT];
+#pragma unroll
+            for (int q = 0; q < PPT; q++) {                 // batched: the PPT particles' LDS traffic overlaps
+                const int i = tid + q * NT;
+                cme[q] = cur[i < P ? i : 0];                                                      // own slot: no hazard
+                ckey[q] = cell_key<T>(k, cme[q].x, cme[q].y, cme[q].z);
+                ch[q] = (ckey[q] * 2654435761u) >> (32 - A.ht_bits);
+            }
+            {
+                bool pend[PPT];
+                bool anyp = false;
+#pragma unroll
+                for (int q = 0; q < PPT; q++) { pend[q] = tid + q * NT < P; anyp |= pend[q]; }
+                while (anyp) {
+                    anyp = false;
+#pragma unroll
+                    for (int q = 0; q < PPT; q++) {
+                        if (pend[q]) {
+                            const uint32_t old = atomicCAS(&hkey[ch[q]], KEY_EMPTY, ckey[q]);
+                            if (old == KEY_EMPTY || old == ckey[q]) pend[q] = false;
+                            else { ch[q] = (ch[q] + 1) & (uint32_t)(HT - 1); anyp = true; }
+                        }
+                    }
+                }
+            }
 #pragma unroll
             for (int q = 0; q < PPT; q++) {
                 const int i = tid + q * NT;
-                if (i >= P) continue;
-                const Pt<T> me = cur[i];                                                          // own slot: no hazard
-                const uint32_t key = cell_key<T>(k, me.x, me.y, me.z);
-                uint32_t h = (key * 2654435761u) >> (32 - A.ht_bits);
-                while (true) {
-                    const uint32_t old = atomicCAS(&hkey[h], KEY_EMPTY, key);
-                    if (old == KEY_EMPTY || old == key) break;
-                    h = (h + 1) & (uint32_t)(HT - 1);
-                }
-                slot[i] = (uint16_t)h;
-                atomicAdd(&hco[h], 1u);
+                if (i < P) { slot[i] = (uint16_t)ch[q]; atomicAdd(&hco[ch[q]], 1u); }
             }
             __syncthreads();
+            TSTAMP(2)
             // exclusive prefix sum of the slot counts -> fill cursors (each thread owns HT/NT consecutive slots)
             const int per = HT / NT;
             uint32_t loc = 0;
@@ -449,58 +483,93 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 2 : NT / 256)) void k_run_schedule
                 base += c;
             }
             __syncthreads();
+            TSTAMP(3)
 #pragma unroll
             for (int q = 0; q < PPT; q++) {
                 const int i = tid + q * NT;
-                if (i >= P) continue;
-                const uint32_t old = atomicAdd(&hco[slot[i]], 1u << 16);   // afterwards cursor = END of the cell
-                memb[old >> 16] = (uint16_t)i;
+                if (i < P) {
+                    const uint32_t old = atomicAdd(&hco[ch[q]], 1u << 16);  // afterwards cursor = END of the cell
+                    memb[old >> 16] = (uint16_t)i;
+                }
             }
             __syncthreads();
+            TSTAMP(4)
             // ---- self-collision (cloth.pyx:313-343) ------------------------------------------------------
             // (1) every particle, in parallel: can it move at all (any same-cell candidate within 2*thickness
             //     at the CURRENT positions)? the smallest such index per cell is the first mover; everything
             //     before it provably stays put. The key word of the slot is recycled to hold that index.
             const T thr2 = k.thresh * k.thresh * ((T)1 + filt_slack<T>());
+            // candidate radius: a particle moves at most thresh/steps in this phase (|corr| = |tot/n/steps| and
+            // every summand has length thresh - dist <= thresh), so a pair farther apart than
+            // thresh * (1 + 2/steps) now can never come within thresh during the sweep.
+            const T cfac = (T)1 + (T)2 / k.sim_steps;
+            const T thr2c = thr2 * cfac * cfac;
+            {
+                int cn[PPT], cstart[PPT];
+                int nmax = 0;
 #pragma unroll
-            for (int q = 0; q < PPT; q++) {
-                const int i = tid + q * NT;
-                if (i >= P) continue;
-                const int sl = (int)slot[i];
-                const uint32_t co = hco[sl];
-                const int n = (int)(co & 0xFFFFu);
-                if (n < 2) continue;
-                const Pt<T> me = cur[i];
-                if (w_cnt(me.w)) continue;
-                const uint16_t *m = memb + ((int)(co >> 16) - n);
-                bool hit = false;
-                for (int b = 0; b < n; b++) {
-                    const int j = (int)m[b];
-                    const Pt<T> o = cur[j];
-                    const T dx = me.x - o.x, dy = me.y - o.y, dz = me.z - o.z;
-                    hit |= (j != i) && !(dx * dx + dy * dy + dz * dz > thr2);
+                for (int q = 0; q < PPT; q++) {
+                    const uint32_t co = hco[ch[q]];
+                    const bool use = (tid + q * NT < P) && w_cnt(cme[q].w) == 0;
+                    cn[q] = use ? (int)(co & 0xFFFFu) : 0;
+                    if (cn[q] < 2) cn[q] = 0;
+                    cstart[q] = (int)(co >> 16) - (int)(co & 0xFFFFu);
+                    nmax = cn[q] > nmax ? cn[q] : nmax;
                 }
-                if (hit) atomicMin(&hkey[sl], (uint32_t)i);
+                bool hit[PPT], cand[PPT];
+#pragma unroll
+                for (int q = 0; q < PPT; q++) hit[q] = cand[q] = false;
+                for (int b = 0; b < nmax; b += 4) {          // 4 members x PPT particles per trip: their LDS reads overlap
+                    int jj[PPT][4];
+#pragma unroll
+                    for (int q = 0; q < PPT; q++)
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const int bb = b + u < cn[q] ? b + u : 0;               // clamped: always a valid read
+                            jj[q][u] = (int)memb[cn[q] ? cstart[q] + bb : 0];
+                        }
+#pragma unroll
+                    for (int q = 0; q < PPT; q++)
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const Pt<T> o = cur[jj[q][u]];
+                            const T dx = cme[q].x - o.x, dy = cme[q].y - o.y, dz = cme[q].z - o.z;
+                            const T d2 = dx * dx + dy * dy + dz * dz;
+                            const bool other = (b + u < cn[q]) && jj[q][u] != tid + q * NT;
+                            hit[q] |= other && !(d2 > thr2);
+                            cand[q] |= other && !(d2 > thr2c);
+                        }
+                }
+#pragma unroll
+                for (int q = 0; q < PPT; q++) {
+                    if (hit[q]) atomicMin(&hkey[ch[q]], (uint32_t)(tid + q * NT));
+                    if (cand[q]) slot[tid + q * NT] = (uint16_t)(ch[q] | 0x8000u);
+                }
             }
             __syncthreads();
-            // (2) one wave per cell that has a mover: exact Gauss-Seidel sweep from the first mover on
+            TSTAMP(5)
+            // (2) one wave per cell that has a mover: exact Gauss-Seidel sweep from the first mover on. Every wave
+            // scans all slots and takes every nw-th active cell, so the cells are spread evenly over the waves.
             {
                 const int wave = tid >> 6, nw = NT >> 6;
-                for (int h0 = wave * 64; h0 < HT; h0 += nw * 64) {
+                int seen = 0;
+                for (int h0 = 0; h0 < HT; h0 += 64) {
                     unsigned long long am = __ballot(hkey[h0 + lane] < KEY_FLOOR);
                     while (am) {
                         const int b = __builtin_amdgcn_readfirstlane(__ffsll((long long)am) - 1);
                         am &= am - 1ull;
+                        if ((seen++ % nw) != wave) continue;
                         const uint32_t co = hco[h0 + b];
                         const int n = (int)(co & 0xFFFFu);
                         uint16_t *m = memb + ((int)(co >> 16) - n);
                         const int first = (int)hkey[h0 + b];
-                        if (n <= 64) collide_cell_wave<T>(cur, m, n, first, k, lane);
+                        if (n <= 64) collide_cell_wave<T>(cur, m, slot, n, first, k, lane);
                         else if (lane == 0) collide_cell_serial<T>(cur, m, n, k);
                     }
                 }
             }
             __syncthreads();
+            TSTAMP(6)
             for (int h = tid; h < HT; h += NT) { hkey[h] = KEY_EMPTY; hco[h] = 0; }     // ready for the next substep
         } else {
             __syncthreads();
@@ -524,6 +593,7 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 2 : NT / 256)) void k_run_schedule
         }
         __syncthreads();
 
+        TSTAMP(7)
         // ---- strain limit + tear (cloth.pyx:258-296) ---------------------------------------------------
         // (1) all threads: which levels hold a spring that would stretch/tear at the CURRENT positions?
         //     A spring untouched by earlier corrections of the sweep behaves exactly as evaluated here.
@@ -532,34 +602,29 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 2 : NT / 256)) void k_run_schedule
         //     correction marks exactly those levels); everything it skips is provably a no-op.
         if (pm & PH_STRAIN) {
             {
-                const int sub = tid & (W - 1), grp = tid >> A.lvw_shift, G = NT >> A.lvw_shift;
-                const int gsh = (lane >> A.lvw_shift) << A.lvw_shift;
-                const unsigned long long gm = (W == 64 ? ~0ull : ((1ull << W) - 1ull)) << gsh;
-                int nflag = 0;
-                for (int L0 = 0; L0 < nL; L0 += G) {
-                    const int L = L0 + grp;
+                unsigned long long *abits = reinterpret_cast<unsigned long long *>(smem + lay.abits);
+                int nact = 0;
+                for (int p0 = 0; p0 < A.Spad; p0 += NT) {
+                    const int p = p0 + tid;
                     bool act = false;
-                    if (L < nL) {
-                        const int idx = (int)loff[L] + sub;
-                        if (idx < (int)loff[L + 1]) {
-                            const uint32_t en = ent[idx];
-                            const T r = rest[idx];
-                            const Pt<T> a = cur[en & 0xFFFFu], b = cur[en >> 16];
-                            const T dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
-                            const T len2 = dx * dx + dy * dy + dz * dz;
-                            const T t11 = r * k.c11, tt = r * k.tear_thresh;
-                            const T tmin = t11 < tt ? t11 : tt;
-                            act = !((w_cnt(a.w) != 0) & (w_cnt(b.w) != 0)) & (len2 > tmin * tmin * ((T)1 - filt_slack<T>()));
-                        }
+                    if (p < A.S) {
+                        const uint32_t en = ent[p];
+                        const T r = rest[p];
+                        const Pt<T> a = cur[en & 0xFFFFu], b = cur[en >> 16];
+                        const T dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+                        const T len2 = dx * dx + dy * dy + dz * dz;
+                        const T t11 = r * k.c11, tt = r * k.tear_thresh;
+                        const T tmin = t11 < tt ? t11 : tt;
+                        act = !(w_cnt(a.w) != 0 && w_cnt(b.w) != 0) && (len2 > tmin * tmin * ((T)1 - filt_slack<T>()));
                     }
                     const unsigned long long bal = __ballot(act);
-                    const bool gact = (bal & gm) != 0ull;
-                    if (sub == 0 && L < nL) lvflag[L] = gact ? 1 : 0;
-                    nflag += __popcll(__ballot(gact && sub == 0));
+                    if (lane == 0 && p < A.Spad) abits[p >> 6] = bal;
+                    nact += __popcll(bal);
                 }
-                if (nflag && lane == 0) atomicAdd(&misc[1], nflag);
+                if (nact && lane == 0) atomicAdd(&misc[1], nact);
             }
             __syncthreads();
+            TSTAMP(8)
             if (tid < 64 && (misc[1] || (pm & PH_NOSKIP))) {
                 int tear = 0;
                 // dense: so many levels are flagged that tracking costs more than it saves -> run every level.
@@ -570,7 +635,17 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 2 : NT / 256)) void k_run_schedule
                     const int Lm = L0 + lane;
                     const bool valid = Lm < nL;
                     const int myoff = valid ? (int)loff[Lm] : 0, myoff1 = valid ? (int)loff[Lm + 1] : 0;
-                    unsigned long long need = __ballot(valid && (dense || lvflag[Lm] != 0));
+                    bool want = dense && valid;
+                    if (valid) {
+                        // any pre-pass bit in this level's spring range [myoff, myoff1)?  (width <= 64)
+                        const unsigned long long *abits = reinterpret_cast<const unsigned long long *>(smem + lay.abits);
+                        const int w0 = myoff >> 6, sh = myoff & 63, nb = myoff1 - myoff;
+                        unsigned long long bits = abits[w0] >> sh;
+                        if (sh) bits |= abits[w0 + 1] << (64 - sh);
+                        want |= (bits & (nb >= 64 ? ~0ull : ((1ull << nb) - 1ull))) != 0ull;
+                        if (lvflag[Lm]) { want = true; lvflag[Lm] = 0; }        // pending mark from an earlier correction
+                    }
+                    unsigned long long need = __ballot(want);
                     int pf_j = -1;
                     uint32_t pf_en = 0u; T pf_r = (T)0;
                     while (need) {
@@ -595,18 +670,25 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 2 : NT / 256)) void k_run_schedule
                             if (moved) {
                                 const int Lcur = L0 + j;
                                 const int pa_ = (int)(en & 0xFFFFu), pb_ = (int)(en >> 16);
-#pragma unroll 1
+                                int lv[2 * HK_SLOTS];
+#pragma unroll
+                                for (int sl = 0; sl < HK_SLOTS; sl++) {         // 24 independent LDS reads, one round trip
+                                    lv[2 * sl] = (int)plev[sl * Ppad + pa_];
+                                    lv[2 * sl + 1] = (int)plev[sl * Ppad + pb_];
+                                }
+#pragma unroll
                                 for (int sl = 0; sl < HK_SLOTS; sl++) {
-                                    const int la = (int)plev[sl * Ppad + pa_], lb = (int)plev[sl * Ppad + pb_];
-                                    if ((moved & 1) && la != 0xFFFF && la > Lcur) lvflag[la] = 1;
-                                    if ((moved & 2) && lb != 0xFFFF && lb > Lcur) lvflag[lb] = 1;
+                                    if ((moved & 1) && lv[2 * sl] != 0xFFFF && lv[2 * sl] > Lcur) lvflag[lv[2 * sl]] = 1;
+                                    if ((moved & 2) && lv[2 * sl + 1] != 0xFFFF && lv[2 * sl + 1] > Lcur) lvflag[lv[2 * sl + 1]] = 1;
                                 }
                             }
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                             __builtin_amdgcn_wave_barrier();
                             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                            // refresh the rest of this chunk from the flags (later chunks read them when they start)
-                            need |= __ballot(valid && lvflag[Lm] != 0) & ~((2ull << j) - 1ull);
+                            // refresh the rest of this chunk from the marks (later chunks consume theirs when they start)
+                            const bool upd = valid && Lm > L0 + j && lvflag[Lm] != 0;
+                            if (upd) lvflag[Lm] = 0;
+                            need |= __ballot(upd);
                         }
                         // the next level's lanes read what this level's lanes wrote: same wave, LDS is in order;
                         // the fences only stop the compiler from moving LDS accesses across the level boundary.
@@ -620,10 +702,12 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 2 : NT / 256)) void k_run_schedule
             }
             __syncthreads();
         }
+        TSTAMP(9)
         done++;
         if (sc.break_on_tear && misc[0]) break;                                            // cloth_env.py:511-514
     }
 
+#undef TSTAMP
     {   // LDS / registers -> HBM
         __syncthreads();
         T *gp = A.pos + (size_t)e * 3 * Ppad, *gq = A.prev + (size_t)e * 3 * Ppad;
@@ -639,7 +723,10 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 2 : NT / 256)) void k_run_schedule
         }
         if (tid == 0) {
             A.tear[e] = misc[0]; A.executed[e] = done;
-            if (A.stats) { A.stats[4 * e] = st_sweeps; A.stats[4 * e + 1] = st_dense; A.stats[4 * e + 2] = st_levels; A.stats[4 * e + 3] = st_trig; }
+            if (A.stats) {
+                A.stats[16 * e] = st_sweeps; A.stats[16 * e + 1] = st_dense; A.stats[16 * e + 2] = st_levels; A.stats[16 * e + 3] = st_trig;
+                for (int q = 0; q < 12; q++) A.stats[16 * e + 4 + q] = (int)(tph[q] >> 6);
+            }
         }
     }
 }

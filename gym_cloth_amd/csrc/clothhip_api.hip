@@ -216,8 +216,8 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
     HC(hipMalloc(&h->d_tear, E * 4));
     HC(hipMalloc(&h->d_exec, E * 4));
     HC(hipMalloc(&h->d_ngrab, E * 4));
-    HC(hipMalloc(&h->d_stats, E * 16));
-    HC(hipMemset(h->d_stats, 0, E * 16));
+    HC(hipMalloc(&h->d_stats, E * 64));
+    HC(hipMemset(h->d_stats, 0, E * 64));
     HC(hipMalloc(&h->d_sched, E * sizeof(ClothSchedule)));
     HC(hipHostMalloc((void **)&h->h_sched, E * sizeof(ClothSchedule), hipHostMallocDefault));
     HC(hipMalloc(&h->d_gather, gather.size() * 4));
@@ -641,7 +641,7 @@ extern "C" int clothhip_debug_stats(clothhip_handle *h, int32_t *stats) {
     if (!h || !stats) return fail(CLOTHHIP_EINVAL, "NULL argument");
     HIPCHECK(hipSetDevice(h->device));
     HIPCHECK(hipStreamSynchronize(h->stream));
-    HIPCHECK(hipMemcpy(stats, h->d_stats, (size_t)h->E * 16, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(stats, h->d_stats, (size_t)h->E * 64, hipMemcpyDeviceToHost));
     return 0;
 }
 

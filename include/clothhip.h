@@ -170,8 +170,9 @@ void *clothhip_stream(clothhip_handle *h);
  * handle's stream around the stepper kernel: milliseconds, or a negative value if none. */
 double clothhip_last_kernel_ms(clothhip_handle *h);
 
-/* Diagnostics of the last clothhip_run*: stats[E][4] = {strain sweeps run, of which dense, dependency levels
- * executed, levels in which a correction was applied}. Not part of the reference surface. */
+/* Diagnostics of the last clothhip_run*: stats[E][16]: [0..3] = {strain sweeps run, of which dense, dependency
+ * levels executed, levels in which a correction was applied}; [4..15] = shader cycles/64 per kernel phase when the
+ * CLOTHHIP_DEBUG_PHASES bit 32 is set. Not part of the reference surface. */
 int clothhip_debug_stats(clothhip_handle *h, int32_t *stats);
 
 /* Arithmetic self-test used by the parity tests: evaluates out[i] = op(a[i], b[i]) in double ON THE
