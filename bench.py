@@ -136,34 +136,25 @@ def main():
     else:
         acts_all = None
 
+    from gym_cloth_amd.dist import StepExchange
     if dist is not None:
         import torch
         dev = torch.device("cuda", local_rank)
-        act_buf = torch.empty((world * E, 4), dtype=torch.float64, device=dev)
-        res_loc = torch.empty((E, 4), dtype=torch.float64, device=dev)
-        res_all = torch.empty((world * E, 4), dtype=torch.float64, device=dev)
-        if args.gather_obs:
-            obs_loc = torch.empty((E, 3 * P), dtype=torch.float32, device=dev)
-            obs_all = torch.empty((world * E, 3 * P), dtype=torch.float32, device=dev)
+    else:
+        dev = None
+    xch = StepExchange(E, obs_dim=(3 * P if args.gather_obs else 0), device=dev) if dist is not None else None
 
     def one_step(t):
-        if dist is not None:
-            if rank == 0:
-                act_buf.copy_(torch.from_numpy(acts_all[t]))
-            dist.broadcast(act_buf, src=0)                   # RCCL broadcast of the action table
-            a = act_buf[g0:g0 + E].cpu().numpy()
-        else:
-            a = acts_all[t]
+        # RCCL broadcast of the action table (rank 0 -> all), each rank keeps its env block
+        a = xch.broadcast_actions(acts_all[t] if rank == 0 else None) if xch else acts_all[t]
         obs, rew, done, info = env.step(a)
         kms = env.batch.last_kernel_ms
-        if dist is not None:
-            res_loc.copy_(torch.from_numpy(np.stack([rew, done.astype(np.float64), info["actual_coverage"],
-                                                     env.last_executed.astype(np.float64)], axis=1)))
-            dist.all_gather_into_tensor(res_all, res_loc)    # RCCL gather of per-env results
+        if xch:
+            xch.gather_results(rew, done, info["actual_coverage"], env.last_executed)   # RCCL all-gather
             if args.gather_obs:
-                env.batch.write_obs_f32_device(obs_loc.data_ptr())
+                env.batch.write_obs_f32_device(xch.obs_loc.data_ptr())
                 env.batch.sync(False)
-                dist.all_gather_into_tensor(obs_all, obs_loc)
+                xch.gather_obs()
         return int(env.last_executed.sum()), kms
 
     def fence():
@@ -185,13 +176,9 @@ def main():
         k_sub += s
     fence()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        ns = torch.tensor([n_sub], dtype=torch.float64, device=dev)
-        dist.all_reduce(ns, op=dist.ReduceOp.SUM)
-        n_sub_all = float(ns.item())
+    if xch:
+        dt = xch.max_over_ranks(dt)
+        n_sub_all = xch.sum_over_ranks(n_sub)
     else:
         n_sub_all = float(n_sub)
 

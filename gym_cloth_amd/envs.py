@@ -55,6 +55,60 @@ def load_cfg(cfg):
         return yaml.safe_load(fh)
 
 
+def decode_actions(actions, low, high, clip_act_space, delta_actions, reduce_factor, iters_up, iters_up_rest,
+                   iters_pull_max, iters_grip_rest, iters_rest):
+    """The action -> schedule arithmetic of ClothEnv.step (cloth_env.py:396-475), vectorised over envs.
+
+    actions [E,4]; iters_up scalar or [E] (tier 3 draws a float per env, cloth_env.py:960).
+    Returns dict(x, y, x_dir_r, y_dir_r, iters_pull, bounds[E,5]); bounds are the integer ceilings of the
+    cumulative phase boundaries (`i < b` for integer i is `i < ceil(b)`), formed left to right as the reference
+    writes them (cloth_env.py:472-475).
+    """
+    a = np.asarray(actions, dtype=np.float64)
+    E = a.shape[0]
+    a = np.maximum(np.minimum(a, np.asarray(high)[None, :]), np.asarray(low)[None, :])    # :402-415
+    x_coord, y_coord, c2, c3 = a[:, 0], a[:, 1], a[:, 2], a[:, 3]
+    if clip_act_space:                                                                  # :417-426
+        x_coord = (x_coord / 2.0) + 0.5
+        y_coord = (y_coord / 2.0) + 0.5
+        if not delta_actions:
+            c2 = (c2 / 2.0) + 0.5
+            c3 = c3 * np.pi
+    if delta_actions:                                                                   # :448-453
+        total_length = np.sqrt((c2) ** 2 + (c3) ** 2)
+        x_dir = c2 / (total_length + _EPS)
+        y_dir = c3 / (total_length + _EPS)
+    else:
+        x_dir = np.cos(c3)
+        y_dir = np.sin(c3)
+    x_dir_r = x_dir * reduce_factor                                                     # :455-456
+    y_dir_r = y_dir * reduce_factor
+    if delta_actions:                                                                   # :460-468
+        step = np.sqrt((x_dir_r) ** 2 + (y_dir_r) ** 2)
+        cur = np.zeros(E)
+        ii = np.zeros(E, dtype=np.int64)
+        alive = np.ones(E, dtype=bool)
+        guard = 0
+        while alive.any():
+            cur = cur + step
+            alive &= ~(cur >= total_length)
+            ii[alive] += 1
+            guard += 1
+            if guard > 1000000:
+                raise FloatingPointError("iters_pull does not terminate (non-finite action?)")
+        iters_pull = ii
+    else:
+        iters_pull = (iters_pull_max * c2).astype(np.int64)                             # :470
+    iu = np.broadcast_to(np.asarray(iters_up, dtype=np.float64), (E,))
+    b1 = iu
+    b2 = iu + iters_up_rest
+    b3 = iu + iters_up_rest + iters_pull
+    b4 = iu + iters_up_rest + iters_pull + iters_grip_rest
+    b5 = iu + iters_up_rest + iters_pull + iters_grip_rest + iters_rest
+    bounds = np.ceil(np.stack([b1, b2, b3, b4, b5], axis=1)).astype(np.int64)
+    return dict(x=x_coord, y=y_coord, x_dir_r=x_dir_r, y_dir_r=y_dir_r, iters_pull=iters_pull, bounds=bounds)
+
+
 class ClothVecEnv(object):
     metadata = {'render.modes': ['human']}
 
@@ -149,50 +203,10 @@ class ClothVecEnv(object):
     # ---- action decoding (cloth_env.py:396-475) -------------------------------------------------------
     def decode_actions(self, actions, iters_up=None):
         """-> dict(x, y, x_dir_r, y_dir_r, iters_pull, bounds[E,5])."""
-        a = np.asarray(actions, dtype=np.float64).reshape(self.E, 4)
-        low, high = self.action_space.low, self.action_space.high
-        a = np.maximum(np.minimum(a, high[None, :]), low[None, :])                     # :402-415
-        x_coord, y_coord, c2, c3 = a[:, 0], a[:, 1], a[:, 2], a[:, 3]
-        if self._clip_act_space:                                                        # :417-426
-            x_coord = (x_coord / 2.0) + 0.5
-            y_coord = (y_coord / 2.0) + 0.5
-            if not self._delta_actions:
-                c2 = (c2 / 2.0) + 0.5
-                c3 = c3 * np.pi
-        if self._delta_actions:                                                         # :448-453
-            total_length = np.sqrt((c2) ** 2 + (c3) ** 2)
-            x_dir = c2 / (total_length + _EPS)
-            y_dir = c3 / (total_length + _EPS)
-        else:
-            x_dir = np.cos(c3)
-            y_dir = np.sin(c3)
-        x_dir_r = x_dir * self.reduce_factor                                            # :455-456
-        y_dir_r = y_dir * self.reduce_factor
-        if self._delta_actions:                                                         # :460-468
-            step = np.sqrt((x_dir_r) ** 2 + (y_dir_r) ** 2)
-            cur = np.zeros(self.E)
-            ii = np.zeros(self.E, dtype=np.int64)
-            alive = np.ones(self.E, dtype=bool)
-            guard = 0
-            while alive.any():
-                cur = cur + step
-                alive &= ~(cur >= total_length)
-                ii[alive] += 1
-                guard += 1
-                if guard > 1000000:
-                    raise FloatingPointError("iters_pull does not terminate (non-finite action?)")
-            iters_pull = ii
-        else:
-            iters_pull = (self.iters_pull_max * c2).astype(np.int64)                    # :470
-        iu = self._iters_up_env if iters_up is None else iters_up
-        b1 = iu
-        b2 = iu + self.iters_up_rest
-        b3 = iu + self.iters_up_rest + iters_pull
-        b4 = iu + self.iters_up_rest + iters_pull + self.iters_grip_rest
-        b5 = iu + self.iters_up_rest + iters_pull + self.iters_grip_rest + self.iters_rest
-        bounds = np.ceil(np.stack([b1, b2, b3, b4, b5], axis=1)).astype(np.int64)       # `i < b` == `i < ceil(b)`
-        return dict(x=x_coord, y=y_coord, x_dir_r=x_dir_r, y_dir_r=y_dir_r, iters_pull=iters_pull,
-                    bounds=bounds)
+        return decode_actions(actions, self.action_space.low, self.action_space.high, self._clip_act_space,
+                              self._delta_actions, self.reduce_factor,
+                              self._iters_up_env if iters_up is None else iters_up, self.iters_up_rest,
+                              self.iters_pull_max, self.iters_grip_rest, self.iters_rest)
 
     # ---- one action for every (active) env ----------------------------------------------------------------
     def step(self, actions, initialize=False, active=None):

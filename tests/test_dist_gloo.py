@@ -1,0 +1,83 @@
+"""world_size-2 test of the multi-GPU data path (gym_cloth_amd/dist.py) on CPU with the gloo backend:
+env blocks sharded over ranks, action table broadcast from rank 0, per-env results all-gathered.
+The physics stand-in on each rank is the CPU oracle (tests may use it); the sharded result must equal the
+single-process result env for env."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _step_block(actions, g):
+    """one short schedule per env on the oracle: returns (rew, done, coverage, executed) per env."""
+    from oracle import pyoracle
+    from gym_cloth_amd.envs import decode_actions
+    out = []
+    for a in actions:
+        c = pyoracle.OracleCloth(g["cfg"])
+        d = decode_actions(a[None], [-1.] * 4, [1.] * 4, True, True, 0.002, 5, 5, 400, 5, 10)
+        n = c.grab_top(float(d["x"][0]), float(d["y"][0]))
+        ex = c.run_schedule(d["bounds"][0] if n else np.zeros(5, int), 0.0025, float(d["x_dir_r"][0]),
+                            float(d["y_dir_r"][0]), True)
+        pos = c.get_state()[0]
+        out.append((float(pos[:, 2].max()), float(c.have_tear), float(pos[:, 0].mean()), float(ex)))
+    return np.array(out)
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from gym_cloth_amd.dist import StepExchange, shard_range
+    from oracle import pyoracle
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    E = 3
+    ex = StepExchange(E, obs_dim=6)
+    assert (ex.g0, ex.g1) == shard_range(rank, world, E) == (rank * E, rank * E + E)
+    g = pyoracle.load_golden("g_traj_lift_pull_25.npz")
+    acts_all = np.random.RandomState(5).uniform(-1, 1, size=(world * E, 4)) if rank == 0 else None
+    mine = ex.broadcast_actions(acts_all)
+    r = _step_block(mine, g)
+    res = ex.gather_results(r[:, 0], r[:, 1], r[:, 2], r[:, 3])
+    ex.obs_loc[:] = float(rank)
+    obs = ex.gather_obs().numpy().copy()
+    tmax = ex.max_over_ranks(1.0 + rank)
+    tsum = ex.sum_over_ranks(r[:, 3].sum())
+    ex.barrier()
+    q.put((rank, mine, res, obs, tmax, tsum))
+    dist.destroy_process_group()
+
+
+def test_sharded_step_equals_single_process():
+    import torch.multiprocessing as mp
+    from oracle import pyoracle
+    pyoracle.build()
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    acts_all = np.random.RandomState(5).uniform(-1, 1, size=(6, 4))
+    ref = _step_block(acts_all, pyoracle.load_golden("g_traj_lift_pull_25.npz"))
+    for rank, mine, res, obs, tmax, tsum in got:
+        assert np.array_equal(mine, acts_all[rank * 3:rank * 3 + 3])          # broadcast + slice
+        assert np.array_equal(res, ref)                                       # all-gather, env for env
+        assert np.array_equal(obs[:3], np.zeros((3, 6))) and np.array_equal(obs[3:], np.ones((3, 6)))
+        assert tmax == 2.0 and tsum == ref[:, 3].sum()
