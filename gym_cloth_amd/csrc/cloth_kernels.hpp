@@ -158,18 +158,14 @@ __device__ __forceinline__ int strain_spring(Pt<T> *cur, uint32_t en, T r, const
     if (!(len > t11)) return 0;                                                         // :275
     const T ux = dev_div<T>(dx, len), uy = dev_div<T>(dy, len), uz = dev_div<T>(dz, len);   // :276-278
     const T extra = len - t11;                                                          // :279
-    if (ca != 0) {
-        cur[b] = Pt<T>{B.x + ux * extra, B.y + uy * extra, B.z + uz * extra, B.w};
-        return 2;
-    } else if (cb != 0) {
-        cur[a] = Pt<T>{A.x - ux * extra, A.y - uy * extra, A.z - uz * extra, A.w};
-        return 1;
-    } else {
-        const T ed = extra * (T)0.5;
-        cur[a] = Pt<T>{A.x - ux * ed, A.y - uy * ed, A.z - uz * ed, A.w};
-        cur[b] = Pt<T>{B.x + ux * ed, B.y + uy * ed, B.z + uz * ed, B.w};
-        return 3;
-    }
+    // A pinned: B += dir*extra ; B pinned: A -= dir*extra ; else A -= dir*(extra*0.5), B += dir*(extra*0.5)
+    // (extra * 1.0 == extra exactly, so one weighted form covers the three reference branches, :281-296)
+    const T wa = ca != 0 ? (T)0 : (cb != 0 ? (T)1 : (T)0.5);
+    const T wb = cb != 0 ? (T)0 : (ca != 0 ? (T)1 : (T)0.5);
+    const T ea = extra * wa, eb = extra * wb;
+    if (ca == 0) cur[a] = Pt<T>{A.x - ux * ea, A.y - uy * ea, A.z - uz * ea, A.w};
+    if (cb == 0) cur[b] = Pt<T>{B.x + ux * eb, B.y + uy * eb, B.z + uz * eb, B.w};
+    return (ca == 0 ? 1 : 0) | (cb == 0 ? 2 : 0);
 }
 
 // Self-collision of ONE spatial cell (cloth.pyx:313-343) by a whole wave, exact Gauss-Seidel order:
@@ -468,9 +464,9 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 2 : NT / 256)) void k_run_schedule
             __syncthreads();
             TSTAMP(2)
             // exclusive prefix sum of the slot counts -> fill cursors (each thread owns HT/NT consecutive slots)
-            const int per = HT / NT;
+            const int per = (HT + NT - 1) / NT;
             uint32_t loc = 0;
-            for (int q = 0; q < per; q++) loc += hco[tid * per + q];
+            for (int q = 0; q < per; q++) { const int h = tid * per + q; loc += h < HT ? hco[h] : 0u; }
             uint32_t inc = loc;
             for (int o = 1; o < 64; o <<= 1) { uint32_t v = __shfl_up(inc, o); if (lane >= o) inc += v; }
             if (lane == 63) misc[8 + (tid >> 6)] = (int)inc;
@@ -478,9 +474,12 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 2 : NT / 256)) void k_run_schedule
             uint32_t base = inc - loc;
             for (int w = 0; w < (tid >> 6); w++) base += (uint32_t)misc[8 + w];
             for (int q = 0; q < per; q++) {
-                const uint32_t c = hco[tid * per + q];
-                hco[tid * per + q] = (base << 16) | c;
-                base += c;
+                const int h = tid * per + q;
+                if (h < HT) {
+                    const uint32_t c = hco[h];
+                    hco[h] = (base << 16) | c;
+                    base += c;
+                }
             }
             __syncthreads();
             TSTAMP(3)
@@ -604,22 +603,33 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 2 : NT / 256)) void k_run_schedule
             {
                 unsigned long long *abits = reinterpret_cast<unsigned long long *>(smem + lay.abits);
                 int nact = 0;
-                for (int p0 = 0; p0 < A.Spad; p0 += NT) {
-                    const int p = p0 + tid;
-                    bool act = false;
-                    if (p < A.S) {
-                        const uint32_t en = ent[p];
-                        const T r = rest[p];
-                        const Pt<T> a = cur[en & 0xFFFFu], b = cur[en >> 16];
+                constexpr int U = 4;                         // springs per thread per trip: their LDS reads overlap
+                for (int p0 = 0; p0 < A.Spad; p0 += U * NT) {
+                    uint32_t en[U]; T r[U];
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const int p = p0 + u * NT + tid;
+                        const int pc = p < A.S ? p : 0;     // clamped: always a valid read, masked below
+                        en[u] = ent[pc]; r[u] = rest[pc];
+                    }
+                    bool act[U];
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const Pt<T> a = cur[en[u] & 0xFFFFu], b = cur[en[u] >> 16];
                         const T dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
                         const T len2 = dx * dx + dy * dy + dz * dz;
-                        const T t11 = r * k.c11, tt = r * k.tear_thresh;
+                        const T t11 = r[u] * k.c11, tt = r[u] * k.tear_thresh;
                         const T tmin = t11 < tt ? t11 : tt;
-                        act = !(w_cnt(a.w) != 0 && w_cnt(b.w) != 0) && (len2 > tmin * tmin * ((T)1 - filt_slack<T>()));
+                        act[u] = (p0 + u * NT + tid < A.S) && !(w_cnt(a.w) != 0 && w_cnt(b.w) != 0) &&
+                                 (len2 > tmin * tmin * ((T)1 - filt_slack<T>()));
                     }
-                    const unsigned long long bal = __ballot(act);
-                    if (lane == 0 && p < A.Spad) abits[p >> 6] = bal;
-                    nact += __popcll(bal);
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const int p = p0 + u * NT + tid;
+                        const unsigned long long bal = __ballot(act[u]);
+                        if (lane == 0 && p < A.Spad) abits[p >> 6] = bal;
+                        nact += __popcll(bal);
+                    }
                 }
                 if (nact && lane == 0) atomicAdd(&misc[1], nact);
             }
@@ -646,47 +656,47 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 2 : NT / 256)) void k_run_schedule
                         if (lvflag[Lm]) { want = true; lvflag[Lm] = 0; }        // pending mark from an earlier correction
                     }
                     unsigned long long need = __ballot(want);
-                    int pf_j = -1;
-                    uint32_t pf_en = 0u; T pf_r = (T)0;
+                    int pj = -1;                                 // level whose springs are already fetched into (pen, pr)
+                    uint32_t pen = 0u; T pr = (T)0;
                     while (need) {
                         const int j = __ffsll((long long)need) - 1;
                         need &= need - 1ull;
                         const int o0 = __builtin_amdgcn_readlane(myoff, j), o1 = __builtin_amdgcn_readlane(myoff1, j);
                         const int idx = o0 + lane;
                         const bool on = idx < o1;
-                        uint32_t en = pf_en; T r = pf_r;
-                        if (j != pf_j && on) { en = ent[idx]; r = rest[idx]; }
-                        // speculative fetch of the next level's springs (hit whenever levels run back to back)
-                        pf_j = j + 1;
-                        if (pf_j < 64) {
-                            const int idn = o1 + lane;          // level j+1 starts where level j ends
-                            const int o2 = __builtin_amdgcn_readlane(myoff1, pf_j);
-                            if (idn < o2) { pf_en = ent[idn]; pf_r = rest[idn]; }
-                        }
+                        uint32_t en = pen; T r = pr;
+                        if (j != pj && on) { en = ent[idx]; r = rest[idx]; }
+                        if (need) {                              // fetch the NEXT level that has to run
+                            pj = __ffsll((long long)need) - 1;
+                            const int q0 = __builtin_amdgcn_readlane(myoff, pj) + lane;
+                            if (q0 < __builtin_amdgcn_readlane(myoff1, pj)) { pen = ent[q0]; pr = rest[q0]; }
+                        } else pj = -1;
                         int moved = 0;
                         if (on) moved = strain_spring<T>(cur, en, r, k, tear);
-                        st_levels++; st_trig += __any(moved) ? 1 : 0;
-                        if (!dense && __any(moved)) {
-                            if (moved) {
-                                const int Lcur = L0 + j;
-                                const int pa_ = (int)(en & 0xFFFFu), pb_ = (int)(en >> 16);
-                                int lv[2 * HK_SLOTS];
-#pragma unroll
-                                for (int sl = 0; sl < HK_SLOTS; sl++) {         // 24 independent LDS reads, one round trip
-                                    lv[2 * sl] = (int)plev[sl * Ppad + pa_];
-                                    lv[2 * sl + 1] = (int)plev[sl * Ppad + pb_];
-                                }
-#pragma unroll
-                                for (int sl = 0; sl < HK_SLOTS; sl++) {
-                                    if ((moved & 1) && lv[2 * sl] != 0xFFFF && lv[2 * sl] > Lcur) lvflag[lv[2 * sl]] = 1;
-                                    if ((moved & 2) && lv[2 * sl + 1] != 0xFFFF && lv[2 * sl + 1] > Lcur) lvflag[lv[2 * sl + 1]] = 1;
-                                }
+                        st_levels++;
+                        unsigned long long mm = __ballot(moved != 0);
+                        st_trig += mm ? 1 : 0;
+                        if (!dense && mm) {
+                            // exact pending marks, lane-cooperative: for each spring that moved a particle, lanes 0..11
+                            // look at ptA's incident springs and lanes 12..23 at ptB's, one table entry per lane, and
+                            // flag those that sit in a later level
+                            const int Lcur = L0 + j;
+                            while (mm) {
+                                const int t = __ffsll((long long)mm) - 1;
+                                mm &= mm - 1ull;
+                                const uint32_t e2 = (uint32_t)__builtin_amdgcn_readlane((int)en, t);
+                                const int mv = __builtin_amdgcn_readlane(moved, t);
+                                const bool isb = lane >= HK_SLOTS;
+                                const int pt = isb ? (int)(e2 >> 16) : (int)(e2 & 0xFFFFu);
+                                const bool use = lane < 2 * HK_SLOTS && ((mv >> (isb ? 1 : 0)) & 1);
+                                const int lv = use ? (int)plev[(lane - (isb ? HK_SLOTS : 0)) * Ppad + pt] : 0xFFFF;
+                                if (lv != 0xFFFF && lv > Lcur) lvflag[lv] = 1;
                             }
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                             __builtin_amdgcn_wave_barrier();
                             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                            // refresh the rest of this chunk from the marks (later chunks consume theirs when they start)
-                            const bool upd = valid && Lm > L0 + j && lvflag[Lm] != 0;
+                            // pull the marks that fall into the rest of this chunk (later chunks consume theirs on entry)
+                            const bool upd = valid && Lm > Lcur && lvflag[Lm] != 0;
                             if (upd) lvflag[Lm] = 0;
                             need |= __ballot(upd);
                         }

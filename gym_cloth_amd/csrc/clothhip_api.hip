@@ -52,7 +52,7 @@ struct clothhip_handle {
     ClothSchedule *d_sched = nullptr, *h_sched = nullptr;   // h_sched: pinned staging
     uint32_t *d_gather = nullptr, *d_lv_ent = nullptr;
     uint16_t *d_lv_off = nullptr, *d_pt_lev = nullptr;
-    int dense_thresh = 48;
+    int dense_thresh = 1 << 30;   // exact pending-level tracking is cheaper than running every level at every trigger density measured
     int HT = 0, ht_bits = 0, lvw_shift = 4, lds_bytes = 0, phase_mask = 15, nt = 256, ppt = 3;
     int tab = 0;            // static tables resident in LDS: 0 none, 1 springs/rest/offsets, 2 + per-point levels
     bool rest_reg = false;
@@ -184,7 +184,7 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
     h->S = h->topo.S; h->Spad = (h->S + 63) / 64 * 64;
     // threads per cloth x particles per thread (compile-time variants of the stepper)
     if (h->P <= 768) { h->nt = 256; h->ppt = 3; } else if (h->P <= 3072) { h->nt = 1024; h->ppt = 3; } else { h->nt = 1024; h->ppt = 4; }
-    h->HT = h->nt; h->ht_bits = 0;
+    h->HT = 64; h->ht_bits = 0;
     while (h->HT <= h->P + h->P / 2) h->HT <<= 1;
     while ((1 << h->ht_bits) < h->HT) h->ht_bits++;
     h->lvw_shift = h->lv.max_width <= 16 ? 4 : (h->lv.max_width <= 32 ? 5 : 6);
