@@ -52,6 +52,10 @@ template <typename T> struct StepArgs {
     const uint32_t *lv_ent;  // [Spad]  ptA | ptB<<16, level order
     const uint16_t *lv_off;  // [n_levels+1]
     const uint16_t *pt_lev;  // [HK_SLOTS][Ppad] dependency level of the k-th incident spring of a point (0xFFFF none)
+    const uint32_t *lv_pad;  // [n_levels + 8][LVW] fixed-width level table for the dense sweep: ent, empty slots = 0 (ptA == ptB)
+    const T *rest_pad;       // [E or 1][(n_levels + 8) * LVW] rest lengths in the same padded order
+    int32_t rest_pad_stride; // 0: shared
+    int32_t lvw;             // padded level width (16 or 32)
     int32_t n_levels;
     int32_t N, P, Ppad, S, Spad;
     int32_t HT, ht_bits;     // spatial hash table slots (power of two > P)
@@ -85,6 +89,14 @@ template <> __device__ __forceinline__ float dev_floor<float>(float x) { return 
 __device__ __forceinline__ float bcast(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 __device__ __forceinline__ double bcast(double v, int l) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+// inclusive OR-scan inside each row of 16 lanes (DPP row_shr 1,2,4,8); lane 16r+15 ends up with row r's OR
+__device__ __forceinline__ uint32_t row_or_scan(uint32_t v) {
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+    return v;
 }
 // relative slack of the conservative "could this comparison against a sqrt be true" pre-filters
 template <typename T> __device__ __forceinline__ T filt_slack();
@@ -143,9 +155,20 @@ struct LdsLayout {
 // One spring of the strain limiter, exactly as cloth.pyx:265-296 evaluates it. Returns which endpoints were
 // moved (bit0: ptA, bit1: ptB; 0 = no correction). `tear` is OR-ed.
 template <typename T>
+__device__ __forceinline__ int strain_apply(Pt<T> *cur, uint32_t en, const Pt<T> &A, const Pt<T> &B, T r,
+                                            const DevConsts<T> &k, int &tear);
+
+template <typename T>
 __device__ __forceinline__ int strain_spring(Pt<T> *cur, uint32_t en, T r, const DevConsts<T> &k, int &tear) {
+    const Pt<T> A = cur[en & 0xFFFFu], B = cur[en >> 16];   // two 16-byte LDS reads (positions + pin state)
+    return strain_apply<T>(cur, en, A, B, r, k, tear);
+}
+
+// The spring update given its two particle records (already loaded).
+template <typename T>
+__device__ __forceinline__ int strain_apply(Pt<T> *cur, uint32_t en, const Pt<T> &A, const Pt<T> &B, T r,
+                                            const DevConsts<T> &k, int &tear) {
     const int a = (int)(en & 0xFFFFu), b = (int)(en >> 16);
-    const Pt<T> A = cur[a], B = cur[b];                     // two 16-byte LDS reads (positions + pin state)
     const uint32_t ca = w_cnt(A.w), cb = w_cnt(B.w);
     const T dx = A.x - B.x, dy = A.y - B.y, dz = A.z - B.z;
     const T len2 = dx * dx + dy * dy + dz * dz;
@@ -640,12 +663,58 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 2 : NT / 256)) void k_run_schedule
                 // dense: so many levels are flagged that tracking costs more than it saves -> run every level.
                 // sparse: a correction marks exactly the later levels that hold a spring of a moved particle.
                 const bool dense = (pm & PH_NOSKIP) || misc[1] > A.dense_thresh;
+                // marking roles: lanes 0..23 serve the first corrected spring of a pass, 24..47 the second
+                const bool mk_on = lane < 4 * HK_SLOTS;
+                const bool mk_grp = lane >= 2 * HK_SLOTS;
+                const int mk_s = lane - (mk_grp ? 2 * HK_SLOTS : 0);
+                const bool mk_isb = mk_s >= HK_SLOTS;
+                const int mk_k = mk_on ? mk_s - (mk_isb ? HK_SLOTS : 0) : 0;
                 st_sweeps++; st_dense += dense ? 1 : 0;
+                if (dense) {
+                    // Dense sweep: so many springs are over-stretched that (almost) every level has to run; walk all
+                    // levels with the leanest possible body: fixed-width level table streamed from L2 two levels
+                    // ahead, LVW active lanes, no skipping / marking bookkeeping. Empty slots hold ptA == ptB == 0,
+                    // which can never stretch (len2 == 0).
+                    const int lvw = A.lvw;
+                    if (lane < lvw) {
+                        const uint32_t *tp = A.lv_pad + lane;
+                        const T *rp = A.rest_pad + (size_t)e * A.rest_pad_stride + lane;
+                        // constants of the spring test pinned in VGPRs (the scalar file is oversubscribed here)
+                        DevConsts<T> kl = k;
+                        asm volatile("" : "+v"(kl.c11), "+v"(kl.tear_thresh));
+                        // ring of 4 levels: level L+u lives in slot u; the table entry of level L+u+3 is requested
+                        // three levels ahead (L2 latency hidden), the table is padded with 8 empty levels
+                        uint32_t ee[4]; T rq[4];
+#pragma unroll
+                        for (int u = 0; u < 3; u++) { ee[u] = tp[u * lvw]; rq[u] = rp[u * lvw]; }
+                        Pt<T> A0 = cur[ee[0] & 0xFFFFu], B0 = cur[ee[0] >> 16];
+                        for (int L = 0; L < nL; L += 4) {
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                ee[(u + 3) & 3] = tp[(L + u + 3) * lvw];
+                                rq[(u + 3) & 3] = rp[(L + u + 3) * lvw];
+                                // software pipeline: the NEXT level's particle records are requested before this
+                                // level decides whether it corrects anything; re-read only if it did write
+                                const uint32_t en1 = ee[(u + 1) & 3];
+                                Pt<T> A1 = cur[en1 & 0xFFFFu], B1 = cur[en1 >> 16];
+                                const int mv = strain_apply<T>(cur, ee[u], A0, B0, rq[u], kl, tear);
+                                if (__any(mv)) {
+                                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                                    __builtin_amdgcn_wave_barrier();
+                                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                                    A1 = cur[en1 & 0xFFFFu]; B1 = cur[en1 >> 16];
+                                }
+                                A0 = A1; B0 = B1;
+                            }
+                        }
+                    }
+                    st_levels += nL;
+                } else
                 for (int L0 = 0; L0 < nL; L0 += 64) {
                     const int Lm = L0 + lane;
                     const bool valid = Lm < nL;
                     const int myoff = valid ? (int)loff[Lm] : 0, myoff1 = valid ? (int)loff[Lm + 1] : 0;
-                    bool want = dense && valid;
+                    bool want = false;
                     if (valid) {
                         // any pre-pass bit in this level's spring range [myoff, myoff1)?  (width <= 64)
                         const unsigned long long *abits = reinterpret_cast<const unsigned long long *>(smem + lay.abits);
@@ -659,6 +728,10 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 2 : NT / 256)) void k_run_schedule
                     int pj = -1;                                 // level whose springs are already fetched into (pen, pr)
                     uint32_t pen = 0u; T pr = (T)0;
                     while (need) {
+#ifdef CLOTHHIP_SWEEP_STAMPS
+                        unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+                        if (timing) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts0)::"memory"); }
+#endif
                         const int j = __ffsll((long long)need) - 1;
                         need &= need - 1ull;
                         const int o0 = __builtin_amdgcn_readlane(myoff, j), o1 = __builtin_amdgcn_readlane(myoff1, j);
@@ -676,30 +749,46 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 2 : NT / 256)) void k_run_schedule
                         st_levels++;
                         unsigned long long mm = __ballot(moved != 0);
                         st_trig += mm ? 1 : 0;
-                        if (!dense && mm) {
-                            // exact pending marks, lane-cooperative: for each spring that moved a particle, lanes 0..11
-                            // look at ptA's incident springs and lanes 12..23 at ptB's, one table entry per lane, and
-                            // flag those that sit in a later level
+#ifdef CLOTHHIP_SWEEP_STAMPS
+                        if (timing) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts1)::"memory"); tph[mm ? 11 : 10] += ts1 - ts0; }
+                        const bool did_mark = mm != 0ull;
+#endif
+                        if (mm) {
+                            // exact pending marks, lane-cooperative: two corrected springs per pass; for each, 24 lanes
+                            // read ONE entry of the incident-level table of ptA (12) / ptB (12). Marks inside the
+                            // current 64-level chunk are OR-reduced with DPP straight into `need`; marks beyond it
+                            // go to LDS flags that the later chunk consumes on entry.
                             const int Lcur = L0 + j;
                             while (mm) {
-                                const int t = __ffsll((long long)mm) - 1;
+                                const int t1 = __ffsll((long long)mm) - 1;
                                 mm &= mm - 1ull;
-                                const uint32_t e2 = (uint32_t)__builtin_amdgcn_readlane((int)en, t);
-                                const int mv = __builtin_amdgcn_readlane(moved, t);
-                                const bool isb = lane >= HK_SLOTS;
-                                const int pt = isb ? (int)(e2 >> 16) : (int)(e2 & 0xFFFFu);
-                                const bool use = lane < 2 * HK_SLOTS && ((mv >> (isb ? 1 : 0)) & 1);
-                                const int lv = use ? (int)plev[(lane - (isb ? HK_SLOTS : 0)) * Ppad + pt] : 0xFFFF;
-                                if (lv != 0xFFFF && lv > Lcur) lvflag[lv] = 1;
+                                const int t2 = mm ? __ffsll((long long)mm) - 1 : t1;
+                                mm &= mm - 1ull;                 // (no-op when mm was already 0)
+                                const uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)en, t1);
+                                const uint32_t e2 = (uint32_t)__builtin_amdgcn_readlane((int)en, t2);
+                                const int m1 = __builtin_amdgcn_readlane(moved, t1), m2 = __builtin_amdgcn_readlane(moved, t2);
+                                const uint32_t es = mk_grp ? e2 : e1;
+                                const int ms = mk_grp ? m2 : m1;
+                                const int pt = mk_isb ? (int)(es >> 16) : (int)(es & 0xFFFFu);
+                                const bool use = mk_on && (t2 != t1 || !mk_grp) && ((ms >> (mk_isb ? 1 : 0)) & 1);
+                                const int lv = use ? (int)plev[mk_k * Ppad + pt] : 0xFFFF;
+                                const bool cond = lv != 0xFFFF && lv > Lcur;
+                                const int rel = lv - L0;
+                                if (cond && rel >= 64) lvflag[lv] = 1;
+                                const bool inch = cond && rel < 64;
+                                const uint32_t blo = (inch && rel < 32) ? (1u << rel) : 0u;
+                                const uint32_t bhi = (inch && rel >= 32) ? (1u << (rel - 32)) : 0u;
+                                const uint32_t slo = row_or_scan(blo), shi = row_or_scan(bhi);
+                                const uint32_t rlo = (uint32_t)(__builtin_amdgcn_readlane((int)slo, 15) | __builtin_amdgcn_readlane((int)slo, 31) |
+                                                                __builtin_amdgcn_readlane((int)slo, 47));
+                                const uint32_t rhi = (uint32_t)(__builtin_amdgcn_readlane((int)shi, 15) | __builtin_amdgcn_readlane((int)shi, 31) |
+                                                                __builtin_amdgcn_readlane((int)shi, 47));
+                                need |= ((unsigned long long)rhi << 32) | rlo;
                             }
-                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                            __builtin_amdgcn_wave_barrier();
-                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                            // pull the marks that fall into the rest of this chunk (later chunks consume theirs on entry)
-                            const bool upd = valid && Lm > Lcur && lvflag[Lm] != 0;
-                            if (upd) lvflag[Lm] = 0;
-                            need |= __ballot(upd);
                         }
+#ifdef CLOTHHIP_SWEEP_STAMPS
+                        if (timing && did_mark) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts2)::"memory"); tph[9] += ts2 - ts1; }
+#endif
                         // the next level's lanes read what this level's lanes wrote: same wave, LDS is in order;
                         // the fences only stop the compiler from moving LDS accesses across the level boundary.
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -712,7 +801,7 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 2 : NT / 256)) void k_run_schedule
             }
             __syncthreads();
         }
-        TSTAMP(9)
+        if (timing) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory"); }
         done++;
         if (sc.break_on_tear && misc[0]) break;                                            // cloth_env.py:511-514
     }
