@@ -113,7 +113,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:     # launched by torch.distributed.run: one rank per GPU
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)

@@ -52,8 +52,8 @@ template <typename T> struct StepArgs {
     const uint32_t *lv_ent;  // [Spad]  ptA | ptB<<16, level order
     const uint16_t *lv_off;  // [n_levels+1]
     const uint16_t *pt_lev;  // [HK_SLOTS][Ppad] dependency level of the k-th incident spring of a point (0xFFFF none)
-    const uint32_t *lv_pad;  // [n_levels + 8][LVW] fixed-width level table for the dense sweep: ent, empty slots = 0 (ptA == ptB)
-    const T *rest_pad;       // [E or 1][(n_levels + 8) * LVW] rest lengths in the same padded order
+    const uint32_t *lv_pad;  // [n_levels + 16][LVW] fixed-width level table for the dense sweep: ent, empty slots = 0 (ptA == ptB)
+    const T *rest_pad;       // [E or 1][(n_levels + 16) * LVW] rest lengths in the same padded order
     int32_t rest_pad_stride; // 0: shared
     int32_t lvw;             // padded level width (16 or 32)
     int32_t n_levels;
@@ -671,44 +671,67 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 2 : NT / 256)) void k_run_schedule
                 const int mk_k = mk_on ? mk_s - (mk_isb ? HK_SLOTS : 0) : 0;
                 st_sweeps++; st_dense += dense ? 1 : 0;
                 if (dense) {
-                    // Dense sweep: so many springs are over-stretched that (almost) every level has to run; walk all
-                    // levels with the leanest possible body: fixed-width level table streamed from L2 two levels
-                    // ahead, LVW active lanes, no skipping / marking bookkeeping. Empty slots hold ptA == ptB == 0,
-                    // which can never stretch (len2 == 0).
-                    const int lvw = A.lvw;
-                    if (lane < lvw) {
-                        const uint32_t *tp = A.lv_pad + lane;
-                        const T *rp = A.rest_pad + (size_t)e * A.rest_pad_stride + lane;
-                        // constants of the spring test pinned in VGPRs (the scalar file is oversubscribed here)
-                        DevConsts<T> kl = k;
-                        asm volatile("" : "+v"(kl.c11), "+v"(kl.tear_thresh));
-                        // ring of 4 levels: level L+u lives in slot u; the table entry of level L+u+3 is requested
-                        // three levels ahead (L2 latency hidden), the table is padded with 8 empty levels
-                        uint32_t ee[4]; T rq[4];
-#pragma unroll
-                        for (int u = 0; u < 3; u++) { ee[u] = tp[u * lvw]; rq[u] = rp[u * lvw]; }
-                        Pt<T> A0 = cur[ee[0] & 0xFFFFu], B0 = cur[ee[0] >> 16];
-                        for (int L = 0; L < nL; L += 4) {
-#pragma unroll
-                            for (int u = 0; u < 4; u++) {
-                                ee[(u + 3) & 3] = tp[(L + u + 3) * lvw];
-                                rq[(u + 3) & 3] = rp[(L + u + 3) * lvw];
-                                // software pipeline: the NEXT level's particle records are requested before this
-                                // level decides whether it corrects anything; re-read only if it did write
-                                const uint32_t en1 = ee[(u + 1) & 3];
-                                Pt<T> A1 = cur[en1 & 0xFFFFu], B1 = cur[en1 >> 16];
-                                const int mv = strain_apply<T>(cur, ee[u], A0, B0, rq[u], kl, tear);
-                                if (__any(mv)) {
-                                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                                    __builtin_amdgcn_wave_barrier();
-                                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                                    A1 = cur[en1 & 0xFFFFu]; B1 = cur[en1 >> 16];
-                                }
-                                A0 = A1; B0 = B1;
-                            }
+                    // Dense sweep: so many springs are over-stretched that (almost) every level has to run. The wave is
+                    // split into GR = 64/lvw lane groups and each pass evaluates GR CONSECUTIVE levels at once, one per
+                    // group, against the same particle state. The first group (in level order) that applies a
+                    // correction commits it; later groups may have read stale particles, so they are discarded and
+                    // re-evaluated by the next pass; groups before it provably changed nothing. This is exactly the
+                    // sequential sweep, ~3 levels per pass instead of 1.
+                    // A lane streams its own sub-sequence of the fixed-width level table (levels = res mod GR) from L2,
+                    // two entries ahead. Empty slots hold ptA == ptB == 0, which can never stretch (len2 == 0).
+                    const int lsh = A.lvw_shift, lvw = 1 << lsh, GR = 64 >> lsh;   // lvw is a power of two
+                    const int res = lane >> lsh;
+                    DevConsts<T> kl = k;                         // spring-test constants pinned in VGPRs
+                    asm volatile("" : "+v"(kl.c11), "+v"(kl.tear_thresh));
+                    const uint32_t *tp = A.lv_pad + (lane & (lvw - 1));
+                    const T *rp = A.rest_pad + (size_t)e * A.rest_pad_stride + (lane & (lvw - 1));
+                    int myL = res;                               // the level this lane currently holds
+                    uint32_t ec = tp[myL << lsh], e1 = tp[(myL + GR) << lsh], e2 = tp[(myL + 2 * GR) << lsh];
+                    T rc = rp[myL << lsh], r1 = rp[(myL + GR) << lsh], r2 = rp[(myL + 2 * GR) << lsh];
+                    int L = 0;
+                    while (L < nL) {
+                        const int grp = myL - L;                 // 0..GR-1: position of my level inside this pass
+                        const int a = (int)(ec & 0xFFFFu), b = (int)(ec >> 16);
+                        const Pt<T> PA = cur[a], PB = cur[b];
+                        const uint32_t ca = w_cnt(PA.w), cb = w_cnt(PB.w);
+                        const T dx = PA.x - PB.x, dy = PA.y - PB.y, dz = PA.z - PB.z;
+                        const T len2 = dx * dx + dy * dy + dz * dz;
+                        const T t11 = rc * kl.c11, tt = rc * kl.tear_thresh;
+                        const T tmin = t11 < tt ? t11 : tt;
+                        bool trig = false, tearl = false;
+                        T len = (T)0;
+                        if (!(ca != 0 && cb != 0) && (len2 > tmin * tmin * ((T)1 - filt_slack<T>()))) {
+                            len = dev_sqrt<T>(len2);                                            // :270
+                            tearl = len > tt;                                                   // :272
+                            trig = len > t11;                                                   // :275
                         }
+                        const unsigned long long tb = __ballot(trig);
+                        // groups sit in lane ranges by residue class; rotate so that bit order == level order
+                        const int rot = (L & (GR - 1)) << lsh;
+                        const unsigned long long tr = rot ? ((tb >> rot) | (tb << (64 - rot))) : tb;
+                        const int g = tr ? (__ffsll((long long)tr) - 1) >> lsh : GR;            // first correcting level of the pass
+                        if (trig && grp == g) {
+                            const T ux = dev_div<T>(dx, len), uy = dev_div<T>(dy, len), uz = dev_div<T>(dz, len);   // :276-278
+                            const T extra = len - t11;                                          // :279
+                            const T wa = ca != 0 ? (T)0 : (cb != 0 ? (T)1 : (T)0.5);
+                            const T wb = cb != 0 ? (T)0 : (ca != 0 ? (T)1 : (T)0.5);
+                            const T ea = extra * wa, eb = extra * wb;
+                            if (ca == 0) cur[a] = Pt<T>{PA.x - ux * ea, PA.y - uy * ea, PA.z - uz * ea, PA.w};
+                            if (cb == 0) cur[b] = Pt<T>{PB.x + ux * eb, PB.y + uy * eb, PB.z + uz * eb, PB.w};
+                        }
+                        if (tearl && grp <= g) tear = 1;
+                        const int adv = g < GR ? g + 1 : GR;
+                        st_levels += adv; st_trig += g < GR ? 1 : 0;
+                        L += adv;
+                        if (myL < L) {                           // my level is done: take the next one of my residue class
+                            myL += GR;
+                            ec = e1; rc = r1; e1 = e2; r1 = r2;
+                            e2 = tp[(myL + 2 * GR) << lsh]; r2 = rp[(myL + 2 * GR) << lsh];
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     }
-                    st_levels += nL;
                 } else
                 for (int L0 = 0; L0 < nL; L0 += 64) {
                     const int Lm = L0 + lane;

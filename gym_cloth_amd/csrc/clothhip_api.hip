@@ -251,7 +251,7 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
     }
     {   // fixed-width (padded) level table for the dense sweep
         h->lvw = 1 << h->lvw_shift;
-        h->npad = (h->lv.n_levels + 8) * h->lvw;
+        h->npad = (h->lv.n_levels + 16) * h->lvw;
         std::vector<uint32_t> pad((size_t)h->npad, 0u);
         for (int L = 0; L < h->lv.n_levels; L++)
             for (int p = h->lv.off[L]; p < h->lv.off[L + 1]; p++) pad[(size_t)L * h->lvw + (p - h->lv.off[L])] = h->lv.ent[p];
