@@ -924,6 +924,102 @@ template <typename T> __global__ void k_write_obs(const T *pos, float *out, int 
     }
 }
 
+// ---- per-env metrics on the device (cloth_env.py:1020-1098): coverage = area of the convex hull of the clipped
+// (x,y) (same monotone-chain + shoelace arithmetic, in double, as clothhip_hull_area on the host), variance_inv of z,
+// out-of-bounds. One 256-thread workgroup per env. LDS: sx/sy[NS] sort buffers + hx/hy[2*NS] hull stack.
+template <typename T>
+__global__ __launch_bounds__(256) void k_metrics(const T *pos, int P, int Ppad, int NS, double *cov, double *vinv, uint8_t *oob) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *sx = reinterpret_cast<double *>(smem), *sy = sx + NS, *hx = sy + NS, *hy = hx + 2 * NS;
+    double *red = hy + 2 * NS;                                    // [64] reduction scratch
+    const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const T *px = pos + (size_t)e * 3 * Ppad, *py = px + Ppad, *pz = py + Ppad;
+    const double INF = __longlong_as_double(0x7ff0000000000000LL);
+    double mnx = INF, mxx = -INF, mny = INF, mxy = -INF, mnz = INF, mxz = -INF, sum = 0.0;
+    for (int i = tid; i < NS; i += 256) {
+        double x = INF, y = INF;
+        if (i < P) {
+            x = (double)px[i]; y = (double)py[i];
+            const double z = (double)pz[i];
+            mnx = fmin(mnx, x); mxx = fmax(mxx, x); mny = fmin(mny, y); mxy = fmax(mxy, y);
+            mnz = fmin(mnz, z); mxz = fmax(mxz, z); sum += z;
+            x = fmin(fmax(x, 0.0), 1.0); y = fmin(fmax(y, 0.0), 1.0);                         // cloth_env.py:629
+        }
+        sx[i] = x; sy[i] = y;
+    }
+    // block reductions (min/max exact; the z-sum order differs from numpy's pairwise sum only in the last bits)
+    auto wred = [&](double v, int op) {
+        for (int o = 32; o > 0; o >>= 1) {
+            const double w = __shfl_xor(v, o);
+            v = op == 0 ? fmin(v, w) : (op == 1 ? fmax(v, w) : v + w);
+        }
+        return v;
+    };
+    double vals[7] = {mnx, mxx, mny, mxy, mnz, mxz, sum};
+    const int ops[7] = {0, 1, 0, 1, 0, 1, 2};
+    for (int q = 0; q < 7; q++) { const double r = wred(vals[q], ops[q]); if (lane == 0) red[q * 4 + wave] = r; }
+    __syncthreads();
+    for (int q = 0; q < 7; q++) {
+        double r = red[q * 4];
+        for (int w = 1; w < 4; w++) r = ops[q] == 0 ? fmin(r, red[q * 4 + w]) : (ops[q] == 1 ? fmax(r, red[q * 4 + w]) : r + red[q * 4 + w]);
+        vals[q] = r;
+    }
+    __syncthreads();
+    const double mean = vals[6] / P;
+    double acc = 0.0;
+    for (int i = tid; i < P; i += 256) { const double d = (double)pz[i] - mean; acc += d * d; }
+    acc = wred(acc, 2);
+    if (lane == 0) red[wave] = acc;
+    // bitonic sort of the clipped points, lexicographic (x, y); padding (+inf,+inf) sinks to the end
+    for (int kk = 2; kk <= NS; kk <<= 1)
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            __syncthreads();
+            for (int t = tid; t < (NS >> 1); t += 256) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+                const double ax = sx[i], ay = sy[i], bx = sx[l], by = sy[l];
+                const bool gt = ax > bx || (ax == bx && ay > by);
+                if (gt == ((i & kk) == 0)) { sx[i] = bx; sy[i] = by; sx[l] = ax; sy[l] = ay; }
+            }
+        }
+    __syncthreads();
+    if (tid == 0) {
+        const double var = (red[0] + red[1] + red[2] + red[3]) / P;                            // np.var
+        vinv[e] = var < 0.000001 ? 1000.0 : 0.001 / var;                                       // cloth_env.py:1081-1084
+        const double slack = 0.25;                                                             // cloth_env.py:1031-1036
+        oob[e] = (vals[1] >= 1.0 + slack || vals[0] < -slack || vals[3] >= 1.0 + slack || vals[2] < -slack ||
+                  vals[5] >= 1.0 || vals[4] < 0) ? 1 : 0;
+        // dedupe (in place), then Andrew's monotone chain exactly as clothhip_hull_area
+        int m = 0;
+        for (int i = 0; i < P; i++)
+            if (m == 0 || sx[i] != sx[m - 1] || sy[i] != sy[m - 1]) { sx[m] = sx[i]; sy[m] = sy[i]; m++; }
+        double area = 0.0;
+        if (m >= 3) {
+            auto cross = [](double ox, double oy, double ax, double ay, double bx, double by) {
+                return (ax - ox) * (by - oy) - (ay - oy) * (bx - ox);
+            };
+            int k = 0;
+            for (int i = 0; i < m; i++) {
+                while (k >= 2 && cross(hx[k - 2], hy[k - 2], hx[k - 1], hy[k - 1], sx[i], sy[i]) <= 0) k--;
+                hx[k] = sx[i]; hy[k] = sy[i]; k++;
+            }
+            for (int i = m - 2, t = k + 1; i >= 0; i--) {
+                while (k >= t && cross(hx[k - 2], hy[k - 2], hx[k - 1], hy[k - 1], sx[i], sy[i]) <= 0) k--;
+                hx[k] = sx[i]; hy[k] = sy[i]; k++;
+            }
+            k--;
+            if (k >= 3) {
+                double a2 = 0.0;
+                for (int i = 0; i < k; i++) {
+                    const int n = (i + 1) % k;
+                    a2 += (hx[i] - hx[0]) * (hy[n] - hy[0]) - (hx[n] - hx[0]) * (hy[i] - hy[0]);
+                }
+                area = 0.5 * fabs(a2);
+            }
+        }
+        cov[e] = area;
+    }
+}
+
 __global__ void k_selftest(int op, const double *a, const double *b, double *out, long long n) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

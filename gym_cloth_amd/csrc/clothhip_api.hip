@@ -59,7 +59,8 @@ struct clothhip_handle {
     int HT = 0, ht_bits = 0, lvw_shift = 4, lds_bytes = 0, phase_mask = 15, nt = 256, ppt = 3;
     int tab = 0;            // static tables resident in LDS: 0 none, 1 springs/rest/offsets, 2 + per-point levels
     bool rest_reg = false;
-    double *d_levels = nullptr, *d_xy = nullptr, *d_radius = nullptr;
+    double *d_levels = nullptr, *d_xy = nullptr, *d_radius = nullptr, *d_cov = nullptr, *d_vinv = nullptr;
+    uint8_t *d_oob = nullptr;
     int n_grab_levels = 0;
     Topology topo;
     LevelSchedule lv;
@@ -155,7 +156,7 @@ static void free_handle(clothhip_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_pos, h->d_prev, h->d_rest, h->d_cnt, h->d_active, h->d_tear, h->d_exec, h->d_ngrab, h->d_stats,
-                    h->d_sched, h->d_gather, h->d_lv_ent, h->d_lv_off, h->d_pt_lev, h->d_lv_pad, h->d_rest_pad, h->d_levels, h->d_xy, h->d_radius};
+                    h->d_sched, h->d_gather, h->d_lv_ent, h->d_lv_off, h->d_pt_lev, h->d_lv_pad, h->d_rest_pad, h->d_levels, h->d_xy, h->d_radius, h->d_cov, h->d_vinv, h->d_oob};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->h_sched) (void)hipHostFree(h->h_sched);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -230,6 +231,9 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
     HC(hipMalloc(&h->d_levels, (levels.size() + 1) * 8));
     HC(hipMalloc(&h->d_xy, E * 2 * 8));
     HC(hipMalloc(&h->d_radius, E * 8));
+    HC(hipMalloc(&h->d_cov, E * 8));
+    HC(hipMalloc(&h->d_vinv, E * 8));
+    HC(hipMalloc(&h->d_oob, E));
     HC(hipMemcpy(h->d_gather, gather.data(), gather.size() * 4, hipMemcpyHostToDevice));
     HC(hipMemset(h->d_lv_ent, 0, (size_t)h->Spad * 4));
     HC(hipMemcpy(h->d_lv_ent, h->lv.ent.data(), (size_t)h->S * 4, hipMemcpyHostToDevice));
@@ -631,32 +635,21 @@ extern "C" int clothhip_metrics(clothhip_handle *h, double *coverage, double *va
     if (!h) return fail(CLOTHHIP_EINVAL, "handle is NULL");
     if (tear) if (int rc = clothhip_get_tear(h, tear)) return rc;
     if (!coverage && !variance_inv && !oob) return 0;
-    std::vector<double> pos((size_t)h->E * h->P * 3);
-    if (int rc = clothhip_get_state(h, 0, h->E, pos.data(), nullptr, nullptr)) return rc;
-    const int P = h->P;
-    std::vector<double> xy((size_t)P * 2);
-    for (int e = 0; e < h->E; e++) {
-        const double *q = pos.data() + (size_t)e * P * 3;
-        double mnx = q[0], mxx = q[0], mny = q[1], mxy = q[1], mnz = q[2], mxz = q[2], sum = 0.0;
-        for (int i = 0; i < P; i++) {
-            const double x = q[3 * i], y = q[3 * i + 1], z = q[3 * i + 2];
-            mnx = std::min(mnx, x); mxx = std::max(mxx, x); mny = std::min(mny, y); mxy = std::max(mxy, y);
-            mnz = std::min(mnz, z); mxz = std::max(mxz, z); sum += z;
-            xy[2 * i] = std::min(std::max(x, 0.0), 1.0); xy[2 * i + 1] = std::min(std::max(y, 0.0), 1.0);   // cloth_env.py:629
-        }
-        if (coverage) coverage[e] = clothhip_hull_area(xy.data(), P);
-        if (variance_inv) {
-            const double mean = sum / P;
-            double acc = 0.0;
-            for (int i = 0; i < P; i++) { const double d = q[3 * i + 2] - mean; acc += d * d; }
-            const double var = acc / P;                                          // np.var (population variance)
-            variance_inv[e] = var < 0.000001 ? 1000.0 : 0.001 / var;             // cloth_env.py:1081-1084
-        }
-        if (oob) {
-            const double slack = 0.25, bx = 1.0, by = 1.0, bz = 1.0;           // cloth_env.py:1031-1036
-            oob[e] = (mxx >= bx + slack || mnx < -slack || mxy >= by + slack || mny < -slack || mxz >= bz || mnz < 0) ? 1 : 0;
-        }
+    HIPCHECK(hipSetDevice(h->device));
+    int NS = 1; while (NS < h->P) NS <<= 1;
+    const int lds = (6 * NS + 64) * 8;
+    if (h->precision == CLOTHHIP_F64) {
+        HIPCHECK(hipFuncSetAttribute((const void *)k_metrics<double>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL(k_metrics<double>, dim3(h->E), dim3(256), lds, h->stream, (const double *)h->d_pos, h->P, h->Ppad, NS, h->d_cov, h->d_vinv, h->d_oob);
+    } else {
+        HIPCHECK(hipFuncSetAttribute((const void *)k_metrics<float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL(k_metrics<float>, dim3(h->E), dim3(256), lds, h->stream, (const float *)h->d_pos, h->P, h->Ppad, NS, h->d_cov, h->d_vinv, h->d_oob);
     }
+    HIPCHECK(hipGetLastError());
+    if (coverage) HIPCHECK(hipMemcpyAsync(coverage, h->d_cov, (size_t)h->E * 8, hipMemcpyDeviceToHost, h->stream));
+    if (variance_inv) HIPCHECK(hipMemcpyAsync(variance_inv, h->d_vinv, (size_t)h->E * 8, hipMemcpyDeviceToHost, h->stream));
+    if (oob) HIPCHECK(hipMemcpyAsync(oob, h->d_oob, (size_t)h->E, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
     return 0;
 }
 

@@ -117,3 +117,30 @@ def test_physics_facade_matches_oracle(oracle_lib):
     gr.release(); oc.release()
     c.update(); oc.update(1)
     assert np.array_equal(c.allpts_arr, oc.get_state()[0]) and not c.have_tear
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_device_metrics_match_reference(prec, oracle_lib):
+    """clothhip_metrics (device kernel: coverage = hull area of clipped xy, variance_inv, out-of-bounds) against
+    what the reference computes with scipy/Qhull + numpy (cloth_env.py:1020-1098) on flat / folded / clipped /
+    out-of-bounds / blob states. fp64 state: coverage within 1e-15, bit-identical to the host routine."""
+    import ctypes as C
+    from gym_cloth_amd import ClothBatch, _lib
+    g = oracle_lib.load_golden("g_metrics.npz")
+    n = len(g["pos"])
+    b = ClothBatch(base_cfg("tier1", 1), n_envs=n, precision=prec)
+    b.set_state(g["pos"], g["pos"], np.zeros((n, 625), dtype=np.uint8))
+    cov, vinv, oob, tear = b.metrics()
+    pos = b.positions()                      # what the device actually holds (rounded to fp32 in f32 mode)
+    L = _lib.load()
+    for i in range(n):
+        xy = np.ascontiguousarray(np.clip(pos[i][:, :2], 0, 1))
+        assert cov[i] == L.clothhip_hull_area(_lib.dp(xy), 625), i          # same arithmetic as the host routine
+        var = np.var(pos[i][:, 2])
+        want = 1000.0 if var < 0.000001 else 0.001 / var
+        assert abs(vinv[i] - want) <= 1e-10 * max(1.0, want), i
+    tol = 1e-15 if prec == "f64" else 2e-6
+    assert np.max(np.abs(cov - g["coverage"])) <= tol
+    assert np.array_equal(oob, g["oob"].astype(bool)) or prec == "f32"
+    assert not tear.any()
+    b.close()
