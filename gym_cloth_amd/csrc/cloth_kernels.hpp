@@ -139,7 +139,7 @@ struct LdsLayout {
         cur = take(4 * Ppad * tsz);
         ent = take(tab >= 1 ? Spad * 4 : 0);
         rest = take(tab >= 1 ? Spad * tsz : 0);
-        off = take(tab >= 1 ? (nL + 1) * 2 : 0);
+        off = take(tab >= 1 ? (nL + 24) * 2 : 0);       // padded: levels past the end are empty
         plev = take(tab >= 2 ? HK_SLOTS * Ppad * 2 : 0);
         flag = take(nL + 64);        // pending-level marks of the running sweep (all zero between sweeps)
         abits = take((Spad / 64 + 2) * 8);   // pre-pass: one bit per spring (level order)
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 2 : NT / 256)) void k_run_schedule
             T *d1 = reinterpret_cast<T *>(smem + lay.rest);
             for (int i = tid; i < A.Spad; i += NT) { d0[i] = A.lv_ent[i]; d1[i] = g_rest[i]; }
             uint16_t *d2 = reinterpret_cast<uint16_t *>(smem + lay.off);
-            for (int i = tid; i <= nL; i += NT) d2[i] = A.lv_off[i];
+            for (int i = tid; i < nL + 24; i += NT) d2[i] = A.lv_off[i < nL ? i : nL];
         }
         if (TAB >= 2) {
             uint16_t *d4 = reinterpret_cast<uint16_t *>(smem + lay.plev);
@@ -659,6 +659,7 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 2 : NT / 256)) void k_run_schedule
             __syncthreads();
             TSTAMP(8)
             if (tid < 64 && (misc[1] || (pm & PH_NOSKIP))) {
+                __builtin_amdgcn_s_setprio(3);            // the serial sweep is the critical path of the whole cloth
                 int tear = 0;
                 // dense: so many levels are flagged that tracking costs more than it saves -> run every level.
                 // sparse: a correction marks exactly the later levels that hold a spring of a moved particle.
@@ -683,54 +684,115 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 2 : NT / 256)) void k_run_schedule
                     const int res = lane >> lsh;
                     DevConsts<T> kl = k;                         // spring-test constants pinned in VGPRs
                     asm volatile("" : "+v"(kl.c11), "+v"(kl.tear_thresh));
-                    const uint32_t *tp = A.lv_pad + (lane & (lvw - 1));
-                    const T *rp = A.rest_pad + (size_t)e * A.rest_pad_stride + (lane & (lvw - 1));
+                    const int sl = lane & (lvw - 1);
                     int myL = res;                               // the level this lane currently holds
-                    uint32_t ec = tp[myL << lsh], e1 = tp[(myL + GR) << lsh], e2 = tp[(myL + 2 * GR) << lsh];
-                    T rc = rp[myL << lsh], r1 = rp[(myL + GR) << lsh], r2 = rp[(myL + 2 * GR) << lsh];
-                    int L = 0;
-                    while (L < nL) {
-                        const int grp = myL - L;                 // 0..GR-1: position of my level inside this pass
-                        const int a = (int)(ec & 0xFFFFu), b = (int)(ec >> 16);
-                        const Pt<T> PA = cur[a], PB = cur[b];
-                        const uint32_t ca = w_cnt(PA.w), cb = w_cnt(PB.w);
-                        const T dx = PA.x - PB.x, dy = PA.y - PB.y, dz = PA.z - PB.z;
-                        const T len2 = dx * dx + dy * dy + dz * dz;
-                        const T t11 = rc * kl.c11, tt = rc * kl.tear_thresh;
-                        const T tmin = t11 < tt ? t11 : tt;
-                        bool trig = false, tearl = false;
-                        T len = (T)0;
-                        if (!(ca != 0 && cb != 0) && (len2 > tmin * tmin * ((T)1 - filt_slack<T>()))) {
-                            len = dev_sqrt<T>(len2);                                            // :270
-                            tearl = len > tt;                                                   // :272
-                            trig = len > t11;                                                   // :275
+                    if (TAB >= 1) {
+                        // Lane-private stream over the compact level table in LDS: entry index = off[level] + slot,
+                        // a slot beyond the level's width reads the all-zero padding entry S (ptA == ptB == 0).
+                        // Every pass re-issues the loads of the NEXT entry unconditionally (same address while the lane
+                        // has not consumed), so no loaded value is touched before the following pass.
+                        const int ZE = A.S;                      // index of a zero entry (Spad > S, zero filled)
+                        int p0 = (int)loff[myL] + sl; p0 = p0 < (int)loff[myL + 1] ? p0 : ZE;
+                        int pn = (int)loff[myL + GR] + sl; pn = pn < (int)loff[myL + GR + 1] ? pn : ZE;
+                        uint32_t ec = ent[p0]; T rc = rest[p0];
+                        uint32_t e1 = ent[pn]; T r1 = rest[pn];
+                        int olo = (int)loff[myL + 2 * GR], ohi = (int)loff[myL + 2 * GR + 1];
+                        Pt<T> PA = cur[ec & 0xFFFFu], PB = cur[ec >> 16];
+                        int L = 0;
+                        while (L < nL) {
+                            const int grp = myL - L;             // 0..GR-1: position of my level inside this pass
+                            const int a = (int)(ec & 0xFFFFu), b = (int)(ec >> 16);
+                            const uint32_t ca = w_cnt(PA.w), cb = w_cnt(PB.w);
+                            const T dx = PA.x - PB.x, dy = PA.y - PB.y, dz = PA.z - PB.z;
+                            const T len2 = dx * dx + dy * dy + dz * dz;
+                            const T t11 = rc * kl.c11, tt = rc * kl.tear_thresh;
+                            const T tmin = t11 < tt ? t11 : tt;
+                            bool trig = false, tearl = false;
+                            T len = (T)0;
+                            if (!(ca != 0 && cb != 0) && (len2 > tmin * tmin * ((T)1 - filt_slack<T>()))) {
+                                len = dev_sqrt<T>(len2);                                        // :270
+                                tearl = len > tt;                                               // :272
+                                trig = len > t11;                                               // :275
+                            }
+                            const unsigned long long tb = __ballot(trig);
+                            // groups sit in lane ranges by residue class; rotate so that bit order == level order
+                            const int rot = (L & (GR - 1)) << lsh;
+                            const unsigned long long tr = rot ? ((tb >> rot) | (tb << (64 - rot))) : tb;
+                            const int g = tr ? (__ffsll((long long)tr) - 1) >> lsh : GR;        // first correcting level of the pass
+                            if (trig && grp == g) {
+                                const T ux = dev_div<T>(dx, len), uy = dev_div<T>(dy, len), uz = dev_div<T>(dz, len);   // :276-278
+                                const T extra = len - t11;                                      // :279
+                                const T wa = ca != 0 ? (T)0 : (cb != 0 ? (T)1 : (T)0.5);
+                                const T wb = cb != 0 ? (T)0 : (ca != 0 ? (T)1 : (T)0.5);
+                                const T ea = extra * wa, eb = extra * wb;
+                                if (ca == 0) cur[a] = Pt<T>{PA.x - ux * ea, PA.y - uy * ea, PA.z - uz * ea, PA.w};
+                                if (cb == 0) cur[b] = Pt<T>{PB.x + ux * eb, PB.y + uy * eb, PB.z + uz * eb, PB.w};
+                            }
+                            const int adv = g < GR ? g + 1 : GR;
+                            L += adv;
+                            // consume (branch-free): lanes whose level is done move on to their next level
+                            const bool cons = myL < L;
+                            myL = cons ? myL + GR : myL;
+                            ec = cons ? e1 : ec; rc = cons ? r1 : rc;
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                            PA = cur[ec & 0xFFFFu]; PB = cur[ec >> 16];      // next pass's particles (after this pass's writes)
+                            if (cons) { int q = olo + sl; pn = q < ohi ? q : ZE; }
+                            e1 = ent[pn]; r1 = rest[pn];
+                            olo = (int)loff[myL + 2 * GR]; ohi = (int)loff[myL + 2 * GR + 1];
+                            if (tearl && grp <= g) tear = 1;
+                            st_levels += adv; st_trig += g < GR ? 1 : 0;
                         }
-                        const unsigned long long tb = __ballot(trig);
-                        // groups sit in lane ranges by residue class; rotate so that bit order == level order
-                        const int rot = (L & (GR - 1)) << lsh;
-                        const unsigned long long tr = rot ? ((tb >> rot) | (tb << (64 - rot))) : tb;
-                        const int g = tr ? (__ffsll((long long)tr) - 1) >> lsh : GR;            // first correcting level of the pass
-                        if (trig && grp == g) {
-                            const T ux = dev_div<T>(dx, len), uy = dev_div<T>(dy, len), uz = dev_div<T>(dz, len);   // :276-278
-                            const T extra = len - t11;                                          // :279
-                            const T wa = ca != 0 ? (T)0 : (cb != 0 ? (T)1 : (T)0.5);
-                            const T wb = cb != 0 ? (T)0 : (ca != 0 ? (T)1 : (T)0.5);
-                            const T ea = extra * wa, eb = extra * wb;
-                            if (ca == 0) cur[a] = Pt<T>{PA.x - ux * ea, PA.y - uy * ea, PA.z - uz * ea, PA.w};
-                            if (cb == 0) cur[b] = Pt<T>{PB.x + ux * eb, PB.y + uy * eb, PB.z + uz * eb, PB.w};
+                    } else {
+                        // tables not resident in LDS (large grids): padded fixed-width table streamed from L2
+                        const uint32_t *tp = A.lv_pad + sl;
+                        const T *rp = A.rest_pad + (size_t)e * A.rest_pad_stride + sl;
+                        uint32_t ec = tp[myL << lsh], e1 = tp[(myL + GR) << lsh], e2 = tp[(myL + 2 * GR) << lsh];
+                        T rc = rp[myL << lsh], r1 = rp[(myL + GR) << lsh], r2 = rp[(myL + 2 * GR) << lsh];
+                        int L = 0;
+                        while (L < nL) {
+                            const int grp = myL - L;
+                            const int a = (int)(ec & 0xFFFFu), b = (int)(ec >> 16);
+                            const Pt<T> PA = cur[a], PB = cur[b];
+                            const uint32_t ca = w_cnt(PA.w), cb = w_cnt(PB.w);
+                            const T dx = PA.x - PB.x, dy = PA.y - PB.y, dz = PA.z - PB.z;
+                            const T len2 = dx * dx + dy * dy + dz * dz;
+                            const T t11 = rc * kl.c11, tt = rc * kl.tear_thresh;
+                            const T tmin = t11 < tt ? t11 : tt;
+                            bool trig = false, tearl = false;
+                            T len = (T)0;
+                            if (!(ca != 0 && cb != 0) && (len2 > tmin * tmin * ((T)1 - filt_slack<T>()))) {
+                                len = dev_sqrt<T>(len2);
+                                tearl = len > tt;
+                                trig = len > t11;
+                            }
+                            const unsigned long long tb = __ballot(trig);
+                            const int rot = (L & (GR - 1)) << lsh;
+                            const unsigned long long tr = rot ? ((tb >> rot) | (tb << (64 - rot))) : tb;
+                            const int g = tr ? (__ffsll((long long)tr) - 1) >> lsh : GR;
+                            if (trig && grp == g) {
+                                const T ux = dev_div<T>(dx, len), uy = dev_div<T>(dy, len), uz = dev_div<T>(dz, len);
+                                const T extra = len - t11;
+                                const T wa = ca != 0 ? (T)0 : (cb != 0 ? (T)1 : (T)0.5);
+                                const T wb = cb != 0 ? (T)0 : (ca != 0 ? (T)1 : (T)0.5);
+                                const T ea = extra * wa, eb = extra * wb;
+                                if (ca == 0) cur[a] = Pt<T>{PA.x - ux * ea, PA.y - uy * ea, PA.z - uz * ea, PA.w};
+                                if (cb == 0) cur[b] = Pt<T>{PB.x + ux * eb, PB.y + uy * eb, PB.z + uz * eb, PB.w};
+                            }
+                            if (tearl && grp <= g) tear = 1;
+                            const int adv = g < GR ? g + 1 : GR;
+                            st_levels += adv; st_trig += g < GR ? 1 : 0;
+                            L += adv;
+                            if (myL < L) {
+                                myL += GR;
+                                ec = e1; rc = r1; e1 = e2; r1 = r2;
+                                e2 = tp[(myL + 2 * GR) << lsh]; r2 = rp[(myL + 2 * GR) << lsh];
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                         }
-                        if (tearl && grp <= g) tear = 1;
-                        const int adv = g < GR ? g + 1 : GR;
-                        st_levels += adv; st_trig += g < GR ? 1 : 0;
-                        L += adv;
-                        if (myL < L) {                           // my level is done: take the next one of my residue class
-                            myL += GR;
-                            ec = e1; rc = r1; e1 = e2; r1 = r2;
-                            e2 = tp[(myL + 2 * GR) << lsh]; r2 = rp[(myL + 2 * GR) << lsh];
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     }
                 } else
                 for (int L0 = 0; L0 < nL; L0 += 64) {
@@ -821,6 +883,7 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 2 : NT / 256)) void k_run_schedule
                 }
                 if (__any(tear) && lane == 0) misc[0] = 1;
                 if (lane == 0) misc[1] = 0;
+                __builtin_amdgcn_s_setprio(0);
             }
             __syncthreads();
         }
