@@ -4,6 +4,7 @@ The HIP library is the ONLY compute path of this package: there is no CPU fallba
 is missing, or no HIP device is visible, the calls below raise -- loudly -- instead of degrading.
 """
 import ctypes as C
+import importlib.util
 import os
 
 import numpy as np
@@ -81,6 +82,30 @@ SYMBOLS = [
 _lib = None
 
 
+def _preload_shared_hip_runtime():
+    """One HIP runtime per process. PyTorch-ROCm wheels bundle their own libamdhip64/libhsa-runtime64 and ask for
+    them by file name, so if the system ROCm copy gets loaded first (by libclothhip.so), a later `import torch`
+    brings in a SECOND runtime that cannot see the GPU. When torch is installed, load its bundled runtime first
+    (no `import torch`): libclothhip's NEEDED libamdhip64.so.7 then binds to that same copy by SONAME. torch is
+    only the transport for the multi-GPU collectives (dist.py); without it the system ROCm runtime is used."""
+    if os.environ.get("CLOTHHIP_SYSTEM_HIP"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if not spec or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def load():
     """dlopen libclothhip.so and bind every declared symbol. Raises ClothHipError if it is not built."""
     global _lib
@@ -90,6 +115,7 @@ def load():
         raise ClothHipError(
             "libclothhip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C gym_cloth_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    _preload_shared_hip_runtime()
     try:
         L = C.CDLL(LIB_PATH)
     except OSError as e:
