@@ -144,3 +144,23 @@ def test_device_metrics_match_reference(prec, oracle_lib):
     assert np.array_equal(oob, g["oob"].astype(bool)) or prec == "f32"
     assert not tear.any()
     b.close()
+
+
+def test_oracle_corner_policy_reproduces_reference_action(oracle_lib):
+    """The vectorised OracleCornerPolicy on the post-reset observation gives exactly the action the reference's
+    examples/analytic.OracleCornerPolicy chose (seed 1337, tier 1), and the episode then ends as the reference's."""
+    from gym_cloth_amd.envs import ClothVecEnv
+    from gym_cloth_amd.policies import OracleCornerPolicy, RandomPolicy
+    g = oracle_lib.load_golden("g_env_tier1_1337.npz")
+    v = ClothVecEnv(base_cfg("tier1", 1337), n_envs=2, precision="f64")
+    v.seed([1337, 1337])
+    obs = v.reset()
+    pol = OracleCornerPolicy(v)
+    a = pol.get_action(obs)
+    k = int(g["n_reset_calls"])
+    assert np.array_equal(a[0], g["act"][k]) and np.array_equal(a[1], g["act"][k])
+    obs, rew, done, info = v.step(a)
+    assert done.all() and abs(rew[0] - g["rew"][0]) <= 1e-12
+    r = RandomPolicy(v).get_action()
+    assert r.shape == (2, 4) and (np.abs(r) <= 1).all()
+    v.close()
