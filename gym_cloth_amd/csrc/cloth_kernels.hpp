@@ -351,6 +351,7 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 2 : NT / 256)) void k_run_schedule
         }
         for (int h = tid; h < HT; h += NT) { hkey[h] = KEY_EMPTY; hco[h] = 0; }
         for (int i = tid; i < nL + 64; i += NT) lvflag[i] = 0;
+        for (int i = tid; i < (A.Spad / 64 + 2) * 2; i += NT) reinterpret_cast<uint32_t *>(smem + lay.abits)[i] = 0u;
         if (tid == 0) { misc[0] = A.tear[e]; misc[1] = 0; }
     }
     __syncthreads();
@@ -624,37 +625,38 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 2 : NT / 256)) void k_run_schedule
         //     correction marks exactly those levels); everything it skips is provably a no-op.
         if (pm & PH_STRAIN) {
             {
-                unsigned long long *abits = reinterpret_cast<unsigned long long *>(smem + lay.abits);
+                // Every spring is tested once, by the owner of its ptB (the particle the reference appended it for):
+                // the owner holds the spring's gather entry (neighbour = ptA, level-order position) and, with
+                // REST_REG, its rest length in registers, so the pre-pass needs one 16-byte LDS read per spring.
+                uint32_t *abits32 = reinterpret_cast<uint32_t *>(smem + lay.abits);
                 int nact = 0;
-                constexpr int U = 4;                         // springs per thread per trip: their LDS reads overlap
-                for (int p0 = 0; p0 < A.Spad; p0 += U * NT) {
-                    uint32_t en[U]; T r[U];
 #pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        const int p = p0 + u * NT + tid;
-                        const int pc = p < A.S ? p : 0;     // clamped: always a valid read, masked below
-                        en[u] = ent[pc]; r[u] = rest[pc];
-                    }
-                    bool act[U];
+                for (int q = 0; q < PPT; q++) {
+                    if (tid + q * NT < P) {
+                        const Pt<T> me = cur[tid + q * NT];
+                        const uint32_t cme_ = w_cnt(me.w);
 #pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        const Pt<T> a = cur[en[u] & 0xFFFFu], b = cur[en[u] >> 16];
-                        const T dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
-                        const T len2 = dx * dx + dy * dy + dz * dz;
-                        const T t11 = r[u] * k.c11, tt = r[u] * k.tear_thresh;
-                        const T tmin = t11 < tt ? t11 : tt;
-                        act[u] = (p0 + u * NT + tid < A.S) && !(w_cnt(a.w) != 0 && w_cnt(b.w) != 0) &&
-                                 (len2 > tmin * tmin * ((T)1 - filt_slack<T>()));
-                    }
-#pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        const int p = p0 + u * NT + tid;
-                        const unsigned long long bal = __ballot(act[u]);
-                        if (lane == 0 && p < A.Spad) abits[p >> 6] = bal;
-                        nact += __popcll(bal);
+                        for (int sl = 0; sl < HK_SLOTS / 2; sl++) {       // own springs come first in ascending list order
+                            uint32_t g = gt[q][sl];
+                            asm volatile("" : "+v"(g));
+                            const Pt<T> nb = cur[g & HK_NBR_MASK];
+                            const uint32_t pos_ = (g >> HK_POS_SHIFT) & HK_POS_MASK;
+                            const T r = REST_REG ? rr[REST_REG ? q : 0][sl] : rest[pos_];
+                            const T dx = nb.x - me.x, dy = nb.y - me.y, dz = nb.z - me.z;   // (ptA - ptB), as :270
+                            const T len2 = dx * dx + dy * dy + dz * dz;
+                            const T t11 = r * k.c11, tt = r * k.tear_thresh;
+                            const T tmin = t11 < tt ? t11 : tt;
+                            const bool act = (g & (HK_VALID | HK_ASB)) == (HK_VALID | HK_ASB) &&
+                                             !(cme_ != 0 && w_cnt(nb.w) != 0) &&
+                                             (len2 > tmin * tmin * ((T)1 - filt_slack<T>()));
+                            if (act) { atomicOr(&abits32[pos_ >> 5], 1u << (pos_ & 31)); nact++; }
+                        }
                     }
                 }
-                if (nact && lane == 0) atomicAdd(&misc[1], nact);
+                if (__any(nact)) {
+                    for (int o = 32; o > 0; o >>= 1) nact += __shfl_xor(nact, o);
+                    if (lane == 0) atomicAdd(&misc[1], nact);
+                }
             }
             __syncthreads();
             TSTAMP(8)
@@ -884,6 +886,8 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? 2 : NT / 256)) void k_run_schedule
                 if (__any(tear) && lane == 0) misc[0] = 1;
                 if (lane == 0) misc[1] = 0;
                 __builtin_amdgcn_s_setprio(0);
+                // the pre-pass ORs into the bitmask: clear the words it set (they are all consumed now)
+                for (int i = lane; i < (A.Spad / 64 + 2) * 2; i += 64) reinterpret_cast<uint32_t *>(smem + lay.abits)[i] = 0u;
             }
             __syncthreads();
         }
