@@ -90,3 +90,73 @@ def test_f32_teacher_forced_windows(name, oracle_lib):
     print("\nfp32 windows %s: %s" % (name, ["cp%d n=%d err=%.2e" % w[:3] for w in worst]))
     assert worst
     assert all(w[2] <= w[3] for w in worst), worst
+
+
+@pytest.mark.parametrize("n_side,prec", [(12, "f64"), (27, "f64"), (33, "f64"), (50, "f64"), (64, "f32")])
+def test_other_grid_sizes_match_oracle(n_side, prec, oracle_lib):
+    """The other kernel variants (grid sizes != 25: different thread/LDS configurations, odd level widths) against
+    the CPU oracle on a lift + pull + release + settle sequence with a perturbed start and PER-ENV rest tables
+    (as tier 2 has): fp64 bit-exact over the whole 150-substep sequence; fp32 (64x64 does not fit LDS in fp64) within
+    1e-6 after 2 substeps."""
+    from gym_cloth_amd import ClothBatch
+    g = oracle_lib.load_golden("g_traj_lift_pull_25.npz")
+    ocfg = dict(g["cfg"], n_side=n_side, thickness=0.02 if n_side <= 27 else min(0.0095, 0.4 / (n_side - 1)))
+    cfg = cfg_from_golden({"cfg": ocfg})
+    E = 2
+    b = ClothBatch(cfg, n_envs=E, precision=prec)
+    rng = np.random.RandomState(n_side)
+    pos0, rest0 = b.init_grid(1)
+    states, rests = [], []
+    for e in range(E):
+        amp = 0.05 / (n_side - 1)                               # 5 % of the grid spacing
+        p = pos0 + rng.uniform(-amp, amp, size=pos0.shape) * np.array([1, 1, 0])
+        p[:, 2] = np.abs(rng.uniform(0, amp, size=len(p)))
+        states.append(p)
+        rests.append(rest0 * rng.uniform(0.995, 1.005, size=len(rest0)))
+    b.set_state(np.stack(states), np.stack(states), np.zeros((E, b.P), dtype=np.uint8), np.stack(rests), rest_shared=False)
+    ocs = []
+    for e in range(E):
+        oc = oracle_lib.OracleCloth(ocfg)
+        oc.set_state(states[e], states[e], np.zeros(b.P, dtype=np.uint8), rests[e])
+        ocs.append(oc)
+    mid = (n_side // 2) * n_side + n_side // 2                 # grab at a grid point (coarse grids have none at 0.5,0.5)
+    gx, gy = float(pos0[mid, 0]), float(pos0[mid, 1])
+    n = b.grab_top([gx, gy])
+    for e, oc in enumerate(ocs):
+        assert oc.grab_top(gx, gy) == n[e] and n[e] > 0
+    seq = [((0.0, 0.0, 0.0025), 2), ((0.0, 0.0, 0.0025), 28), ((0.0014, 0.0014, 0.0), 60), (None, 20)]
+    for si, (delta, k) in enumerate(seq):
+        b.update(k, delta=delta)
+        for oc in ocs:
+            for _ in range(k):
+                if delta is not None:
+                    oc.adjust(*delta)
+                oc.update(1)
+        if si == 0 and prec == "f32":                            # 2 substeps: a wrong kernel variant would show here
+            p2 = b.positions()                                   # (measured 1.3e-7..1.9e-7 = 1-2 fp32 ulp for every size)
+            for e, oc in enumerate(ocs):
+                assert max_abs(p2[e], oc.get_state()[0]) <= 1e-6, (n_side, e, max_abs(p2[e], oc.get_state()[0]))
+    b.release()
+    b.update(40)
+    for oc in ocs:
+        oc.release(); oc.update(40)
+    pos, prev, pin = b.get_state()
+    for e, oc in enumerate(ocs):
+        op, oq, opin = oc.get_state()
+        if prec == "f64":
+            assert np.array_equal(pos[e], op) and np.array_equal(prev[e], oq), (n_side, e, max_abs(pos[e], op))
+        else:
+            # this start sits on the strain-limit knife edge, so fp32 drifts chaotically over 150 substeps (SURVEY 7-H2):
+            # only a loose bound here, the sharp fp32 check is the 2-substep one above
+            assert np.isfinite(pos[e]).all() and max_abs(pos[e], op) <= 5e-2, (n_side, e, max_abs(pos[e], op))
+        assert bool(b.tear[e]) == oc.have_tear
+    b.close()
+
+
+def test_grid_too_large_for_lds_is_rejected():
+    from gym_cloth_amd import ClothBatch
+    g_cfg = cfg_from_golden({"cfg": {"n_side": 64, "width": 1, "height": 1, "density": 200.0, "ks": 1e4, "damping": 2.0,
+                                     "thickness": 0.0095, "plane_friction": 1.0, "tear_thresh": 2.0, "frames_per_sec": 30,
+                                     "simulation_steps": 30, "grip_radius": 0.003}})
+    with pytest.raises(ValueError):
+        ClothBatch(g_cfg, n_envs=1, precision="f64")        # 64x64 doubles do not fit the CU's 160 KiB LDS
