@@ -292,7 +292,7 @@ __device__ __forceinline__ void collide_cell_serial(Pt<T> *cur, uint16_t *m, int
 // lengths of its incident springs). Only the current positions are shared, through LDS.
 //   TAB: 0 static tables in global memory, 1 ent/rest/offsets in LDS, 2 also the per-point level table.
 template <typename T, int NT, int PPT, int TAB, bool REST_REG>
-__global__ __launch_bounds__(NT, (NT <= 256 ? 2 : NT / 256)) void k_run_schedule(StepArgs<T> A) {
+__global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule(StepArgs<T> A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int e = blockIdx.x;
     const int tid = threadIdx.x;

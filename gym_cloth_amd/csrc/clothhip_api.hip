@@ -187,7 +187,9 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
     h->lv = build_levels(h->topo);
     h->S = h->topo.S; h->Spad = (h->S + 63) / 64 * 64;
     // threads per cloth x particles per thread (compile-time variants of the stepper)
-    if (h->P <= 768) { h->nt = 256; h->ppt = 3; } else if (h->P <= 3072) { h->nt = 1024; h->ppt = 3; } else { h->nt = 1024; h->ppt = 4; }
+    if (h->P <= 768) { h->nt = 256; h->ppt = 3; }
+    else if (h->P <= 2560 && !getenv("CLOTHHIP_DEBUG_NT1024")) { h->nt = 512; h->ppt = 5; }
+    else if (h->P <= 3072) { h->nt = 1024; h->ppt = 3; } else { h->nt = 1024; h->ppt = 4; }
     h->HT = 64; h->ht_bits = 0;
     while (h->HT <= h->P + h->P / 2) h->HT <<= 1;
     while ((1 << h->ht_bits) < h->HT) h->ht_bits++;
@@ -274,7 +276,7 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
         const int tsz = (int)h->tsz;
         // 256-thread variants: two cloths per CU (<= 80 KiB each); 1024-thread variants own the CU (<= 160 KiB)
         const int budget = h->nt == 256 ? 80 * 1024 : 160 * 1024;
-        const int tmax = h->nt == 256 ? 2 : (h->ppt == 3 ? 1 : 0);
+        const int tmax = h->nt == 256 ? 2 : ((h->ppt == 3 || h->nt == 512) ? 1 : 0);
         h->tab = 0;
         for (int t = tmax; t >= 1; t--)
             if (LdsLayout(tsz, h->Ppad, h->Spad, h->lv.n_levels, h->HT, t).total <= budget) { h->tab = t; break; }
@@ -518,7 +520,7 @@ template <typename T> static StepArgs<T> make_args(clothhip_handle *h, const Clo
 // compile-time variants: (threads per cloth, particles per thread) x tables-in-LDS level x rest-in-registers
 #define CLOTH_VARIANTS(X, T)                                              \
     X(T, 256, 3, 2, true) X(T, 256, 3, 2, false) X(T, 256, 3, 1, false) X(T, 256, 3, 0, false)   \
-    X(T, 1024, 3, 0, false) X(T, 1024, 3, 1, false) X(T, 1024, 4, 0, false)
+    X(T, 512, 5, 0, false) X(T, 512, 5, 1, false) X(T, 1024, 3, 0, false) X(T, 1024, 3, 1, false) X(T, 1024, 4, 0, false)
 
 template <typename T> static const void *stepper_fn_t(const clothhip_handle *h) {
 #define X(T_, NT, PPT, TAB, RR) \
