@@ -993,12 +993,12 @@ template <typename T> __global__ void k_write_obs(const T *pos, float *out, int 
 
 // ---- per-env metrics on the device (cloth_env.py:1020-1098): coverage = area of the convex hull of the clipped
 // (x,y) (same monotone-chain + shoelace arithmetic, in double, as clothhip_hull_area on the host), variance_inv of z,
-// out-of-bounds. One 256-thread workgroup per env. LDS: sx/sy[NS] sort buffers + hx/hy[2*NS] hull stack.
+// out-of-bounds. One 256-thread workgroup per env. LDS: sx/sy[NS] sort buffers + hx/hy[NH] hull stack (NH >= P + 2).
 template <typename T>
-__global__ __launch_bounds__(256) void k_metrics(const T *pos, int P, int Ppad, int NS, double *cov, double *vinv, uint8_t *oob) {
+__global__ __launch_bounds__(256) void k_metrics(const T *pos, int P, int Ppad, int NS, int NH, double *cov, double *vinv, uint8_t *oob) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double *sx = reinterpret_cast<double *>(smem), *sy = sx + NS, *hx = sy + NS, *hy = hx + 2 * NS;
-    double *red = hy + 2 * NS;                                    // [64] reduction scratch
+    double *sx = reinterpret_cast<double *>(smem), *sy = sx + NS, *hx = sy + NS, *hy = hx + NH;
+    double *red = hy + NH;                                    // [64] reduction scratch
     const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const T *px = pos + (size_t)e * 3 * Ppad, *py = px + Ppad, *pz = py + Ppad;
     const double INF = __longlong_as_double(0x7ff0000000000000LL);

@@ -639,13 +639,14 @@ extern "C" int clothhip_metrics(clothhip_handle *h, double *coverage, double *va
     if (!coverage && !variance_inv && !oob) return 0;
     HIPCHECK(hipSetDevice(h->device));
     int NS = 1; while (NS < h->P) NS <<= 1;
-    const int lds = (6 * NS + 64) * 8;
+    const int NH = h->Ppad + 8;                 // the monotone chain holds at most m + 1 <= P + 1 points
+    const int lds = (2 * NS + 2 * NH + 64) * 8;
     if (h->precision == CLOTHHIP_F64) {
         HIPCHECK(hipFuncSetAttribute((const void *)k_metrics<double>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL(k_metrics<double>, dim3(h->E), dim3(256), lds, h->stream, (const double *)h->d_pos, h->P, h->Ppad, NS, h->d_cov, h->d_vinv, h->d_oob);
+        hipLaunchKernelGGL(k_metrics<double>, dim3(h->E), dim3(256), lds, h->stream, (const double *)h->d_pos, h->P, h->Ppad, NS, NH, h->d_cov, h->d_vinv, h->d_oob);
     } else {
         HIPCHECK(hipFuncSetAttribute((const void *)k_metrics<float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL(k_metrics<float>, dim3(h->E), dim3(256), lds, h->stream, (const float *)h->d_pos, h->P, h->Ppad, NS, h->d_cov, h->d_vinv, h->d_oob);
+        hipLaunchKernelGGL(k_metrics<float>, dim3(h->E), dim3(256), lds, h->stream, (const float *)h->d_pos, h->P, h->Ppad, NS, NH, h->d_cov, h->d_vinv, h->d_oob);
     }
     HIPCHECK(hipGetLastError());
     if (coverage) HIPCHECK(hipMemcpyAsync(coverage, h->d_cov, (size_t)h->E * 8, hipMemcpyDeviceToHost, h->stream));

@@ -164,3 +164,15 @@ def test_oracle_corner_policy_reproduces_reference_action(oracle_lib):
     r = RandomPolicy(v).get_action()
     assert r.shape == (2, 4) and (np.abs(r) <= 1).all()
     v.close()
+
+
+def test_device_metrics_large_grid():
+    """k_metrics at 50x50 (sort buffer of 4096 points): flat cloth -> coverage 1, variance_inv 1000, in bounds."""
+    from gym_cloth_amd import ClothBatch
+    cfg = base_cfg("tier1", 1)
+    cfg["cloth"]["num_width_points"] = cfg["cloth"]["num_height_points"] = 50
+    cfg["cloth"]["thickness"] = 0.0095
+    b = ClothBatch(cfg, n_envs=3, precision="f32")
+    cov, vinv, oob, tear = b.metrics()
+    assert np.allclose(cov, 1.0, atol=1e-6) and (vinv == 1000.0).all() and not oob.any() and not tear.any()
+    b.close()
