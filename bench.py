@@ -44,9 +44,10 @@ def bench_cfg(n_side, thickness):
         "log": {"level": "info", "file": "logs/bench.log"}, "seed": 1000}
 
 
-def cpu_baseline(cfg, acts0, budget_s=15.0):
+def cpu_baseline(cfg, acts0, states, budget_s=15.0):
     """The CPU oracle (oracle/, exact-order fp64 C port of the reference) timed on this box's host cores on a
-    bounded sample of the same workload: flat cloths + the first timed action of the first n envs."""
+    bounded sample of the SAME workload: the first timed bench step of the first n envs, started from the very
+    cloth states the GPU path started that step from (downloaded before the timed region)."""
     from oracle import pyoracle
     pyoracle.build()
     cores = len(os.sched_getaffinity(0))
@@ -57,43 +58,37 @@ def cpu_baseline(cfg, acts0, budget_s=15.0):
             "plane_friction": c["plane_friction"], "tear_thresh": c["tear_thresh"],
             "frames_per_sec": cfg["frames_per_sec"], "simulation_steps": cfg["simulation_steps"],
             "gravity": -9.8, "minimum_z": 0.0, "grip_radius": cfg["env"]["grip_radius"]}
-    # ~70 us per 25x25 substep per core -> size the sample for ~budget_s of wall time
-    per_sub = 70e-6 * (c["num_width_points"] ** 2) / 625.0
-    n = int(max(threads, min(len(acts0), budget_s * threads / (1600 * per_sub))))
-    n = max(threads, (n // threads) * threads)
-    n = min(n, len(acts0))
-    from gym_cloth_amd.envs import _EPS
-    cloths, sched, delta = [], np.zeros((n, 5), dtype=np.int32), np.zeros((n, 3))
+    pos, prev, pin = states
+    # ~70-150 us per 25x25 substep per core -> size the sample for ~budget_s of wall time
+    per_sub = 100e-6 * (c["num_width_points"] ** 2) / 625.0
+    n = int(max(threads, min(len(acts0), budget_s * threads / (1200 * per_sub))))
+    n = min(max(threads, (n // threads) * threads), len(acts0), len(pos))
+    from gym_cloth_amd.envs import decode_actions
     e = cfg["env"]
+    d = decode_actions(acts0[:n], [-1.] * 4, [1.] * 4, True, True, e["reduce_factor"], e["iters_up"], e["iters_up_rest"],
+                       e["iters_pull_max"], e["iters_grip_rest"], e["iters_rest"])
+    cloths, sched, delta = [], np.zeros((n, 5), dtype=np.int32), np.zeros((n, 3))
     for k in range(n):
         oc = pyoracle.OracleCloth(ocfg)
-        a = np.clip(acts0[k], -1, 1)
-        x, y = a[0] / 2 + 0.5, a[1] / 2 + 0.5
-        L = np.sqrt(a[2] ** 2 + a[3] ** 2)
-        xr, yr = a[2] / (L + _EPS) * e["reduce_factor"], a[3] / (L + _EPS) * e["reduce_factor"]
-        step, cur, ii = np.sqrt(xr ** 2 + yr ** 2), 0.0, 0
-        while True:
-            cur += step
-            if cur >= L:
-                break
-            ii += 1
-        ng = oc.grab_top(x, y)
-        b = np.cumsum([e["iters_up"], e["iters_up_rest"], ii, e["iters_grip_rest"], e["iters_rest"]])
-        sched[k] = b if ng > 0 else 0
-        delta[k] = (0.0025, xr, yr)
+        oc.set_state(pos[k], prev[k], pin[k])
+        ng = oc.grab_top(float(d["x"][k]), float(d["y"][k]))
+        sched[k] = d["bounds"][k] if ng > 0 else 0
+        delta[k] = (0.0025, d["x_dir_r"][k], d["y_dir_r"][k])
         cloths.append(oc)
     t0 = time.perf_counter()
     ex = pyoracle.batch_run_schedule(cloths, sched, delta, True, threads)
     dt = time.perf_counter() - t0
-    t1 = time.perf_counter()                                # single-core figure on a small slice
-    n1 = min(2, n)
-    ex1 = pyoracle.batch_run_schedule([pyoracle.OracleCloth(ocfg) for _ in range(n1)],
-                                      np.tile([0, 0, 0, 400, 400], (n1, 1)), np.zeros((n1, 3)), False, 1)
+    k1 = int(np.argmax(ex))                                    # single-core figure: the busiest of those cloths again
+    oc = pyoracle.OracleCloth(ocfg)
+    oc.set_state(pos[k1], prev[k1], pin[k1])
+    oc.grab_top(float(d["x"][k1]), float(d["y"][k1]))
+    t1 = time.perf_counter()
+    ex1 = oc.run_schedule(sched[k1], 0.0025, float(d["x_dir_r"][k1]), float(d["y_dir_r"][k1]), True)
     dt1 = time.perf_counter() - t1
     return {"value": float(ex.sum() / dt), "unit": "cloth-substeps/s", "cores": int(threads), "kind": "port",
-            "sample": "%d flat %dx%d cloths x first bench action (%d substeps total), OpenMP one cloth per thread"
-                      % (n, c["num_width_points"], c["num_width_points"], int(ex.sum())),
-            "single_core_value": float(ex1.sum() / dt1)}
+            "sample": "first timed step of the first %d envs (same start states and actions as the GPU run, %d substeps "
+                      "in total), OpenMP one cloth per thread" % (n, int(ex.sum())),
+            "single_core_value": float(ex1 / dt1) if dt1 > 0 and ex1 > 0 else None}
 
 
 def main():
@@ -167,6 +162,11 @@ def main():
     for t in range(args.warmup):
         one_step(t)
     fence()
+    cpu_states = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # start states of the first timed step (untimed copy)
+        ncpu = min(E, 512)
+        cpu_states = env.batch.get_state(0, ncpu)
+        fence()
     t0 = time.perf_counter()
     n_sub, k_ms, k_sub = 0, 0.0, 0
     for t in range(args.warmup, total_steps):
@@ -202,7 +202,7 @@ def main():
                          "alg_bytes_per_substep": b_alg},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, acts_all[args.warmup])
+            out["cpu_baseline"] = cpu_baseline(cfg, acts_all[args.warmup], cpu_states)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
