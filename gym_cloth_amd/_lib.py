@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libclothhip.so")
+# CLOTHHIP_LIB: another build of the same library (A/B kernel comparisons); it must export the same C ABI
+LIB_PATH = os.environ.get("CLOTHHIP_LIB") or os.path.join(_HERE, "libclothhip.so")
 
 F64, F32 = 0, 1
 

@@ -51,6 +51,7 @@ template <typename T> struct StepArgs {
     const uint32_t *gather;  // [HK_SLOTS][Ppad]
     const uint32_t *lv_ent;  // [Spad]  ptA | ptB<<16, level order
     const uint16_t *lv_off;  // [n_levels+1]
+    const uint16_t *lv_off8; // [n_levels8+1] the same springs cut into levels of width <= 8 (sub-levels of the levels above)
     const uint16_t *pt_lev;  // [HK_SLOTS][Ppad] dependency level of the k-th incident spring of a point (0xFFFF none)
     const uint32_t *lv_pad;  // [n_levels + 16][LVW] fixed-width level table for the dense sweep: ent, empty slots = 0 (ptA == ptB)
     const T *rest_pad;       // [E or 1][(n_levels + 16) * LVW] rest lengths in the same padded order
@@ -62,6 +63,8 @@ template <typename T> struct StepArgs {
     int32_t lvw_shift;       // lanes per level in the parallel pre-pass = 1 << lvw_shift (16 or 32)
     int32_t rest_stride;     // 0: one shared table
     int32_t dense_thresh;    // pre-pass flagged levels above which the sweep stops tracking and runs every level
+    int32_t n_levels8;       // 0: no narrow table
+    int32_t narrow_thresh;   // dense sweep: at most this many flagged levels -> narrow table (8 levels per pass)
     int32_t phase_mask;      // debug/ablation: bit0 hooke+verlet, bit1 collide, bit2 plane, bit3 strain, bit4 no-skip
     DevConsts<T> k;
 };
@@ -98,6 +101,13 @@ __device__ __forceinline__ uint32_t row_or_scan(uint32_t v) {
     v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
     return v;
 }
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// value of lane `src` (per-lane varying) through the LDS crossbar
+__device__ __forceinline__ int lane_pull(int v, int src) { return __builtin_amdgcn_ds_bpermute(src << 2, v); }
+__device__ __forceinline__ float lane_pull(float v, int src) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(v))); }
+__device__ __forceinline__ double lane_pull(double v, int src) {
+    return __hiloint2double(__builtin_amdgcn_ds_bpermute(src << 2, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(src << 2, __double2loint(v)));
+}
 // relative slack of the conservative "could this comparison against a sqrt be true" pre-filters
 template <typename T> __device__ __forceinline__ T filt_slack();
 template <> __device__ __forceinline__ double filt_slack<double>() { return 1e-9; }
@@ -132,14 +142,15 @@ template <typename T> __device__ __forceinline__ uint32_t cell_key(const DevCons
 // LDS carve-up (dynamic shared memory), all offsets in bytes, 16-byte aligned.
 // tab: 0 = static tables stay in global memory, 1 = ent/rest/off in LDS, 2 = + per-point level table
 struct LdsLayout {
-    int cur, ent, rest, off, plev, flag, abits, hkey, hco, memb, slot, misc, total;
-    __host__ __device__ LdsLayout(int tsz, int Ppad, int Spad, int nL, int HT, int tab) {
+    int cur, ent, rest, off, off8, plev, flag, abits, hkey, hco, memb, slot, misc, alist, total;
+    __host__ __device__ LdsLayout(int tsz, int Ppad, int Spad, int nL, int nL8, int HT, int tab) {
         int o = 0;
         auto take = [&](int bytes) { int r = o; o += (bytes + 15) / 16 * 16; return r; };
         cur = take(4 * Ppad * tsz);
         ent = take(tab >= 1 ? Spad * 4 : 0);
         rest = take(tab >= 1 ? Spad * tsz : 0);
         off = take(tab >= 1 ? (nL + 24) * 2 : 0);       // padded: levels past the end are empty
+        off8 = take(tab >= 1 && nL8 > 0 ? (nL8 + 40) * 2 : 0);
         plev = take(tab >= 2 ? HK_SLOTS * Ppad * 2 : 0);
         flag = take(nL + 64);        // pending-level marks of the running sweep (all zero between sweeps)
         abits = take((Spad / 64 + 2) * 8);   // pre-pass: one bit per spring (level order)
@@ -147,7 +158,8 @@ struct LdsLayout {
         hco = take(HT * 4);          // (fill cursor << 16) | member count
         memb = take(Ppad * 2);
         slot = take(Ppad * 2);
-        misc = take(256);
+        misc = take(128);            // flags and scan scratch
+        alist = take(Ppad);           // hash slots of the cells that have a seed this substep (<= P/2 entries, u16)
         total = o;
     }
 };
@@ -193,11 +205,9 @@ __device__ __forceinline__ int strain_apply(Pt<T> *cur, uint32_t en, const Pt<T>
 
 // Self-collision of ONE spatial cell (cloth.pyx:313-343) by a whole wave, exact Gauss-Seidel order:
 // lane b holds the cell's b-th member in ascending point index; members are visited serially in that order
-// (a = first..n-1), each against all lanes in parallel; the hits are summed in ascending member order.
-// `first` = smallest member index that can move (from the parallel pre-check); members before it provably
-// do not move. n <= 64.
+// each against all lanes in parallel; the hits are summed in ascending member order. n <= 64.
 template <typename T>
-__device__ __forceinline__ void collide_cell_wave(Pt<T> *cur, uint16_t *m, const uint16_t *slot, int n, int first,
+__device__ __forceinline__ void collide_cell_wave(Pt<T> *cur, uint16_t *m, const uint16_t *slot, int n,
                                                   const DevConsts<T> &k, int lane) {
     const bool in = lane < n;
     const int mine = in ? (int)m[lane] : 0x7fff;
@@ -210,11 +220,16 @@ __device__ __forceinline__ void collide_cell_wave(Pt<T> *cur, uint16_t *m, const
     const int i = in ? (int)m[lane] : 0;
     const Pt<T> me = cur[i];
     T x = me.x, y = me.y, z = me.z;
-    // members to visit: candidates (a neighbour close enough that it could come within range even after both
-    // moved by the per-substep maximum) that are not pinned, from the first real mover on. Everyone else
-    // provably collects no hit (cloth.pyx:330 never true) and is skipped without changing the result.
-    unsigned long long todo = __ballot(in && (slot[i] & 0x8000u) != 0 && w_cnt(me.w) == 0 && i >= first);
+    // Members to visit, in ascending order: the SEEDS (unpinned members that have a hit at the positions the phase
+    // started from, flagged by the parallel pre-check) and, dynamically, every later unpinned member that is within
+    // the candidate radius of a member that actually MOVED: a move displaces a particle by at most thresh/steps, so
+    // anyone farther than thresh*(1+2/steps) from the mover's old position cannot be hit by it. All other members
+    // provably collect no hit at their turn (cloth.pyx:330 never true) and are skipped without changing the result.
+    const bool free_ = in && w_cnt(me.w) == 0;
+    unsigned long long todo = ballot64(free_ && (slot[i] & 0x8000u) != 0);
     const T thr2 = k.thresh * k.thresh * ((T)1 + filt_slack<T>());
+    const T cfac = (T)1 + (T)2 / k.sim_steps;
+    const T thr2c = thr2 * cfac * cfac;
     bool moved = false;
     while (todo) {
         const int a = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
@@ -230,7 +245,7 @@ __device__ __forceinline__ void collide_cell_wave(Pt<T> *cur, uint16_t *m, const
             const T factor = dev_div<T>(k.thresh - dist, dist);                         // :331
             fx = dx * factor; fy = dy * factor; fz = dz * factor;
         }
-        unsigned long long hm = __ballot(hit);
+        unsigned long long hm = ballot64(hit);
         if (!hm) continue;
         T tx = (T)0, ty = (T)0, tz = (T)0;
         int nh = 0;
@@ -245,6 +260,75 @@ __device__ __forceinline__ void collide_cell_wave(Pt<T> *cur, uint16_t *m, const
         const T nya = ya + dev_div<T>(dev_div<T>(ty, nf), k.sim_steps);
         const T nza = za + dev_div<T>(dev_div<T>(tz, nf), k.sim_steps);
         if (lane == a) { x = nxa; y = nya; z = nza; moved = true; }
+        todo |= ballot64(free_ && lane > a && !(d2 > thr2c));                           // a moved: later neighbours must look
+    }
+    if (moved) cur[i] = Pt<T>{x, y, z, me.w};
+}
+
+// Four SMALL cells (<= 16 members each) at once, one per 16-lane group of the wave; same exact Gauss-Seidel
+// semantics as collide_cell_wave, with group-local broadcasts through ds_bpermute. `hs` = this lane's group's hash
+// slot (or -1: no cell for this group).
+template <typename T>
+__device__ __forceinline__ void collide_cells_group16(Pt<T> *cur, uint16_t *memb, const uint16_t *slot,
+                                                      const uint32_t *hco, int hs, const DevConsts<T> &k, int lane) {
+    const int sub = lane & 15, base = lane & ~15, gsh = base;            // my group's lanes are [base, base+16)
+    const bool gvalid = hs >= 0;
+    const uint32_t co = gvalid ? hco[hs] : 0u;
+    const int n = (int)(co & 0xFFFFu);
+    const int start = (int)(co >> 16) - n;
+    const bool in = gvalid && sub < n;
+    const int mine = in ? (int)memb[start + sub] : 0x7fff;
+    int rank = 0;
+#pragma unroll 4
+    for (int t = 0; t < 16; t++) rank += (lane_pull(mine, base + t) < mine) ? 1 : 0;
+    // members get ranks 0..n-1 (ascending index); the other lanes of the group keep their own position (>= n)
+    const int i = __builtin_amdgcn_ds_permute((base + (in ? rank : sub)) << 2, in ? mine : 0);
+    const bool ins = gvalid && sub < n;                                  // after the permutation lane sub < n holds rank sub
+    const Pt<T> me = cur[ins ? i : 0];
+    T x = me.x, y = me.y, z = me.z;
+    const bool free_ = ins && w_cnt(me.w) == 0;
+    const bool want = free_ && (slot[ins ? i : 0] & 0x8000u) != 0;
+    unsigned int todo = (unsigned int)((ballot64(want) >> gsh) & 0xFFFFull);          // my group's seeds
+    const T thr2 = k.thresh * k.thresh * ((T)1 + filt_slack<T>());
+    const T cfac = (T)1 + (T)2 / k.sim_steps;
+    const T thr2c = thr2 * cfac * cfac;
+    bool moved = false;
+    while (__any(todo != 0u)) {
+        const bool act = todo != 0u;
+        const int a = act ? __ffs((int)todo) - 1 : 0;
+        todo &= todo - 1u;
+        const T xa = lane_pull(x, base + a), ya = lane_pull(y, base + a), za = lane_pull(z, base + a);
+        const T dx = xa - x, dy = ya - y, dz = za - z;
+        const T d2 = dx * dx + dy * dy + dz * dz;
+        bool hit = act && ins && sub != a && !(d2 > thr2);
+        T fx = (T)0, fy = (T)0, fz = (T)0;
+        if (hit) {
+            const T dist = dev_sqrt<T>(d2);                                             // :327
+            hit = dist <= k.thresh;                                                     // :330
+            const T factor = dev_div<T>(k.thresh - dist, dist);                         // :331
+            fx = dx * factor; fy = dy * factor; fz = dz * factor;
+        }
+        unsigned int hm = (unsigned int)((ballot64(hit) >> gsh) & 0xFFFFull);
+        if (!__any(hm != 0u)) continue;
+        T tx = (T)0, ty = (T)0, tz = (T)0;
+        int nh = 0;
+        while (__any(hm != 0u)) {                                                       // ascending candidate order
+            const bool has = hm != 0u;
+            const int b = has ? __ffs((int)hm) - 1 : 0;
+            hm &= hm - 1u;
+            const T vx = lane_pull(fx, base + b), vy = lane_pull(fy, base + b), vz = lane_pull(fz, base + b);
+            if (has) { tx += vx; ty += vy; tz += vz; nh++; }
+        }
+        if (nh != 0 && sub == a && act) {                                               // :336-343
+            const T nf = (T)nh;
+            x = xa + dev_div<T>(dev_div<T>(tx, nf), k.sim_steps);
+            y = ya + dev_div<T>(dev_div<T>(ty, nf), k.sim_steps);
+            z = za + dev_div<T>(dev_div<T>(tz, nf), k.sim_steps);
+            moved = true;
+        }
+        // my group's `a` moved: its later neighbours within the candidate radius must look too
+        const bool wake = act && nh != 0 && free_ && sub > a && !(d2 > thr2c);
+        todo |= (unsigned int)((ballot64(wake) >> gsh) & 0xFFFFull);
     }
     if (moved) cur[i] = Pt<T>{x, y, z, me.w};
 }
@@ -303,14 +387,15 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
         return;
     }
     const int P = A.P, Ppad = A.Ppad, nL = A.n_levels, HT = A.HT;
-    const LdsLayout lay((int)sizeof(T), Ppad, A.Spad, nL, HT, TAB);
+    const LdsLayout lay((int)sizeof(T), Ppad, A.Spad, nL, A.n_levels8, HT, TAB);
     Pt<T> *cur = reinterpret_cast<Pt<T> *>(smem + lay.cur);
     uint8_t *lvflag = smem + lay.flag;
     uint32_t *hkey = reinterpret_cast<uint32_t *>(smem + lay.hkey);
     uint32_t *hco = reinterpret_cast<uint32_t *>(smem + lay.hco);
     uint16_t *memb = reinterpret_cast<uint16_t *>(smem + lay.memb);
     uint16_t *slot = reinterpret_cast<uint16_t *>(smem + lay.slot);
-    int *misc = reinterpret_cast<int *>(smem + lay.misc);   // [0] tear, [1] #levels flagged by the pre-pass, [8..] scan
+    int *misc = reinterpret_cast<int *>(smem + lay.misc);   // [0] tear, [1] #levels flagged by the pre-pass, [2] #active cells, [8..] scan
+    uint16_t *alist = reinterpret_cast<uint16_t *>(smem + lay.alist);
     const DevConsts<T> &k = A.k;
     const T *g_rest = A.rest + (size_t)e * A.rest_stride;
     const uint32_t *ent = TAB >= 1 ? reinterpret_cast<const uint32_t *>(smem + lay.ent) : A.lv_ent;
@@ -344,6 +429,8 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
             for (int i = tid; i < A.Spad; i += NT) { d0[i] = A.lv_ent[i]; d1[i] = g_rest[i]; }
             uint16_t *d2 = reinterpret_cast<uint16_t *>(smem + lay.off);
             for (int i = tid; i < nL + 24; i += NT) d2[i] = A.lv_off[i < nL ? i : nL];
+            uint16_t *d3 = reinterpret_cast<uint16_t *>(smem + lay.off8);
+            for (int i = tid; i < (A.n_levels8 > 0 ? A.n_levels8 + 40 : 0); i += NT) d3[i] = A.lv_off8[i < A.n_levels8 ? i : A.n_levels8];
         }
         if (TAB >= 2) {
             uint16_t *d4 = reinterpret_cast<uint16_t *>(smem + lay.plev);
@@ -352,7 +439,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
         for (int h = tid; h < HT; h += NT) { hkey[h] = KEY_EMPTY; hco[h] = 0; }
         for (int i = tid; i < nL + 64; i += NT) lvflag[i] = 0;
         for (int i = tid; i < (A.Spad / 64 + 2) * 2; i += NT) reinterpret_cast<uint32_t *>(smem + lay.abits)[i] = 0u;
-        if (tid == 0) { misc[0] = A.tear[e]; misc[1] = 0; }
+        if (tid == 0) { misc[0] = A.tear[e]; misc[1] = 0; misc[2] = 0; }
     }
     __syncthreads();
 
@@ -360,7 +447,11 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
     int done = 0;
     int st_sweeps = 0, st_dense = 0, st_levels = 0, st_trig = 0;      // wave 0 only (uniform)
     unsigned long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+#ifdef CLOTHHIP_PHASE_STAMPS                 // profiling build (make stamps): phase mask bit 32 turns the stamps on
     const bool timing = (pm & PH_TIME) != 0;
+#else
+    constexpr bool timing = false;          // the stamp accumulators would cost the hot loops two dozen SGPRs
+#endif
 #define TSTAMP(slot_)                                                          \
     if (timing) {                                                              \
         unsigned long long tn_;                                                \
@@ -518,15 +609,10 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
             __syncthreads();
             TSTAMP(4)
             // ---- self-collision (cloth.pyx:313-343) ------------------------------------------------------
-            // (1) every particle, in parallel: can it move at all (any same-cell candidate within 2*thickness
-            //     at the CURRENT positions)? the smallest such index per cell is the first mover; everything
-            //     before it provably stays put. The key word of the slot is recycled to hold that index.
+            // (1) every unpinned particle, in parallel: does it have a hit (a same-cell member within 2*thickness) at
+            //     the CURRENT positions? Those are the seeds of the exact sweep (flag bit of its slot word); a cell
+            //     with a seed is active (its key word is recycled to hold the smallest seed index).
             const T thr2 = k.thresh * k.thresh * ((T)1 + filt_slack<T>());
-            // candidate radius: a particle moves at most thresh/steps in this phase (|corr| = |tot/n/steps| and
-            // every summand has length thresh - dist <= thresh), so a pair farther apart than
-            // thresh * (1 + 2/steps) now can never come within thresh during the sweep.
-            const T cfac = (T)1 + (T)2 / k.sim_steps;
-            const T thr2c = thr2 * cfac * cfac;
             {
                 int cn[PPT], cstart[PPT];
                 int nmax = 0;
@@ -539,9 +625,9 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                     cstart[q] = (int)(co >> 16) - (int)(co & 0xFFFFu);
                     nmax = cn[q] > nmax ? cn[q] : nmax;
                 }
-                bool hit[PPT], cand[PPT];
+                bool hit[PPT];
 #pragma unroll
-                for (int q = 0; q < PPT; q++) hit[q] = cand[q] = false;
+                for (int q = 0; q < PPT; q++) hit[q] = false;
                 for (int b = 0; b < nmax; b += 4) {          // 4 members x PPT particles per trip: their LDS reads overlap
                     int jj[PPT][4];
 #pragma unroll
@@ -560,40 +646,68 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                             const T d2 = dx * dx + dy * dy + dz * dz;
                             const bool other = (b + u < cn[q]) && jj[q][u] != tid + q * NT;
                             hit[q] |= other && !(d2 > thr2);
-                            cand[q] |= other && !(d2 > thr2c);
                         }
                 }
 #pragma unroll
                 for (int q = 0; q < PPT; q++) {
-                    if (hit[q]) atomicMin(&hkey[ch[q]], (uint32_t)(tid + q * NT));
-                    if (cand[q]) slot[tid + q * NT] = (uint16_t)(ch[q] | 0x8000u);
+                    if (hit[q]) {
+                        slot[tid + q * NT] = (uint16_t)(ch[q] | 0x8000u);
+                        // the first seed of a cell (whoever wins) puts the cell on the active list
+                        if (atomicMin(&hkey[ch[q]], (uint32_t)(tid + q * NT)) >= KEY_FLOOR)
+                            alist[atomicAdd(&misc[2], 1)] = (uint16_t)ch[q];
+                    }
                 }
             }
             __syncthreads();
             TSTAMP(5)
-            // (2) one wave per cell that has a mover: exact Gauss-Seidel sweep from the first mover on. Every wave
-            // scans all slots and takes every nw-th active cell, so the cells are spread evenly over the waves.
+            // (2) the active cells (those with a seed): exact Gauss-Seidel sweep. Wave w takes list entries w, w+nw, ...
+            // (cells are independent: each particle sits in exactly one). Cells with <= 16 members are processed four
+            // at a time, one per 16-lane group; larger cells get the whole wave.
             {
                 const int wave = tid >> 6, nw = NT >> 6;
-                int seen = 0;
-                for (int h0 = 0; h0 < HT; h0 += 64) {
-                    unsigned long long am = __ballot(hkey[h0 + lane] < KEY_FLOOR);
-                    while (am) {
-                        const int b = __builtin_amdgcn_readfirstlane(__ffsll((long long)am) - 1);
-                        am &= am - 1ull;
-                        if ((seen++ % nw) != wave) continue;
-                        const uint32_t co = hco[h0 + b];
+                const int na = __builtin_amdgcn_readfirstlane(misc[2]);
+                for (int c0 = 0; c0 < na; c0 += 64 * nw) {
+                    const int ei = c0 + lane * nw + wave;
+                    const bool ev = ei < na;
+                    const int hs_l = ev ? (int)alist[ei] : 0;
+                    const uint32_t co_l = ev ? hco[hs_l] : 0u;
+                    const int n_l = (int)(co_l & 0xFFFFu);
+                    unsigned long long big = ballot64(ev && n_l > 16);
+                    unsigned long long sm = ballot64(ev && n_l <= 16);
+                    while (big) {
+                        const int b = __builtin_amdgcn_readfirstlane(__ffsll((long long)big) - 1);
+                        big &= big - 1ull;
+                        const uint32_t co = (uint32_t)__builtin_amdgcn_readlane((int)co_l, b);
                         const int n = (int)(co & 0xFFFFu);
                         uint16_t *m = memb + ((int)(co >> 16) - n);
-                        const int first = (int)hkey[h0 + b];
-                        if (n <= 64) collide_cell_wave<T>(cur, m, slot, n, first, k, lane);
+                        if (n <= 64) collide_cell_wave<T>(cur, m, slot, n, k, lane);
                         else if (lane == 0) collide_cell_serial<T>(cur, m, n, k);
                     }
+#ifdef CLOTHHIP_CELL_STAMPS
+                    TSTAMP(10)
+#endif
+                    while (sm) {                                  // up to four small cells per pass
+                        int hs = -1;
+#pragma unroll
+                        for (int g = 0; g < 4; g++) {
+                            if (sm) {
+                                const int b = __builtin_amdgcn_readfirstlane(__ffsll((long long)sm) - 1);
+                                sm &= sm - 1ull;
+                                const int v = __builtin_amdgcn_readlane(hs_l, b);
+                                hs = (lane >> 4) == g ? v : hs;
+                            }
+                        }
+                        collide_cells_group16<T>(cur, memb, slot, hco, hs, k, lane);
+                    }
+#ifdef CLOTHHIP_CELL_STAMPS
+                    TSTAMP(11)
+#endif
                 }
             }
             __syncthreads();
             TSTAMP(6)
             for (int h = tid; h < HT; h += NT) { hkey[h] = KEY_EMPTY; hco[h] = 0; }     // ready for the next substep
+            if (tid == 0) misc[2] = 0;
         } else {
             __syncthreads();
         }
@@ -682,7 +796,10 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                     // sequential sweep, ~3 levels per pass instead of 1.
                     // A lane streams its own sub-sequence of the fixed-width level table (levels = res mod GR) from L2,
                     // two entries ahead. Empty slots hold ptA == ptB == 0, which can never stretch (len2 == 0).
-                    const int lsh = A.lvw_shift, lvw = 1 << lsh, GR = 64 >> lsh;   // lvw is a power of two
+                    // Few flagged levels: most passes find nothing to correct, so the narrow table (same springs, levels cut
+                    // to width <= 8) lets a pass look at 8 levels instead of 64/lvw.
+                    const bool narrow = TAB >= 1 && A.n_levels8 > 0 && misc[1] <= A.narrow_thresh && !(pm & PH_NOSKIP);
+                    const int lsh = narrow ? 3 : A.lvw_shift, lvw = 1 << lsh, GR = 64 >> lsh;   // lvw is a power of two
                     const int res = lane >> lsh;
                     DevConsts<T> kl = k;                         // spring-test constants pinned in VGPRs
                     asm volatile("" : "+v"(kl.c11), "+v"(kl.tear_thresh));
@@ -694,34 +811,58 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                         // Every pass re-issues the loads of the NEXT entry unconditionally (same address while the lane
                         // has not consumed), so no loaded value is touched before the following pass.
                         const int ZE = A.S;                      // index of a zero entry (Spad > S, zero filled)
-                        int p0 = (int)loff[myL] + sl; p0 = p0 < (int)loff[myL + 1] ? p0 : ZE;
-                        int pn = (int)loff[myL + GR] + sl; pn = pn < (int)loff[myL + GR + 1] ? pn : ZE;
+                        const uint16_t *loffD = narrow ? reinterpret_cast<const uint16_t *>(smem + lay.off8) : loff;
+                        const int nLD = narrow ? A.n_levels8 : nL;
+                        int p0 = (int)loffD[myL] + sl; p0 = p0 < (int)loffD[myL + 1] ? p0 : ZE;
+                        int pn = (int)loffD[myL + GR] + sl; pn = pn < (int)loffD[myL + GR + 1] ? pn : ZE;
                         uint32_t ec = ent[p0]; T rc = rest[p0];
                         uint32_t e1 = ent[pn]; T r1 = rest[pn];
-                        int olo = (int)loff[myL + 2 * GR], ohi = (int)loff[myL + 2 * GR + 1];
+                        int olo = (int)loffD[myL + 2 * GR], ohi = (int)loffD[myL + 2 * GR + 1];
                         Pt<T> PA = cur[ec & 0xFFFFu], PB = cur[ec >> 16];
                         int L = 0;
-                        while (L < nL) {
+                        while (L < nLD) {
                             const int grp = myL - L;             // 0..GR-1: position of my level inside this pass
                             const int a = (int)(ec & 0xFFFFu), b = (int)(ec >> 16);
                             const uint32_t ca = w_cnt(PA.w), cb = w_cnt(PB.w);
                             const T dx = PA.x - PB.x, dy = PA.y - PB.y, dz = PA.z - PB.z;
                             const T len2 = dx * dx + dy * dy + dz * dz;
                             const T t11 = rc * kl.c11, tt = rc * kl.tear_thresh;
-                            const T tmin = t11 < tt ? t11 : tt;
-                            bool trig = false, tearl = false;
-                            T len = (T)0;
-                            if (!(ca != 0 && cb != 0) && (len2 > tmin * tmin * ((T)1 - filt_slack<T>()))) {
+                            bool trig, tearl;
+                            T len;
+                            if constexpr (sizeof(T) == 4) {      // one v_sqrt: cheaper than a branch around it
                                 len = dev_sqrt<T>(len2);                                        // :270
-                                tearl = len > tt;                                               // :272
-                                trig = len > t11;                                               // :275
+                                const bool live = !(ca != 0 && cb != 0);                        // :268
+                                tearl = live && len > tt;                                       // :272
+                                trig = live && len > t11;                                       // :275
+                            } else {
+                                const T tmin = t11 < tt ? t11 : tt;
+                                trig = false; tearl = false; len = (T)0;
+                                if (!(ca != 0 && cb != 0) && (len2 > tmin * tmin * ((T)1 - filt_slack<T>()))) {
+                                    len = dev_sqrt<T>(len2);
+                                    tearl = len > tt;
+                                    trig = len > t11;
+                                }
                             }
-                            const unsigned long long tb = __ballot(trig);
+                            const unsigned long long tb = ballot64(trig);
                             // groups sit in lane ranges by residue class; rotate so that bit order == level order
                             const int rot = (L & (GR - 1)) << lsh;
                             const unsigned long long tr = rot ? ((tb >> rot) | (tb << (64 - rot))) : tb;
                             const int g = tr ? (__ffsll((long long)tr) - 1) >> lsh : GR;        // first correcting level of the pass
-                            if (trig && grp == g) {
+                            const bool commit = trig && grp == g;
+                            if (tearl && grp <= g) tear = 1;
+                            const int adv = g < GR ? g + 1 : GR;
+                            L += adv;
+                            st_levels += adv; st_trig += g < GR ? 1 : 0;
+                            // consume (branch-free): lanes whose level is done move on to their next level; the
+                            // stream loads of the pass after next go out before this pass's writes
+                            const bool cons = myL < L;
+                            myL = cons ? myL + GR : myL;
+                            const uint32_t ecn = cons ? e1 : ec;
+                            rc = cons ? r1 : rc;
+                            if (cons) { int q = olo + sl; pn = q < ohi ? q : ZE; }
+                            e1 = ent[pn]; r1 = rest[pn];
+                            olo = (int)loffD[myL + 2 * GR]; ohi = (int)loffD[myL + 2 * GR + 1];
+                            if (commit) {
                                 const T ux = dev_div<T>(dx, len), uy = dev_div<T>(dy, len), uz = dev_div<T>(dz, len);   // :276-278
                                 const T extra = len - t11;                                      // :279
                                 const T wa = ca != 0 ? (T)0 : (cb != 0 ? (T)1 : (T)0.5);
@@ -730,21 +871,11 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                                 if (ca == 0) cur[a] = Pt<T>{PA.x - ux * ea, PA.y - uy * ea, PA.z - uz * ea, PA.w};
                                 if (cb == 0) cur[b] = Pt<T>{PB.x + ux * eb, PB.y + uy * eb, PB.z + uz * eb, PB.w};
                             }
-                            const int adv = g < GR ? g + 1 : GR;
-                            L += adv;
-                            // consume (branch-free): lanes whose level is done move on to their next level
-                            const bool cons = myL < L;
-                            myL = cons ? myL + GR : myL;
-                            ec = cons ? e1 : ec; rc = cons ? r1 : rc;
-                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            ec = ecn;
+                            // same-wave LDS operations execute in program order: the reads below see the writes
+                            // above without waiting for them; the barrier only pins the compiler's ordering
                             __builtin_amdgcn_wave_barrier();
-                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                             PA = cur[ec & 0xFFFFu]; PB = cur[ec >> 16];      // next pass's particles (after this pass's writes)
-                            if (cons) { int q = olo + sl; pn = q < ohi ? q : ZE; }
-                            e1 = ent[pn]; r1 = rest[pn];
-                            olo = (int)loff[myL + 2 * GR]; ohi = (int)loff[myL + 2 * GR + 1];
-                            if (tearl && grp <= g) tear = 1;
-                            st_levels += adv; st_trig += g < GR ? 1 : 0;
                         }
                     } else {
                         // tables not resident in LDS (large grids): padded fixed-width table streamed from L2
@@ -769,7 +900,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                                 tearl = len > tt;
                                 trig = len > t11;
                             }
-                            const unsigned long long tb = __ballot(trig);
+                            const unsigned long long tb = ballot64(trig);
                             const int rot = (L & (GR - 1)) << lsh;
                             const unsigned long long tr = rot ? ((tb >> rot) | (tb << (64 - rot))) : tb;
                             const int g = tr ? (__ffsll((long long)tr) - 1) >> lsh : GR;
@@ -811,7 +942,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                         want |= (bits & (nb >= 64 ? ~0ull : ((1ull << nb) - 1ull))) != 0ull;
                         if (lvflag[Lm]) { want = true; lvflag[Lm] = 0; }        // pending mark from an earlier correction
                     }
-                    unsigned long long need = __ballot(want);
+                    unsigned long long need = ballot64(want);
                     int pj = -1;                                 // level whose springs are already fetched into (pen, pr)
                     uint32_t pen = 0u; T pr = (T)0;
                     while (need) {
@@ -834,7 +965,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                         int moved = 0;
                         if (on) moved = strain_spring<T>(cur, en, r, k, tear);
                         st_levels++;
-                        unsigned long long mm = __ballot(moved != 0);
+                        unsigned long long mm = ballot64(moved != 0);
                         st_trig += mm ? 1 : 0;
 #ifdef CLOTHHIP_SWEEP_STAMPS
                         if (timing) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts1)::"memory"); tph[mm ? 11 : 10] += ts1 - ts0; }

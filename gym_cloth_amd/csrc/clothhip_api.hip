@@ -51,7 +51,8 @@ struct clothhip_handle {
     int32_t *d_tear = nullptr, *d_exec = nullptr, *d_ngrab = nullptr, *d_stats = nullptr;
     ClothSchedule *d_sched = nullptr, *h_sched = nullptr;   // h_sched: pinned staging
     uint32_t *d_gather = nullptr, *d_lv_ent = nullptr;
-    uint16_t *d_lv_off = nullptr, *d_pt_lev = nullptr;
+    uint16_t *d_lv_off = nullptr, *d_lv_off8 = nullptr, *d_pt_lev = nullptr;
+    int n_levels8 = 0, narrow_thresh = 160;
     uint32_t *d_lv_pad = nullptr;
     void *d_rest_pad = nullptr;
     int lvw = 16, npad = 0, rest_pad_stride = 0;
@@ -156,7 +157,7 @@ static void free_handle(clothhip_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_pos, h->d_prev, h->d_rest, h->d_cnt, h->d_active, h->d_tear, h->d_exec, h->d_ngrab, h->d_stats,
-                    h->d_sched, h->d_gather, h->d_lv_ent, h->d_lv_off, h->d_pt_lev, h->d_lv_pad, h->d_rest_pad, h->d_levels, h->d_xy, h->d_radius, h->d_cov, h->d_vinv, h->d_oob};
+                    h->d_sched, h->d_gather, h->d_lv_ent, h->d_lv_off, h->d_lv_off8, h->d_pt_lev, h->d_lv_pad, h->d_rest_pad, h->d_levels, h->d_xy, h->d_radius, h->d_cov, h->d_vinv, h->d_oob};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->h_sched) (void)hipHostFree(h->h_sched);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -193,7 +194,7 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
     h->HT = 64; h->ht_bits = 0;
     while (h->HT <= h->P + h->P / 2) h->HT <<= 1;
     while ((1 << h->ht_bits) < h->HT) h->ht_bits++;
-    h->lvw_shift = h->lv.max_width <= 16 ? 4 : (h->lv.max_width <= 32 ? 5 : 6);
+    h->lvw_shift = h->lv.max_width <= 8 ? 3 : (h->lv.max_width <= 16 ? 4 : (h->lv.max_width <= 32 ? 5 : 6));
     if (h->lv.max_width > 64) { delete h; return fail(CLOTHHIP_EINVAL, "level width %d > 64", h->lv.max_width); }
     if (const char *pmk = getenv("CLOTHHIP_DEBUG_PHASES")) h->phase_mask = atoi(pmk);
     std::vector<uint32_t> gather = build_gather(h->topo, h->lv, h->Ppad);
@@ -242,6 +243,14 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
     {
         std::vector<uint16_t> off16(h->lv.off.begin(), h->lv.off.end());
         HC(hipMemcpy(h->d_lv_off, off16.data(), off16.size() * 2, hipMemcpyHostToDevice));
+        // narrow table: every level cut into consecutive sub-levels of at most 8 springs (still antichains, same order)
+        std::vector<uint16_t> off8;
+        for (int L = 0; L < h->lv.n_levels; L++)
+            for (int p = h->lv.off[L]; p < h->lv.off[L + 1]; p += 8) off8.push_back((uint16_t)p);
+        off8.push_back((uint16_t)h->lv.off[h->lv.n_levels]);
+        h->n_levels8 = h->lv.max_width > 8 ? (int)off8.size() - 1 : 0;     // width <= 8 already: the main table is narrow
+        HC(hipMalloc(&h->d_lv_off8, off8.size() * 2));
+        HC(hipMemcpy(h->d_lv_off8, off8.data(), off8.size() * 2, hipMemcpyHostToDevice));
     }
     {   // dependency level of every incident spring of every point (for the exact pending-level marking)
         std::vector<int> lvl_of_pos(h->S);
@@ -267,6 +276,7 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
         HC(hipMemset(h->d_rest_pad, 0, E * (size_t)h->npad * h->tsz));
     }
     if (const char *dt = getenv("CLOTHHIP_DEBUG_DENSE")) h->dense_thresh = atoi(dt);
+    if (const char *dt = getenv("CLOTHHIP_DEBUG_NARROW")) h->narrow_thresh = atoi(dt);
     HC(hipMemset(h->d_rest, 0, E * h->Spad * h->tsz));
     if (!levels.empty()) HC(hipMemcpy(h->d_levels, levels.data(), levels.size() * 8, hipMemcpyHostToDevice));
     HC(hipMemset(h->d_exec, 0, E * 4));
@@ -279,10 +289,10 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
         const int tmax = h->nt == 256 ? 2 : ((h->ppt == 3 || h->nt == 512) ? 1 : 0);
         h->tab = 0;
         for (int t = tmax; t >= 1; t--)
-            if (LdsLayout(tsz, h->Ppad, h->Spad, h->lv.n_levels, h->HT, t).total <= budget) { h->tab = t; break; }
+            if (LdsLayout(tsz, h->Ppad, h->Spad, h->lv.n_levels, h->n_levels8, h->HT, t).total <= budget) { h->tab = t; break; }
         if (const char *t = getenv("CLOTHHIP_DEBUG_TAB_LDS")) h->tab = std::min(h->tab, atoi(t));
         h->rest_reg = (h->nt == 256 && precision == CLOTHHIP_F32 && h->tab == 2);
-        h->lds_bytes = LdsLayout(tsz, h->Ppad, h->Spad, h->lv.n_levels, h->HT, h->tab).total;
+        h->lds_bytes = LdsLayout(tsz, h->Ppad, h->Spad, h->lv.n_levels, h->n_levels8, h->HT, h->tab).total;
         if (h->lds_bytes > 160 * 1024) { free_handle(h); return fail(CLOTHHIP_EINVAL, "n_side %d needs %d B of LDS (> 160 KiB)", h->N, h->lds_bytes); }
         const void *fn = stepper_fn(h);
         if (!fn) { free_handle(h); return fail(CLOTHHIP_EINVAL, "no stepper variant for n_side %d", h->N); }
@@ -507,7 +517,7 @@ template <typename T> static StepArgs<T> make_args(clothhip_handle *h, const Clo
     StepArgs<T> a;
     a.pos = (T *)h->d_pos; a.prev = (T *)h->d_prev; a.cnt = h->d_cnt; a.rest = (const T *)h->d_rest;
     a.tear = h->d_tear; a.executed = h->d_exec; a.stats = h->d_stats; a.sched = d_sched;
-    a.gather = h->d_gather; a.lv_ent = h->d_lv_ent; a.lv_off = h->d_lv_off; a.pt_lev = h->d_pt_lev; a.dense_thresh = h->dense_thresh;
+    a.gather = h->d_gather; a.lv_ent = h->d_lv_ent; a.lv_off = h->d_lv_off; a.lv_off8 = h->d_lv_off8; a.n_levels8 = h->n_levels8; a.narrow_thresh = h->narrow_thresh; a.pt_lev = h->d_pt_lev; a.dense_thresh = h->dense_thresh;
     a.lv_pad = h->d_lv_pad; a.rest_pad = (const T *)h->d_rest_pad; a.rest_pad_stride = h->rest_pad_stride; a.lvw = h->lvw;
     a.n_levels = h->lv.n_levels;
     a.N = h->N; a.P = h->P; a.Ppad = h->Ppad; a.S = h->S; a.Spad = h->Spad;
