@@ -64,6 +64,7 @@ template <typename T> struct StepArgs {
     int32_t rest_stride;     // 0: one shared table
     int32_t dense_thresh;    // pre-pass flagged levels above which the sweep stops tracking and runs every level
     int32_t n_levels8;       // 0: no narrow table
+    int32_t cell_copy;       // 1: LDS holds a cell-ordered copy of the particle records for the collision pre-check
     int32_t narrow_thresh;   // dense sweep: at most this many flagged levels -> narrow table (8 levels per pass)
     int32_t phase_mask;      // debug/ablation: bit0 hooke+verlet, bit1 collide, bit2 plane, bit3 strain, bit4 no-skip
     DevConsts<T> k;
@@ -108,6 +109,16 @@ __device__ __forceinline__ float lane_pull(float v, int src) { return __int_as_f
 __device__ __forceinline__ double lane_pull(double v, int src) {
     return __hiloint2double(__builtin_amdgcn_ds_bpermute(src << 2, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(src << 2, __double2loint(v)));
 }
+// inclusive +scan over the 64 lanes of the wave (DPP: row_shr 1,2,4,8, then row_bcast 15 and 31)
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true);     // lane 15 of rows 0,2 -> rows 1,3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true);     // lane 31 -> rows 2,3
+    return v;
+}
 // relative slack of the conservative "could this comparison against a sqrt be true" pre-filters
 template <typename T> __device__ __forceinline__ T filt_slack();
 template <> __device__ __forceinline__ double filt_slack<double>() { return 1e-9; }
@@ -142,8 +153,8 @@ template <typename T> __device__ __forceinline__ uint32_t cell_key(const DevCons
 // LDS carve-up (dynamic shared memory), all offsets in bytes, 16-byte aligned.
 // tab: 0 = static tables stay in global memory, 1 = ent/rest/off in LDS, 2 = + per-point level table
 struct LdsLayout {
-    int cur, ent, rest, off, off8, plev, flag, abits, hkey, hco, memb, slot, misc, alist, total;
-    __host__ __device__ LdsLayout(int tsz, int Ppad, int Spad, int nL, int nL8, int HT, int tab) {
+    int cur, ent, rest, off, off8, plev, flag, abits, hkey, hco, memb, slot, misc, alist, olist, cpos, total;
+    __host__ __device__ LdsLayout(int tsz, int Ppad, int Spad, int nL, int nL8, int HT, int tab, int cp) {
         int o = 0;
         auto take = [&](int bytes) { int r = o; o += (bytes + 15) / 16 * 16; return r; };
         cur = take(4 * Ppad * tsz);
@@ -159,7 +170,9 @@ struct LdsLayout {
         memb = take(Ppad * 2);
         slot = take(Ppad * 2);
         misc = take(128);            // flags and scan scratch
-        alist = take(Ppad);           // hash slots of the cells that have a seed this substep (<= P/2 entries, u16)
+        olist = take(2 * Ppad);       // u16 hash slots: occupied cells from the front, cells with a seed from the back
+        alist = olist;                //   (an active cell has >= 2 members, so #occupied + #active <= P)
+        cpos = take(cp ? 4 * Ppad * tsz : 0);   // particle records in cell (CSR) order for the pre-check
         total = o;
     }
 };
@@ -265,22 +278,23 @@ __device__ __forceinline__ void collide_cell_wave(Pt<T> *cur, uint16_t *m, const
     if (moved) cur[i] = Pt<T>{x, y, z, me.w};
 }
 
-// Four SMALL cells (<= 16 members each) at once, one per 16-lane group of the wave; same exact Gauss-Seidel
-// semantics as collide_cell_wave, with group-local broadcasts through ds_bpermute. `hs` = this lane's group's hash
-// slot (or -1: no cell for this group).
-template <typename T>
-__device__ __forceinline__ void collide_cells_group16(Pt<T> *cur, uint16_t *memb, const uint16_t *slot,
+// 64/GSZ cells of at most GSZ (16 or 32) members each at once, one per GSZ-lane group of the wave; same exact
+// Gauss-Seidel semantics as collide_cell_wave, with group-local broadcasts through ds_bpermute. `hs` = this lane's
+// group's hash slot (or -1: no cell for this group).
+template <typename T, int GSZ>
+__device__ __forceinline__ void collide_cells_group(Pt<T> *cur, uint16_t *memb, const uint16_t *slot,
                                                       const uint32_t *hco, int hs, const DevConsts<T> &k, int lane) {
-    const int sub = lane & 15, base = lane & ~15, gsh = base;            // my group's lanes are [base, base+16)
+    const int sub = lane & (GSZ - 1), base = lane & ~(GSZ - 1), gsh = base;   // my group's lanes are [base, base+GSZ)
+    constexpr unsigned long long GM = GSZ == 32 ? 0xFFFFFFFFull : 0xFFFFull;
     const bool gvalid = hs >= 0;
     const uint32_t co = gvalid ? hco[hs] : 0u;
     const int n = (int)(co & 0xFFFFu);
-    const int start = (int)(co >> 16) - n;
+    const int start = (int)(co >> 16);
     const bool in = gvalid && sub < n;
     const int mine = in ? (int)memb[start + sub] : 0x7fff;
     int rank = 0;
 #pragma unroll 4
-    for (int t = 0; t < 16; t++) rank += (lane_pull(mine, base + t) < mine) ? 1 : 0;
+    for (int t = 0; t < GSZ; t++) rank += (lane_pull(mine, base + t) < mine) ? 1 : 0;
     // members get ranks 0..n-1 (ascending index); the other lanes of the group keep their own position (>= n)
     const int i = __builtin_amdgcn_ds_permute((base + (in ? rank : sub)) << 2, in ? mine : 0);
     const bool ins = gvalid && sub < n;                                  // after the permutation lane sub < n holds rank sub
@@ -288,7 +302,7 @@ __device__ __forceinline__ void collide_cells_group16(Pt<T> *cur, uint16_t *memb
     T x = me.x, y = me.y, z = me.z;
     const bool free_ = ins && w_cnt(me.w) == 0;
     const bool want = free_ && (slot[ins ? i : 0] & 0x8000u) != 0;
-    unsigned int todo = (unsigned int)((ballot64(want) >> gsh) & 0xFFFFull);          // my group's seeds
+    unsigned int todo = (unsigned int)((ballot64(want) >> gsh) & GM);          // my group's seeds
     const T thr2 = k.thresh * k.thresh * ((T)1 + filt_slack<T>());
     const T cfac = (T)1 + (T)2 / k.sim_steps;
     const T thr2c = thr2 * cfac * cfac;
@@ -308,7 +322,7 @@ __device__ __forceinline__ void collide_cells_group16(Pt<T> *cur, uint16_t *memb
             const T factor = dev_div<T>(k.thresh - dist, dist);                         // :331
             fx = dx * factor; fy = dy * factor; fz = dz * factor;
         }
-        unsigned int hm = (unsigned int)((ballot64(hit) >> gsh) & 0xFFFFull);
+        unsigned int hm = (unsigned int)((ballot64(hit) >> gsh) & GM);
         if (!__any(hm != 0u)) continue;
         T tx = (T)0, ty = (T)0, tz = (T)0;
         int nh = 0;
@@ -328,7 +342,7 @@ __device__ __forceinline__ void collide_cells_group16(Pt<T> *cur, uint16_t *memb
         }
         // my group's `a` moved: its later neighbours within the candidate radius must look too
         const bool wake = act && nh != 0 && free_ && sub > a && !(d2 > thr2c);
-        todo |= (unsigned int)((ballot64(wake) >> gsh) & 0xFFFFull);
+        todo |= (unsigned int)((ballot64(wake) >> gsh) & GM);
     }
     if (moved) cur[i] = Pt<T>{x, y, z, me.w};
 }
@@ -387,15 +401,17 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
         return;
     }
     const int P = A.P, Ppad = A.Ppad, nL = A.n_levels, HT = A.HT;
-    const LdsLayout lay((int)sizeof(T), Ppad, A.Spad, nL, A.n_levels8, HT, TAB);
+    const LdsLayout lay((int)sizeof(T), Ppad, A.Spad, nL, A.n_levels8, HT, TAB, A.cell_copy);
     Pt<T> *cur = reinterpret_cast<Pt<T> *>(smem + lay.cur);
     uint8_t *lvflag = smem + lay.flag;
     uint32_t *hkey = reinterpret_cast<uint32_t *>(smem + lay.hkey);
     uint32_t *hco = reinterpret_cast<uint32_t *>(smem + lay.hco);
     uint16_t *memb = reinterpret_cast<uint16_t *>(smem + lay.memb);
     uint16_t *slot = reinterpret_cast<uint16_t *>(smem + lay.slot);
-    int *misc = reinterpret_cast<int *>(smem + lay.misc);   // [0] tear, [1] #levels flagged by the pre-pass, [2] #active cells, [8..] scan
-    uint16_t *alist = reinterpret_cast<uint16_t *>(smem + lay.alist);
+    int *misc = reinterpret_cast<int *>(smem + lay.misc);   // [0] tear, [1] #levels flagged by the pre-pass, [2] #active cells, [3] #occupied cells, [4] member cursor
+    uint16_t *olist = reinterpret_cast<uint16_t *>(smem + lay.olist);
+    uint16_t *alist_end = olist + (Ppad - 1);            // active list grows downwards: entry k = alist_end[-k]
+    Pt<T> *cpos = reinterpret_cast<Pt<T> *>(smem + lay.cpos);
     const DevConsts<T> &k = A.k;
     const T *g_rest = A.rest + (size_t)e * A.rest_stride;
     const uint32_t *ent = TAB >= 1 ? reinterpret_cast<const uint32_t *>(smem + lay.ent) : A.lv_ent;
@@ -439,7 +455,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
         for (int h = tid; h < HT; h += NT) { hkey[h] = KEY_EMPTY; hco[h] = 0; }
         for (int i = tid; i < nL + 64; i += NT) lvflag[i] = 0;
         for (int i = tid; i < (A.Spad / 64 + 2) * 2; i += NT) reinterpret_cast<uint32_t *>(smem + lay.abits)[i] = 0u;
-        if (tid == 0) { misc[0] = A.tear[e]; misc[1] = 0; misc[2] = 0; }
+        if (tid == 0) { misc[0] = A.tear[e]; misc[1] = 0; misc[2] = 0; misc[3] = 0; misc[4] = 0; }
     }
     __syncthreads();
 
@@ -542,119 +558,150 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
         }
 
         TSTAMP(1)
-        // ---- spatial map (cloth.pyx:298-311): hash table in LDS keyed by the exact cell key, CSR member
-        // lists; the order inside a cell is restored to ascending point index by the cell's wave.
+        // ---- spatial map (cloth.pyx:298-311): hash table in LDS keyed by the exact cell key + a list of the occupied
+        // slots; members of a cell are stored contiguously (CSR); ascending point index is restored by the sweep.
         if (pm & PH_COLLIDE) {
-            Pt<T> cme[PPT];
-            uint32_t ckey[PPT], ch[PPT];
-#pragma unroll
-            for (int q = 0; q < PPT; q++) {                 // batched: the PPT particles' LDS traffic overlaps
-                const int i = tid + q * NT;
-                cme[q] = cur[i < P ? i : 0];                                                      // own slot: no hazard
-                ckey[q] = cell_key<T>(k, cme[q].x, cme[q].y, cme[q].z);
-                ch[q] = (ckey[q] * 2654435761u) >> (32 - A.ht_bits);
-            }
+            uint32_t ch[PPT], rank[PPT];
             {
-                bool pend[PPT];
+                uint32_t ckey[PPT];
+                bool pend[PPT], made[PPT];
                 bool anyp = false;
 #pragma unroll
-                for (int q = 0; q < PPT; q++) { pend[q] = tid + q * NT < P; anyp |= pend[q]; }
+                for (int q = 0; q < PPT; q++) {             // batched: the PPT particles' LDS traffic overlaps
+                    const int i = tid + q * NT;
+                    const Pt<T> c = cur[i < P ? i : 0];                                           // own slot: no hazard
+                    ckey[q] = cell_key<T>(k, c.x, c.y, c.z);
+                    ch[q] = (ckey[q] * 2654435761u) >> (32 - A.ht_bits);
+                    pend[q] = i < P; made[q] = false; anyp |= pend[q];
+                }
                 while (anyp) {
                     anyp = false;
 #pragma unroll
                     for (int q = 0; q < PPT; q++) {
                         if (pend[q]) {
                             const uint32_t old = atomicCAS(&hkey[ch[q]], KEY_EMPTY, ckey[q]);
-                            if (old == KEY_EMPTY || old == ckey[q]) pend[q] = false;
+                            if (old == KEY_EMPTY || old == ckey[q]) { pend[q] = false; made[q] = old == KEY_EMPTY; }
                             else { ch[q] = (ch[q] + 1) & (uint32_t)(HT - 1); anyp = true; }
                         }
                     }
                 }
-            }
+                int nmade = 0;
 #pragma unroll
-            for (int q = 0; q < PPT; q++) {
-                const int i = tid + q * NT;
-                if (i < P) { slot[i] = (uint16_t)ch[q]; atomicAdd(&hco[ch[q]], 1u); }
+                for (int q = 0; q < PPT; q++) {
+                    const int i = tid + q * NT;
+                    rank[q] = 0;
+                    if (i < P) { slot[i] = (uint16_t)ch[q]; rank[q] = atomicAdd(&hco[ch[q]], 1u); }   // my place in the cell
+                    nmade += made[q] ? 1 : 0;
+                }
+                // whoever created a slot lists it: one LDS atomic per wave
+                const int inc = wave_incl_scan(nmade);
+                const int tot = __builtin_amdgcn_readlane(inc, 63);
+                if (tot) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&misc[3], tot);
+                    int o = __builtin_amdgcn_readfirstlane(base) + inc - nmade;
+#pragma unroll
+                    for (int q = 0; q < PPT; q++)
+                        if (made[q]) olist[o++] = (uint16_t)ch[q];
+                }
             }
             __syncthreads();
             TSTAMP(2)
-            // exclusive prefix sum of the slot counts -> fill cursors (each thread owns HT/NT consecutive slots)
-            const int per = (HT + NT - 1) / NT;
-            uint32_t loc = 0;
-            for (int q = 0; q < per; q++) { const int h = tid * per + q; loc += h < HT ? hco[h] : 0u; }
-            uint32_t inc = loc;
-            for (int o = 1; o < 64; o <<= 1) { uint32_t v = __shfl_up(inc, o); if (lane >= o) inc += v; }
-            if (lane == 63) misc[8 + (tid >> 6)] = (int)inc;
-            __syncthreads();
-            uint32_t base = inc - loc;
-            for (int w = 0; w < (tid >> 6); w++) base += (uint32_t)misc[8 + w];
-            for (int q = 0; q < per; q++) {
-                const int h = tid * per + q;
-                if (h < HT) {
-                    const uint32_t c = hco[h];
-                    hco[h] = (base << 16) | c;
-                    base += c;
-                }
+            const int nocc = __builtin_amdgcn_readfirstlane(misc[3]);
+            for (int t0 = 0; t0 < nocc; t0 += NT) {         // member range of every occupied cell (any order)
+                const int t = t0 + tid;
+                const int h = t < nocc ? (int)olist[t] : 0;
+                const int c = t < nocc ? (int)hco[h] : 0;
+                const int inc = wave_incl_scan(c);
+                int base = 0;
+                if (lane == 63) base = atomicAdd(&misc[4], inc);
+                base = __builtin_amdgcn_readlane(base, 63);
+                if (t < nocc) hco[h] = ((uint32_t)(base + inc - c) << 16) | (uint32_t)c;          // (start << 16) | count
             }
             __syncthreads();
             TSTAMP(3)
+            int cn[PPT], cstart[PPT];
+            Pt<T> cme[PPT];
+            int nmax = 0;
 #pragma unroll
             for (int q = 0; q < PPT; q++) {
                 const int i = tid + q * NT;
+                const uint32_t co = hco[ch[q]];
+                cme[q] = cur[i < P ? i : 0];
+                cstart[q] = (int)(co >> 16);
                 if (i < P) {
-                    const uint32_t old = atomicAdd(&hco[ch[q]], 1u << 16);  // afterwards cursor = END of the cell
-                    memb[old >> 16] = (uint16_t)i;
+                    memb[cstart[q] + (int)rank[q]] = (uint16_t)i;
+                    if (A.cell_copy) cpos[cstart[q] + (int)rank[q]] = Pt<T>{cme[q].x, cme[q].y, cme[q].z, w_make<T>((uint32_t)i)};
                 }
+                const bool use = i < P && w_cnt(cme[q].w) == 0;
+                cn[q] = use ? (int)(co & 0xFFFFu) : 0;
+                if (cn[q] < 2) cn[q] = 0;
+                nmax = cn[q] > nmax ? cn[q] : nmax;
             }
             __syncthreads();
             TSTAMP(4)
             // ---- self-collision (cloth.pyx:313-343) ------------------------------------------------------
-            // (1) every unpinned particle, in parallel: does it have a hit (a same-cell member within 2*thickness) at
-            //     the CURRENT positions? Those are the seeds of the exact sweep (flag bit of its slot word); a cell
-            //     with a seed is active (its key word is recycled to hold the smallest seed index).
-            const T thr2 = k.thresh * k.thresh * ((T)1 + filt_slack<T>());
+            // (1) seeds: every unpinned particle, in parallel: does it have a hit (a same-cell member within
+            //     2*thickness) at the CURRENT positions? A seed gets the flag bit of its slot word; the first seed of
+            //     a cell (whoever wins) puts the cell on the active list. Conservative by the filter slack; the sweep
+            //     re-tests exactly. With the cell-ordered record copy a pair costs ONE LDS read.
             {
-                int cn[PPT], cstart[PPT];
-                int nmax = 0;
-#pragma unroll
-                for (int q = 0; q < PPT; q++) {
-                    const uint32_t co = hco[ch[q]];
-                    const bool use = (tid + q * NT < P) && w_cnt(cme[q].w) == 0;
-                    cn[q] = use ? (int)(co & 0xFFFFu) : 0;
-                    if (cn[q] < 2) cn[q] = 0;
-                    cstart[q] = (int)(co >> 16) - (int)(co & 0xFFFFu);
-                    nmax = cn[q] > nmax ? cn[q] : nmax;
-                }
+                const T thr2 = k.thresh * k.thresh * ((T)1 + filt_slack<T>());
                 bool hit[PPT];
 #pragma unroll
                 for (int q = 0; q < PPT; q++) hit[q] = false;
-                for (int b = 0; b < nmax; b += 4) {          // 4 members x PPT particles per trip: their LDS reads overlap
-                    int jj[PPT][4];
+#ifdef CLOTHHIP_EXP_NOPRE
+                nmax = 0;
+#endif
+                if (A.cell_copy) {
+                    constexpr int CU = 2;
+                    // no clamping: a read past the cell's range (another cell's record, or past the array: LDS returns
+                    // zeros there) is masked out by the member count
+                    const Pt<T> *cb[PPT];
 #pragma unroll
-                    for (int q = 0; q < PPT; q++)
+                    for (int q = 0; q < PPT; q++) cb[q] = cpos + cstart[q];
+                    for (int b = 0; b < nmax; b += CU) {     // CU members x PPT particles per trip: their LDS reads overlap
+                        Pt<T> o[PPT][CU];
 #pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            const int bb = b + u < cn[q] ? b + u : 0;               // clamped: always a valid read
-                            jj[q][u] = (int)memb[cn[q] ? cstart[q] + bb : 0];
-                        }
+                        for (int q = 0; q < PPT; q++)
 #pragma unroll
-                    for (int q = 0; q < PPT; q++)
+                            for (int u = 0; u < CU; u++) o[q][u] = cb[q][b + u];
 #pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            const Pt<T> o = cur[jj[q][u]];
-                            const T dx = cme[q].x - o.x, dy = cme[q].y - o.y, dz = cme[q].z - o.z;
-                            const T d2 = dx * dx + dy * dy + dz * dz;
-                            const bool other = (b + u < cn[q]) && jj[q][u] != tid + q * NT;
-                            hit[q] |= other && !(d2 > thr2);
-                        }
+                        for (int q = 0; q < PPT; q++)
+#pragma unroll
+                            for (int u = 0; u < CU; u++) {                              // branch-free on purpose (& not &&)
+                                const T dx = cme[q].x - o[q][u].x, dy = cme[q].y - o[q][u].y, dz = cme[q].z - o[q][u].z;
+                                const bool other = (b + u < cn[q]) & ((int)w_cnt(o[q][u].w) != tid + q * NT);
+                                hit[q] |= other & !(dx * dx + dy * dy + dz * dz > thr2);
+                            }
+                    }
+                } else {
+                    for (int b = 0; b < nmax; b += 4) {
+                        int jj[PPT][4];
+#pragma unroll
+                        for (int q = 0; q < PPT; q++)
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                const int bb = b + u < cn[q] ? b + u : 0;
+                                jj[q][u] = (int)memb[cn[q] ? cstart[q] + bb : 0];
+                            }
+#pragma unroll
+                        for (int q = 0; q < PPT; q++)
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                const Pt<T> o = cur[jj[q][u]];
+                                const T dx = cme[q].x - o.x, dy = cme[q].y - o.y, dz = cme[q].z - o.z;
+                                const bool other = (b + u < cn[q]) & (jj[q][u] != tid + q * NT);
+                                hit[q] |= other & !(dx * dx + dy * dy + dz * dz > thr2);
+                            }
+                    }
                 }
 #pragma unroll
                 for (int q = 0; q < PPT; q++) {
                     if (hit[q]) {
                         slot[tid + q * NT] = (uint16_t)(ch[q] | 0x8000u);
-                        // the first seed of a cell (whoever wins) puts the cell on the active list
                         if (atomicMin(&hkey[ch[q]], (uint32_t)(tid + q * NT)) >= KEY_FLOOR)
-                            alist[atomicAdd(&misc[2], 1)] = (uint16_t)ch[q];
+                            alist_end[-atomicAdd(&misc[2], 1)] = (uint16_t)ch[q];
                     }
                 }
             }
@@ -662,14 +709,15 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
             TSTAMP(5)
             // (2) the active cells (those with a seed): exact Gauss-Seidel sweep. Wave w takes list entries w, w+nw, ...
             // (cells are independent: each particle sits in exactly one). Cells with <= 16 members are processed four
-            // at a time, one per 16-lane group; larger cells get the whole wave.
+            // at a time, one per 16-lane group; larger cells get the whole wave (two per wave in 32-lane groups was
+            // measured: the bpermute broadcasts cost what the pairing saves).
             {
                 const int wave = tid >> 6, nw = NT >> 6;
                 const int na = __builtin_amdgcn_readfirstlane(misc[2]);
                 for (int c0 = 0; c0 < na; c0 += 64 * nw) {
                     const int ei = c0 + lane * nw + wave;
                     const bool ev = ei < na;
-                    const int hs_l = ev ? (int)alist[ei] : 0;
+                    const int hs_l = ev ? (int)alist_end[-ei] : 0;
                     const uint32_t co_l = ev ? hco[hs_l] : 0u;
                     const int n_l = (int)(co_l & 0xFFFFu);
                     unsigned long long big = ballot64(ev && n_l > 16);
@@ -679,7 +727,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                         big &= big - 1ull;
                         const uint32_t co = (uint32_t)__builtin_amdgcn_readlane((int)co_l, b);
                         const int n = (int)(co & 0xFFFFu);
-                        uint16_t *m = memb + ((int)(co >> 16) - n);
+                        uint16_t *m = memb + (int)(co >> 16);
                         if (n <= 64) collide_cell_wave<T>(cur, m, slot, n, k, lane);
                         else if (lane == 0) collide_cell_serial<T>(cur, m, n, k);
                     }
@@ -697,7 +745,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                                 hs = (lane >> 4) == g ? v : hs;
                             }
                         }
-                        collide_cells_group16<T>(cur, memb, slot, hco, hs, k, lane);
+                        collide_cells_group<T, 16>(cur, memb, slot, hco, hs, k, lane);
                     }
 #ifdef CLOTHHIP_CELL_STAMPS
                     TSTAMP(11)
@@ -706,8 +754,8 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
             }
             __syncthreads();
             TSTAMP(6)
-            for (int h = tid; h < HT; h += NT) { hkey[h] = KEY_EMPTY; hco[h] = 0; }     // ready for the next substep
-            if (tid == 0) misc[2] = 0;
+            for (int t = tid; t < nocc; t += NT) { const int h = (int)olist[t]; hkey[h] = KEY_EMPTY; hco[h] = 0; }   // ready for the next substep
+            if (tid == 0) { misc[2] = 0; misc[3] = 0; misc[4] = 0; }
         } else {
             __syncthreads();
         }

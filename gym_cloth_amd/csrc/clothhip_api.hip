@@ -52,7 +52,7 @@ struct clothhip_handle {
     ClothSchedule *d_sched = nullptr, *h_sched = nullptr;   // h_sched: pinned staging
     uint32_t *d_gather = nullptr, *d_lv_ent = nullptr;
     uint16_t *d_lv_off = nullptr, *d_lv_off8 = nullptr, *d_pt_lev = nullptr;
-    int n_levels8 = 0, narrow_thresh = 160;
+    int n_levels8 = 0, narrow_thresh = 160, cell_copy = 0;
     uint32_t *d_lv_pad = nullptr;
     void *d_rest_pad = nullptr;
     int lvw = 16, npad = 0, rest_pad_stride = 0;
@@ -289,10 +289,13 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
         const int tmax = h->nt == 256 ? 2 : ((h->ppt == 3 || h->nt == 512) ? 1 : 0);
         h->tab = 0;
         for (int t = tmax; t >= 1; t--)
-            if (LdsLayout(tsz, h->Ppad, h->Spad, h->lv.n_levels, h->n_levels8, h->HT, t).total <= budget) { h->tab = t; break; }
+            if (LdsLayout(tsz, h->Ppad, h->Spad, h->lv.n_levels, h->n_levels8, h->HT, t, 0).total <= budget) { h->tab = t; break; }
         if (const char *t = getenv("CLOTHHIP_DEBUG_TAB_LDS")) h->tab = std::min(h->tab, atoi(t));
         h->rest_reg = (h->nt == 256 && precision == CLOTHHIP_F32 && h->tab == 2);
-        h->lds_bytes = LdsLayout(tsz, h->Ppad, h->Spad, h->lv.n_levels, h->n_levels8, h->HT, h->tab).total;
+        // the cell-ordered record copy for the collision pre-check is taken only if it costs no table tier
+        h->cell_copy = LdsLayout(tsz, h->Ppad, h->Spad, h->lv.n_levels, h->n_levels8, h->HT, h->tab, 1).total <= budget ? 1 : 0;
+        if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) h->cell_copy = h->cell_copy && atoi(t);
+        h->lds_bytes = LdsLayout(tsz, h->Ppad, h->Spad, h->lv.n_levels, h->n_levels8, h->HT, h->tab, h->cell_copy).total;
         if (h->lds_bytes > 160 * 1024) { free_handle(h); return fail(CLOTHHIP_EINVAL, "n_side %d needs %d B of LDS (> 160 KiB)", h->N, h->lds_bytes); }
         const void *fn = stepper_fn(h);
         if (!fn) { free_handle(h); return fail(CLOTHHIP_EINVAL, "no stepper variant for n_side %d", h->N); }
@@ -517,7 +520,7 @@ template <typename T> static StepArgs<T> make_args(clothhip_handle *h, const Clo
     StepArgs<T> a;
     a.pos = (T *)h->d_pos; a.prev = (T *)h->d_prev; a.cnt = h->d_cnt; a.rest = (const T *)h->d_rest;
     a.tear = h->d_tear; a.executed = h->d_exec; a.stats = h->d_stats; a.sched = d_sched;
-    a.gather = h->d_gather; a.lv_ent = h->d_lv_ent; a.lv_off = h->d_lv_off; a.lv_off8 = h->d_lv_off8; a.n_levels8 = h->n_levels8; a.narrow_thresh = h->narrow_thresh; a.pt_lev = h->d_pt_lev; a.dense_thresh = h->dense_thresh;
+    a.gather = h->d_gather; a.lv_ent = h->d_lv_ent; a.lv_off = h->d_lv_off; a.lv_off8 = h->d_lv_off8; a.n_levels8 = h->n_levels8; a.cell_copy = h->cell_copy; a.narrow_thresh = h->narrow_thresh; a.pt_lev = h->d_pt_lev; a.dense_thresh = h->dense_thresh;
     a.lv_pad = h->d_lv_pad; a.rest_pad = (const T *)h->d_rest_pad; a.rest_pad_stride = h->rest_pad_stride; a.lvw = h->lvw;
     a.n_levels = h->lv.n_levels;
     a.N = h->N; a.P = h->P; a.Ppad = h->Ppad; a.S = h->S; a.Spad = h->Spad;
