@@ -52,11 +52,11 @@ struct clothhip_handle {
     ClothSchedule *d_sched = nullptr, *h_sched = nullptr;   // h_sched: pinned staging
     uint32_t *d_gather = nullptr, *d_lv_ent = nullptr;
     uint16_t *d_lv_off = nullptr, *d_lv_off8 = nullptr, *d_pt_lev = nullptr;
-    int n_levels8 = 0, narrow_thresh = 160, cell_copy = 0;
+    int n_levels8 = 0, narrow_thresh = 300, cell_copy = 0;
     uint32_t *d_lv_pad = nullptr;
     void *d_rest_pad = nullptr;
     int lvw = 16, npad = 0, rest_pad_stride = 0;
-    int dense_thresh = 40;        // pre-pass flagged springs above which the lean dense sweep beats exact pending-level tracking
+    int dense_thresh = 14;        // pre-pass flagged springs above which the lean dense sweep beats exact pending-level tracking
     int HT = 0, ht_bits = 0, lvw_shift = 4, lds_bytes = 0, phase_mask = 15, nt = 256, ppt = 3;
     int tab = 0;            // static tables resident in LDS: 0 none, 1 springs/rest/offsets, 2 + per-point levels
     bool rest_reg = false;
