@@ -326,12 +326,18 @@ __device__ __forceinline__ void collide_cells_group(Pt<T> *cur, uint16_t *memb, 
         if (!__any(hm != 0u)) continue;
         T tx = (T)0, ty = (T)0, tz = (T)0;
         int nh = 0;
-        while (__any(hm != 0u)) {                                                       // ascending candidate order
-            const bool has = hm != 0u;
-            const int b = has ? __ffs((int)hm) - 1 : 0;
-            hm &= hm - 1u;
-            const T vx = lane_pull(fx, base + b), vy = lane_pull(fy, base + b), vz = lane_pull(fz, base + b);
-            if (has) { tx += vx; ty += vy; tz += vz; nh++; }
+        while (__any(hm != 0u)) {               // ascending candidate order; four hits are fetched per LDS round trip
+            bool has[4]; T vx[4], vy[4], vz[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                has[u] = hm != 0u;
+                const int b = has[u] ? __ffs((int)hm) - 1 : 0;
+                hm &= hm - 1u;
+                vx[u] = lane_pull(fx, base + b); vy[u] = lane_pull(fy, base + b); vz[u] = lane_pull(fz, base + b);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (has[u]) { tx += vx[u]; ty += vy[u]; tz += vz[u]; nh++; }
         }
         if (nh != 0 && sub == a && act) {                                               // :336-343
             const T nf = (T)nh;
@@ -408,7 +414,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
     uint32_t *hco = reinterpret_cast<uint32_t *>(smem + lay.hco);
     uint16_t *memb = reinterpret_cast<uint16_t *>(smem + lay.memb);
     uint16_t *slot = reinterpret_cast<uint16_t *>(smem + lay.slot);
-    int *misc = reinterpret_cast<int *>(smem + lay.misc);   // [0] tear, [1] #levels flagged by the pre-pass, [2] #active cells, [3] #occupied cells, [4] member cursor
+    int *misc = reinterpret_cast<int *>(smem + lay.misc);   // [0] tear, [1] #levels flagged by the pre-pass, [2] #active cells, [3] #occupied cells, [4] member cursor, [5],[6] cell tickets
     uint16_t *olist = reinterpret_cast<uint16_t *>(smem + lay.olist);
     uint16_t *alist_end = olist + (Ppad - 1);            // active list grows downwards: entry k = alist_end[-k]
     Pt<T> *cpos = reinterpret_cast<Pt<T> *>(smem + lay.cpos);
@@ -455,7 +461,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
         for (int h = tid; h < HT; h += NT) { hkey[h] = KEY_EMPTY; hco[h] = 0; }
         for (int i = tid; i < nL + 64; i += NT) lvflag[i] = 0;
         for (int i = tid; i < (A.Spad / 64 + 2) * 2; i += NT) reinterpret_cast<uint32_t *>(smem + lay.abits)[i] = 0u;
-        if (tid == 0) { misc[0] = A.tear[e]; misc[1] = 0; misc[2] = 0; misc[3] = 0; misc[4] = 0; }
+        if (tid == 0) { misc[0] = A.tear[e]; misc[1] = 0; misc[2] = 0; misc[3] = 0; misc[4] = 0; misc[5] = 0; misc[6] = 0; }
     }
     __syncthreads();
 
@@ -707,34 +713,44 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
             }
             __syncthreads();
             TSTAMP(5)
-            // (2) the active cells (those with a seed): exact Gauss-Seidel sweep. Wave w takes list entries w, w+nw, ...
-            // (cells are independent: each particle sits in exactly one). Cells with <= 16 members are processed four
-            // at a time, one per 16-lane group; larger cells get the whole wave (two per wave in 32-lane groups was
-            // measured: the bpermute broadcasts cost what the pairing saves).
+            // (2) the active cells (those with a seed): exact Gauss-Seidel sweep (cells are independent: each particle
+            // sits in exactly one). Every wave reads the whole list; work is handed out by LDS tickets so that the waves
+            // finish together: first the cells with more than 16 members, one per wave at a time, then the small
+            // cells four at a time, one per 16-lane group (two larger cells per wave in 32-lane groups was measured:
+            // the bpermute broadcasts cost what the pairing saves).
             {
-                const int wave = tid >> 6, nw = NT >> 6;
                 const int na = __builtin_amdgcn_readfirstlane(misc[2]);
-                for (int c0 = 0; c0 < na; c0 += 64 * nw) {
-                    const int ei = c0 + lane * nw + wave;
+                int tkb = -1, tks = -1, bbase = 0, sbase = 0;       // outstanding tickets, tickets used up by earlier chunks
+                for (int c0 = 0; c0 < na; c0 += 64) {
+                    const int ei = c0 + lane;
                     const bool ev = ei < na;
                     const int hs_l = ev ? (int)alist_end[-ei] : 0;
                     const uint32_t co_l = ev ? hco[hs_l] : 0u;
                     const int n_l = (int)(co_l & 0xFFFFu);
                     unsigned long long big = ballot64(ev && n_l > 16);
                     unsigned long long sm = ballot64(ev && n_l <= 16);
-                    while (big) {
+                    const int nbig = (int)__popcll(big), nsb = ((int)__popcll(sm) + 3) >> 2;
+                    for (int used = 0;;) {
+                        if (tkb < 0) { int t = 0; if (lane == 0) t = atomicAdd(&misc[5], 1); tkb = __builtin_amdgcn_readfirstlane(t); }
+                        if (tkb >= bbase + nbig) break;             // that ticket is for a later chunk (or nothing)
+                        for (; used < tkb - bbase; used++) big &= big - 1ull;
+                        tkb = -1;
                         const int b = __builtin_amdgcn_readfirstlane(__ffsll((long long)big) - 1);
-                        big &= big - 1ull;
                         const uint32_t co = (uint32_t)__builtin_amdgcn_readlane((int)co_l, b);
                         const int n = (int)(co & 0xFFFFu);
                         uint16_t *m = memb + (int)(co >> 16);
                         if (n <= 64) collide_cell_wave<T>(cur, m, slot, n, k, lane);
                         else if (lane == 0) collide_cell_serial<T>(cur, m, n, k);
                     }
+                    bbase += nbig;
 #ifdef CLOTHHIP_CELL_STAMPS
                     TSTAMP(10)
 #endif
-                    while (sm) {                                  // up to four small cells per pass
+                    for (int used = 0;;) {                        // up to four small cells per ticket
+                        if (tks < 0) { int t = 0; if (lane == 0) t = atomicAdd(&misc[6], 1); tks = __builtin_amdgcn_readfirstlane(t); }
+                        if (tks >= sbase + nsb) break;
+                        for (; used < 4 * (tks - sbase); used++) sm &= sm - 1ull;
+                        tks = -1;
                         int hs = -1;
 #pragma unroll
                         for (int g = 0; g < 4; g++) {
@@ -745,8 +761,10 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                                 hs = (lane >> 4) == g ? v : hs;
                             }
                         }
+                        used += 4;
                         collide_cells_group<T, 16>(cur, memb, slot, hco, hs, k, lane);
                     }
+                    sbase += nsb;
 #ifdef CLOTHHIP_CELL_STAMPS
                     TSTAMP(11)
 #endif
@@ -755,7 +773,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
             __syncthreads();
             TSTAMP(6)
             for (int t = tid; t < nocc; t += NT) { const int h = (int)olist[t]; hkey[h] = KEY_EMPTY; hco[h] = 0; }   // ready for the next substep
-            if (tid == 0) { misc[2] = 0; misc[3] = 0; misc[4] = 0; }
+            if (tid == 0) { misc[2] = 0; misc[3] = 0; misc[4] = 0; misc[5] = 0; misc[6] = 0; }
         } else {
             __syncthreads();
         }

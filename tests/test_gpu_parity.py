@@ -160,3 +160,42 @@ def test_grid_too_large_for_lds_is_rejected():
                                      "simulation_steps": 30, "grip_radius": 0.003}})
     with pytest.raises(ValueError):
         ClothBatch(g_cfg, n_envs=1, precision="f64")        # 64x64 doubles do not fit the CU's 160 KiB LDS
+
+
+@pytest.mark.parametrize("scale,lift", [(0.07, 0.5), (0.22, 0.3), (0.45, 0.1), (0.9, 0.02)])
+def test_crowded_cells_selfcollision_f64(scale, lift, oracle_lib):
+    """Self-collision stress: the whole 25x25 cloth squeezed into a fraction of its size, so the spatial cells hold
+    from a dozen up to several hundred particles (scale 0.07: > 64 members per cell -> the single-lane path; 0.22: the
+    whole-wave path; 0.45 / 0.9: 16-lane groups and mixed). Every sweep path (seeds, wake-on-move, tickets) must
+    reproduce the reference order exactly: fp64 bit-identical to the oracle after every one of 4 substeps, with one
+    pinned corner and a strain limiter that is very busy (the squeezed springs are far from rest)."""
+    from gym_cloth_amd import ClothBatch
+    g = oracle_lib.load_golden("g_traj_lift_pull_25.npz")
+    cfg = cfg_from_golden(g)
+    E = 3
+    b = ClothBatch(cfg, n_envs=E, precision="f64")
+    pos0, rest0 = b.init_grid(1)
+    rng = np.random.RandomState(int(scale * 1000))
+    states = []
+    for e in range(E):
+        p = pos0 * scale + 0.3
+        p += rng.uniform(-0.004, 0.004, size=p.shape)
+        p[:, 2] = lift * rng.uniform(0.0, 0.05, size=len(p)) + 0.001          # a thin slab: many layers in each cell
+        states.append(p)
+    pin = np.zeros((E, b.P), dtype=np.uint8)
+    pin[:, 0] = 1
+    b.set_state(np.stack(states), np.stack(states), pin, rest0)
+    ocs = []
+    for e in range(E):
+        oc = oracle_lib.OracleCloth(g["cfg"])
+        oc.set_state(states[e], states[e], pin[e], rest0)
+        ocs.append(oc)
+    census = ocs[0].cell_census()
+    for step in range(4):
+        b.update(1)
+        got = b.positions()
+        for e, oc in enumerate(ocs):
+            oc.update(1)
+            assert np.array_equal(got[e], oc.get_state()[0]), (scale, step, e, census, max_abs(got[e], oc.get_state()[0]))
+    assert ocs[0].last_stats()[1] > 0, "the case must exercise self-collision"
+    b.close()

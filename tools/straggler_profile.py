@@ -43,4 +43,7 @@ for name, nn, f in phases:
     tot += ms
     print("%-13s %4d substeps %8.2f ms  %7.2f us/substep | sweeps %.2f dense %.2f levels %6.1f corrected %5.1f" %
           (name, nn, ms, ms * 1e3 / nn, q[0], q[1], q[2], q[3]))
+    if q[4:14].sum() > 0:       # stamps build (make -C gym_cloth_amd/csrc stamps) + CLOTHHIP_DEBUG_PHASES=47
+        names = ["adjust", "hooke", "insert", "ranges", "fill", "precheck", "cells-wait", "reset+plane", "prepass", "sweep", "big cells", "small cells"]
+        print("      cycles/substep: " + "  ".join("%s %.0f" % (n, q[4 + i] * 64) for i, n in enumerate(names)))
 print("total %.1f ms" % tot)
