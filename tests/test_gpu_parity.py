@@ -165,10 +165,11 @@ def test_grid_too_large_for_lds_is_rejected():
 @pytest.mark.parametrize("scale,lift", [(0.07, 0.5), (0.22, 0.3), (0.45, 0.1), (0.9, 0.02)])
 def test_crowded_cells_selfcollision_f64(scale, lift, oracle_lib):
     """Self-collision stress: the whole 25x25 cloth squeezed into a fraction of its size, so the spatial cells hold
-    from a dozen up to several hundred particles (scale 0.07: > 64 members per cell -> the single-lane path; 0.22: the
-    whole-wave path; 0.45 / 0.9: 16-lane groups and mixed). Every sweep path (seeds, wake-on-move, tickets) must
-    reproduce the reference order exactly: fp64 bit-identical to the oracle after every one of 4 substeps, with one
-    pinned corner and a strain limiter that is very busy (the squeezed springs are far from rest)."""
+    from a dozen up to several hundred particles (max occupancy 468 / 138 at scales 0.07 / 0.22 -> the single-lane
+    path for cells over 64 members; 49 at 0.45 -> the whole-wave path; 14 at 0.9 -> four cells per wave in 16-lane
+    groups) and nearly every particle is moved by the collision pass. Every sweep path (seeds, wake-on-move, tickets)
+    must reproduce the reference order exactly: fp64 bit-identical to the oracle after each of 4 substeps, with one
+    pinned corner."""
     from gym_cloth_amd import ClothBatch
     g = oracle_lib.load_golden("g_traj_lift_pull_25.npz")
     cfg = cfg_from_golden(g)
