@@ -468,7 +468,8 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
     const T dz_up = (T)sc.dz_up, dxp = (T)sc.dx_pull, dyp = (T)sc.dy_pull, dzp = (T)sc.dz_pull;
     int done = 0;
     int st_sweeps = 0, st_dense = 0, st_levels = 0, st_trig = 0;      // wave 0 only (uniform)
-    unsigned long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+    unsigned long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0, tstart = 0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tstart)::"memory");   // whole-schedule clock of this cloth (stats[15])
 #ifdef CLOTHHIP_PHASE_STAMPS                 // profiling build (make stamps): phase mask bit 32 turns the stamps on
     const bool timing = (pm & PH_TIME) != 0;
 #else
@@ -1112,6 +1113,11 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
             if (A.stats) {
                 A.stats[16 * e] = st_sweeps; A.stats[16 * e + 1] = st_dense; A.stats[16 * e + 2] = st_levels; A.stats[16 * e + 3] = st_trig;
                 for (int q = 0; q < 12; q++) A.stats[16 * e + 4 + q] = (int)(tph[q] >> 6);
+#ifndef CLOTHHIP_PHASE_STAMPS
+                unsigned long long tend;
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tend)::"memory");
+                A.stats[16 * e + 15] = (int)((tend - tstart) >> 10);   // shader clocks / 1024 this cloth's schedule took
+#endif
             }
         }
     }

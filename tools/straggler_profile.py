@@ -19,7 +19,7 @@ pos0, prev0, pin0 = env.batch.get_state()
 env.step(acts[1])
 st = env.batch.debug_stats()
 ex = env.last_executed
-w = int(np.argmax(np.where(ex > 0, st[:, 2], 0)))
+w = int(np.argmax(np.where(ex > 0, st[:, 15], 0)))   # the cloth whose schedule took the most shader clocks
 print("worst env", w, "executed", ex[w], "levels/substep %.1f" % (st[w, 2] / ex[w]), "iters_pull", env.last_iters_pull[w])
 b = env.batch
 b.set_state(pos0[w], prev0[w], pin0[w] * 0)
