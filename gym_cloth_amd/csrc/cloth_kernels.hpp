@@ -581,7 +581,9 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                     ch[q] = (ckey[q] * 2654435761u) >> (32 - A.ht_bits);
                     pend[q] = i < P; made[q] = false; anyp |= pend[q];
                 }
-                while (anyp) {
+                // linear probing; the table has >= 1.5 P slots, so a free one always exists -- the probe bound only
+                // guarantees termination should LDS ever be corrupted
+                for (int probe = 0; anyp && probe < HT; probe++) {
                     anyp = false;
 #pragma unroll
                     for (int q = 0; q < PPT; q++) {
