@@ -50,13 +50,9 @@ template <typename T> struct StepArgs {
     const ClothSchedule *sched;   // [E]
     const uint32_t *gather;  // [HK_SLOTS][Ppad]
     const uint32_t *lv_ent;  // [Spad]  ptA | ptB<<16, level order
-    const uint16_t *lv_off;  // [n_levels+1]
-    const uint16_t *lv_off8; // [n_levels8+1] the same springs cut into levels of width <= 8 (sub-levels of the levels above)
+    const uint16_t *lv_off;  // [n_levels+40] level offsets, padded with the end offset
+    const uint16_t *lv_off8; // [n_levels8+40] the same springs cut into levels of width <= 8 (sub-levels of the levels above)
     const uint16_t *pt_lev;  // [HK_SLOTS][Ppad] dependency level of the k-th incident spring of a point (0xFFFF none)
-    const uint32_t *lv_pad;  // [n_levels + 16][LVW] fixed-width level table for the dense sweep: ent, empty slots = 0 (ptA == ptB)
-    const T *rest_pad;       // [E or 1][(n_levels + 16) * LVW] rest lengths in the same padded order
-    int32_t rest_pad_stride; // 0: shared
-    int32_t lvw;             // padded level width (16 or 32)
     int32_t n_levels;
     int32_t N, P, Ppad, S, Spad;
     int32_t HT, ht_bits;     // spatial hash table slots (power of two > P)
@@ -160,7 +156,7 @@ struct LdsLayout {
         cur = take(4 * Ppad * tsz);
         ent = take(tab >= 1 ? Spad * 4 : 0);
         rest = take(tab >= 1 ? Spad * tsz : 0);
-        off = take(tab >= 1 ? (nL + 24) * 2 : 0);       // padded: levels past the end are empty
+        off = take(tab >= 1 ? (nL + 40) * 2 : 0);       // padded: levels past the end are empty
         off8 = take(tab >= 1 && nL8 > 0 ? (nL8 + 40) * 2 : 0);
         plev = take(tab >= 2 ? HK_SLOTS * Ppad * 2 : 0);
         flag = take(nL + 64);        // pending-level marks of the running sweep (all zero between sweeps)
@@ -450,9 +446,9 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
             T *d1 = reinterpret_cast<T *>(smem + lay.rest);
             for (int i = tid; i < A.Spad; i += NT) { d0[i] = A.lv_ent[i]; d1[i] = g_rest[i]; }
             uint16_t *d2 = reinterpret_cast<uint16_t *>(smem + lay.off);
-            for (int i = tid; i < nL + 24; i += NT) d2[i] = A.lv_off[i < nL ? i : nL];
+            for (int i = tid; i < nL + 40; i += NT) d2[i] = A.lv_off[i];
             uint16_t *d3 = reinterpret_cast<uint16_t *>(smem + lay.off8);
-            for (int i = tid; i < (A.n_levels8 > 0 ? A.n_levels8 + 40 : 0); i += NT) d3[i] = A.lv_off8[i < A.n_levels8 ? i : A.n_levels8];
+            for (int i = tid; i < (A.n_levels8 > 0 ? A.n_levels8 + 40 : 0); i += NT) d3[i] = A.lv_off8[i];
         }
         if (TAB >= 2) {
             uint16_t *d4 = reinterpret_cast<uint16_t *>(smem + lay.plev);
@@ -867,20 +863,20 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                     // two entries ahead. Empty slots hold ptA == ptB == 0, which can never stretch (len2 == 0).
                     // Few flagged levels: most passes find nothing to correct, so the narrow table (same springs, levels cut
                     // to width <= 8) lets a pass look at 8 levels instead of 64/lvw.
-                    const bool narrow = TAB >= 1 && A.n_levels8 > 0 && misc[1] <= A.narrow_thresh && !(pm & PH_NOSKIP);
+                    const bool narrow = A.n_levels8 > 0 && misc[1] <= A.narrow_thresh && !(pm & PH_NOSKIP);
                     const int lsh = narrow ? 3 : A.lvw_shift, lvw = 1 << lsh, GR = 64 >> lsh;   // lvw is a power of two
                     const int res = lane >> lsh;
                     DevConsts<T> kl = k;                         // spring-test constants pinned in VGPRs
                     asm volatile("" : "+v"(kl.c11), "+v"(kl.tear_thresh));
                     const int sl = lane & (lvw - 1);
                     int myL = res;                               // the level this lane currently holds
-                    if (TAB >= 1) {
-                        // Lane-private stream over the compact level table in LDS: entry index = off[level] + slot,
+                    {
+                        // Lane-private stream over the compact level table (LDS, or L2 for the large grids): entry index = off[level] + slot,
                         // a slot beyond the level's width reads the all-zero padding entry S (ptA == ptB == 0).
                         // Every pass re-issues the loads of the NEXT entry unconditionally (same address while the lane
                         // has not consumed), so no loaded value is touched before the following pass.
                         const int ZE = A.S;                      // index of a zero entry (Spad > S, zero filled)
-                        const uint16_t *loffD = narrow ? reinterpret_cast<const uint16_t *>(smem + lay.off8) : loff;
+                        const uint16_t *loffD = narrow ? (TAB >= 1 ? reinterpret_cast<const uint16_t *>(smem + lay.off8) : A.lv_off8) : loff;
                         const int nLD = narrow ? A.n_levels8 : nL;
                         int p0 = (int)loffD[myL] + sl; p0 = p0 < (int)loffD[myL + 1] ? p0 : ZE;
                         int pn = (int)loffD[myL + GR] + sl; pn = pn < (int)loffD[myL + GR + 1] ? pn : ZE;
@@ -945,55 +941,6 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                             // above without waiting for them; the barrier only pins the compiler's ordering
                             __builtin_amdgcn_wave_barrier();
                             PA = cur[ec & 0xFFFFu]; PB = cur[ec >> 16];      // next pass's particles (after this pass's writes)
-                        }
-                    } else {
-                        // tables not resident in LDS (large grids): padded fixed-width table streamed from L2
-                        const uint32_t *tp = A.lv_pad + sl;
-                        const T *rp = A.rest_pad + (size_t)e * A.rest_pad_stride + sl;
-                        uint32_t ec = tp[myL << lsh], e1 = tp[(myL + GR) << lsh], e2 = tp[(myL + 2 * GR) << lsh];
-                        T rc = rp[myL << lsh], r1 = rp[(myL + GR) << lsh], r2 = rp[(myL + 2 * GR) << lsh];
-                        int L = 0;
-                        while (L < nL) {
-                            const int grp = myL - L;
-                            const int a = (int)(ec & 0xFFFFu), b = (int)(ec >> 16);
-                            const Pt<T> PA = cur[a], PB = cur[b];
-                            const uint32_t ca = w_cnt(PA.w), cb = w_cnt(PB.w);
-                            const T dx = PA.x - PB.x, dy = PA.y - PB.y, dz = PA.z - PB.z;
-                            const T len2 = dx * dx + dy * dy + dz * dz;
-                            const T t11 = rc * kl.c11, tt = rc * kl.tear_thresh;
-                            const T tmin = t11 < tt ? t11 : tt;
-                            bool trig = false, tearl = false;
-                            T len = (T)0;
-                            if (!(ca != 0 && cb != 0) && (len2 > tmin * tmin * ((T)1 - filt_slack<T>()))) {
-                                len = dev_sqrt<T>(len2);
-                                tearl = len > tt;
-                                trig = len > t11;
-                            }
-                            const unsigned long long tb = ballot64(trig);
-                            const int rot = (L & (GR - 1)) << lsh;
-                            const unsigned long long tr = rot ? ((tb >> rot) | (tb << (64 - rot))) : tb;
-                            const int g = tr ? (__ffsll((long long)tr) - 1) >> lsh : GR;
-                            if (trig && grp == g) {
-                                const T ux = dev_div<T>(dx, len), uy = dev_div<T>(dy, len), uz = dev_div<T>(dz, len);
-                                const T extra = len - t11;
-                                const T wa = ca != 0 ? (T)0 : (cb != 0 ? (T)1 : (T)0.5);
-                                const T wb = cb != 0 ? (T)0 : (ca != 0 ? (T)1 : (T)0.5);
-                                const T ea = extra * wa, eb = extra * wb;
-                                if (ca == 0) cur[a] = Pt<T>{PA.x - ux * ea, PA.y - uy * ea, PA.z - uz * ea, PA.w};
-                                if (cb == 0) cur[b] = Pt<T>{PB.x + ux * eb, PB.y + uy * eb, PB.z + uz * eb, PB.w};
-                            }
-                            if (tearl && grp <= g) tear = 1;
-                            const int adv = g < GR ? g + 1 : GR;
-                            st_levels += adv; st_trig += g < GR ? 1 : 0;
-                            L += adv;
-                            if (myL < L) {
-                                myL += GR;
-                                ec = e1; rc = r1; e1 = e2; r1 = r2;
-                                e2 = tp[(myL + 2 * GR) << lsh]; r2 = rp[(myL + 2 * GR) << lsh];
-                            }
-                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                            __builtin_amdgcn_wave_barrier();
-                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                         }
                     }
                 } else

@@ -53,9 +53,6 @@ struct clothhip_handle {
     uint32_t *d_gather = nullptr, *d_lv_ent = nullptr;
     uint16_t *d_lv_off = nullptr, *d_lv_off8 = nullptr, *d_pt_lev = nullptr;
     int n_levels8 = 0, narrow_thresh = 300, cell_copy = 0;
-    uint32_t *d_lv_pad = nullptr;
-    void *d_rest_pad = nullptr;
-    int lvw = 16, npad = 0, rest_pad_stride = 0;
     int dense_thresh = 14;        // pre-pass flagged springs above which the lean dense sweep beats exact pending-level tracking
     int HT = 0, ht_bits = 0, lvw_shift = 4, lds_bytes = 0, phase_mask = 15, nt = 256, ppt = 3;
     int tab = 0;            // static tables resident in LDS: 0 none, 1 springs/rest/offsets, 2 + per-point levels
@@ -157,7 +154,7 @@ static void free_handle(clothhip_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_pos, h->d_prev, h->d_rest, h->d_cnt, h->d_active, h->d_tear, h->d_exec, h->d_ngrab, h->d_stats,
-                    h->d_sched, h->d_gather, h->d_lv_ent, h->d_lv_off, h->d_lv_off8, h->d_pt_lev, h->d_lv_pad, h->d_rest_pad, h->d_levels, h->d_xy, h->d_radius, h->d_cov, h->d_vinv, h->d_oob};
+                    h->d_sched, h->d_gather, h->d_lv_ent, h->d_lv_off, h->d_lv_off8, h->d_pt_lev, h->d_levels, h->d_xy, h->d_radius, h->d_cov, h->d_vinv, h->d_oob};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->h_sched) (void)hipHostFree(h->h_sched);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -186,7 +183,7 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
     h->tsz = precision == CLOTHHIP_F64 ? 8 : 4;
     h->topo = build_topology(h->N);
     h->lv = build_levels(h->topo);
-    h->S = h->topo.S; h->Spad = (h->S + 63) / 64 * 64;
+    h->S = h->topo.S; h->Spad = (h->S + 64) / 64 * 64;      // > S: entry S is the all-zero padding entry of the sweeps
     // threads per cloth x particles per thread (compile-time variants of the stepper)
     if (h->P <= 768) { h->nt = 256; h->ppt = 3; }
     else if (h->P <= 2560 && !getenv("CLOTHHIP_DEBUG_NT1024")) { h->nt = 512; h->ppt = 5; }
@@ -229,7 +226,7 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
     HC(hipHostMalloc((void **)&h->h_sched, E * sizeof(ClothSchedule), hipHostMallocDefault));
     HC(hipMalloc(&h->d_gather, gather.size() * 4));
     HC(hipMalloc(&h->d_lv_ent, (size_t)h->Spad * 4));
-    HC(hipMalloc(&h->d_lv_off, (size_t)(h->lv.n_levels + 1) * 2));
+    HC(hipMalloc(&h->d_lv_off, (size_t)(h->lv.n_levels + 40) * 2));
     HC(hipMalloc(&h->d_pt_lev, (size_t)HK_SLOTS * h->Ppad * 2));
     HC(hipMalloc(&h->d_levels, (levels.size() + 1) * 8));
     HC(hipMalloc(&h->d_xy, E * 2 * 8));
@@ -242,6 +239,7 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
     HC(hipMemcpy(h->d_lv_ent, h->lv.ent.data(), (size_t)h->S * 4, hipMemcpyHostToDevice));
     {
         std::vector<uint16_t> off16(h->lv.off.begin(), h->lv.off.end());
+        off16.resize((size_t)h->lv.n_levels + 40, (uint16_t)h->lv.off[h->lv.n_levels]);   // levels past the end are empty
         HC(hipMemcpy(h->d_lv_off, off16.data(), off16.size() * 2, hipMemcpyHostToDevice));
         // narrow table: every level cut into consecutive sub-levels of at most 8 springs (still antichains, same order)
         std::vector<uint16_t> off8;
@@ -249,6 +247,7 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
             for (int p = h->lv.off[L]; p < h->lv.off[L + 1]; p += 8) off8.push_back((uint16_t)p);
         off8.push_back((uint16_t)h->lv.off[h->lv.n_levels]);
         h->n_levels8 = h->lv.max_width > 8 ? (int)off8.size() - 1 : 0;     // width <= 8 already: the main table is narrow
+        off8.resize(off8.size() + 40, (uint16_t)h->lv.off[h->lv.n_levels]);
         HC(hipMalloc(&h->d_lv_off8, off8.size() * 2));
         HC(hipMemcpy(h->d_lv_off8, off8.data(), off8.size() * 2, hipMemcpyHostToDevice));
     }
@@ -263,17 +262,6 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
                 if (g & HK_VALID) pl[(size_t)sl * h->Ppad + i] = (uint16_t)lvl_of_pos[(g >> HK_POS_SHIFT) & HK_POS_MASK];
             }
         HC(hipMemcpy(h->d_pt_lev, pl.data(), pl.size() * 2, hipMemcpyHostToDevice));
-    }
-    {   // fixed-width (padded) level table for the dense sweep
-        h->lvw = 1 << h->lvw_shift;
-        h->npad = (h->lv.n_levels + 16) * h->lvw;
-        std::vector<uint32_t> pad((size_t)h->npad, 0u);
-        for (int L = 0; L < h->lv.n_levels; L++)
-            for (int p = h->lv.off[L]; p < h->lv.off[L + 1]; p++) pad[(size_t)L * h->lvw + (p - h->lv.off[L])] = h->lv.ent[p];
-        HC(hipMalloc(&h->d_lv_pad, pad.size() * 4));
-        HC(hipMemcpy(h->d_lv_pad, pad.data(), pad.size() * 4, hipMemcpyHostToDevice));
-        HC(hipMalloc(&h->d_rest_pad, E * (size_t)h->npad * h->tsz));
-        HC(hipMemset(h->d_rest_pad, 0, E * (size_t)h->npad * h->tsz));
     }
     if (const char *dt = getenv("CLOTHHIP_DEBUG_DENSE")) h->dense_thresh = atoi(dt);
     if (const char *dt = getenv("CLOTHHIP_DEBUG_NARROW")) h->narrow_thresh = atoi(dt);
@@ -394,25 +382,6 @@ extern "C" int clothhip_set_state(clothhip_handle *h, int32_t env0, int32_t n, c
         char *dst = (char *)h->d_rest + (rest_shared ? 0 : (size_t)env0 * h->Spad * h->tsz);
         HIPCHECK(hipMemcpy(dst, buf.data(), buf.size(), hipMemcpyHostToDevice));
         h->rest_stride = rest_shared ? 0 : h->Spad;
-        // the same rest lengths in the padded (fixed-width) level order of the dense sweep
-        if (!rest_shared && h->rest_pad_stride == 0 && !(env0 == 0 && n == h->E)) {
-            std::vector<unsigned char> one((size_t)h->npad * h->tsz);
-            HIPCHECK(hipMemcpy(one.data(), h->d_rest_pad, one.size(), hipMemcpyDeviceToHost));
-            for (int e = 1; e < h->E; e++)
-                HIPCHECK(hipMemcpy((char *)h->d_rest_pad + (size_t)e * one.size(), one.data(), one.size(), hipMemcpyHostToDevice));
-        }
-        std::vector<unsigned char> pb((size_t)nt * h->npad * h->tsz, 0);
-        for (int e = 0; e < nt; e++)
-            for (int L = 0; L < h->lv.n_levels; L++)
-                for (int p = h->lv.off[L]; p < h->lv.off[L + 1]; p++) {
-                    const double v = rest[(size_t)e * h->S + h->lv.order[p]];
-                    const size_t q = (size_t)e * h->npad + (size_t)L * h->lvw + (p - h->lv.off[L]);
-                    if (h->precision == CLOTHHIP_F64) ((double *)pb.data())[q] = v;
-                    else ((float *)pb.data())[q] = (float)v;
-                }
-        char *dp = (char *)h->d_rest_pad + (rest_shared ? 0 : (size_t)env0 * h->npad * h->tsz);
-        HIPCHECK(hipMemcpy(dp, pb.data(), pb.size(), hipMemcpyHostToDevice));
-        h->rest_pad_stride = rest_shared ? 0 : h->npad;
     }
     return 0;
 }
@@ -521,7 +490,6 @@ template <typename T> static StepArgs<T> make_args(clothhip_handle *h, const Clo
     a.pos = (T *)h->d_pos; a.prev = (T *)h->d_prev; a.cnt = h->d_cnt; a.rest = (const T *)h->d_rest;
     a.tear = h->d_tear; a.executed = h->d_exec; a.stats = h->d_stats; a.sched = d_sched;
     a.gather = h->d_gather; a.lv_ent = h->d_lv_ent; a.lv_off = h->d_lv_off; a.lv_off8 = h->d_lv_off8; a.n_levels8 = h->n_levels8; a.cell_copy = h->cell_copy; a.narrow_thresh = h->narrow_thresh; a.pt_lev = h->d_pt_lev; a.dense_thresh = h->dense_thresh;
-    a.lv_pad = h->d_lv_pad; a.rest_pad = (const T *)h->d_rest_pad; a.rest_pad_stride = h->rest_pad_stride; a.lvw = h->lvw;
     a.n_levels = h->lv.n_levels;
     a.N = h->N; a.P = h->P; a.Ppad = h->Ppad; a.S = h->S; a.Spad = h->Spad;
     a.HT = h->HT; a.ht_bits = h->ht_bits; a.lvw_shift = h->lvw_shift;
