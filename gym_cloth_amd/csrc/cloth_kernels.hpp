@@ -914,19 +914,11 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                             const unsigned long long tr = rot ? ((tb >> rot) | (tb << (64 - rot))) : tb;
                             const int g = tr ? (__ffsll((long long)tr) - 1) >> lsh : GR;        // first correcting level of the pass
                             const bool commit = trig && grp == g;
-                            if (tearl && grp <= g) tear = 1;
                             const int adv = g < GR ? g + 1 : GR;
                             L += adv;
-                            st_levels += adv; st_trig += g < GR ? 1 : 0;
-                            // consume (branch-free): lanes whose level is done move on to their next level; the
-                            // stream loads of the pass after next go out before this pass's writes
+                            // lanes whose level is done move on to their next level (branch-free consume)
                             const bool cons = myL < L;
-                            myL = cons ? myL + GR : myL;
                             const uint32_t ecn = cons ? e1 : ec;
-                            rc = cons ? r1 : rc;
-                            if (cons) { int q = olo + sl; pn = q < ohi ? q : ZE; }
-                            e1 = ent[pn]; r1 = rest[pn];
-                            olo = (int)loffD[myL + 2 * GR]; ohi = (int)loffD[myL + 2 * GR + 1];
                             if (commit) {
                                 const T ux = dev_div<T>(dx, len), uy = dev_div<T>(dy, len), uz = dev_div<T>(dz, len);   // :276-278
                                 const T extra = len - t11;                                      // :279
@@ -936,11 +928,21 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                                 if (ca == 0) cur[a] = Pt<T>{PA.x - ux * ea, PA.y - uy * ea, PA.z - uz * ea, PA.w};
                                 if (cb == 0) cur[b] = Pt<T>{PB.x + ux * eb, PB.y + uy * eb, PB.z + uz * eb, PB.w};
                             }
-                            ec = ecn;
                             // same-wave LDS operations execute in program order: the reads below see the writes
                             // above without waiting for them; the barrier only pins the compiler's ordering
                             __builtin_amdgcn_wave_barrier();
-                            PA = cur[ec & 0xFFFFu]; PB = cur[ec >> 16];      // next pass's particles (after this pass's writes)
+                            PA = cur[ecn & 0xFFFFu]; PB = cur[ecn >> 16];    // next pass's particles (after this pass's writes)
+                            __builtin_amdgcn_sched_barrier(0);
+                            // the rest of the bookkeeping runs in the shadow of those reads; the stream loads for the
+                            // pass after next queue behind them
+                            if (tearl && grp <= g) tear = 1;
+                            st_levels += adv; st_trig += g < GR ? 1 : 0;
+                            myL = cons ? myL + GR : myL;
+                            rc = cons ? r1 : rc;
+                            if (cons) { int q = olo + sl; pn = q < ohi ? q : ZE; }
+                            e1 = ent[pn]; r1 = rest[pn];
+                            olo = (int)loffD[myL + 2 * GR]; ohi = (int)loffD[myL + 2 * GR + 1];
+                            ec = ecn;
                         }
                     }
                 } else
