@@ -168,7 +168,8 @@ struct LdsLayout {
         misc = take(128);            // flags and scan scratch
         olist = take(2 * Ppad);       // u16 hash slots: occupied cells from the front, cells with a seed from the back
         alist = olist;                //   (an active cell has >= 2 members, so #occupied + #active <= P)
-        cpos = take(cp ? 4 * Ppad * tsz : 0);   // particle records in cell (CSR) order for the pre-check
+        cpos = take(cp ? 4 * (Ppad + 32) * tsz : 0);   // particle records in cell (CSR) order for the pre-check; the
+                                                       // unclamped member loop may read up to a cell's width past the end
         total = o;
     }
 };
@@ -660,17 +661,16 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
 #endif
                 if (A.cell_copy) {
                     constexpr int CU = 2;
-                    // no clamping: a read past the cell's range (another cell's record, or past the array: LDS returns
-                    // zeros there) is masked out by the member count
-                    const Pt<T> *cb[PPT];
-#pragma unroll
-                    for (int q = 0; q < PPT; q++) cb[q] = cpos + cstart[q];
+                    // a read past the cell's range (another cell's record or the padding behind the array) is masked out
+                    // by the member count; the trip base is clamped so that no read leaves the padded array
                     for (int b = 0; b < nmax; b += CU) {     // CU members x PPT particles per trip: their LDS reads overlap
                         Pt<T> o[PPT][CU];
 #pragma unroll
-                        for (int q = 0; q < PPT; q++)
+                        for (int q = 0; q < PPT; q++) {
+                            const int base = cstart[q] + b < Ppad + 32 - CU ? cstart[q] + b : Ppad + 32 - CU;
 #pragma unroll
-                            for (int u = 0; u < CU; u++) o[q][u] = cb[q][b + u];
+                            for (int u = 0; u < CU; u++) o[q][u] = cpos[base + u];
+                        }
 #pragma unroll
                         for (int q = 0; q < PPT; q++)
 #pragma unroll
