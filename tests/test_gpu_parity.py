@@ -200,3 +200,38 @@ def test_crowded_cells_selfcollision_f64(scale, lift, oracle_lib):
             assert np.array_equal(got[e], oc.get_state()[0]), (scale, step, e, census, max_abs(got[e], oc.get_state()[0]))
     assert ocs[0].last_stats()[1] > 0, "the case must exercise self-collision"
     b.close()
+
+
+@pytest.mark.parametrize("mode,env", [
+    ("sparse only", {"CLOTHHIP_DEBUG_DENSE": "100000"}),
+    ("dense, natural levels only", {"CLOTHHIP_DEBUG_DENSE": "0", "CLOTHHIP_DEBUG_NARROW": "0"}),
+    ("dense, narrow table only", {"CLOTHHIP_DEBUG_DENSE": "0", "CLOTHHIP_DEBUG_NARROW": "100000"}),
+    ("tables streamed from L2", {"CLOTHHIP_DEBUG_TAB_LDS": "0"}),
+    ("dense from L2, narrow", {"CLOTHHIP_DEBUG_TAB_LDS": "0", "CLOTHHIP_DEBUG_DENSE": "0", "CLOTHHIP_DEBUG_NARROW": "100000"}),
+    ("pre-check without the cell-ordered copy", {"CLOTHHIP_DEBUG_CELL_COPY": "0"}),
+])
+def test_every_sweep_mode_is_exact_f64(mode, env, oracle_lib, monkeypatch):
+    """The strain sweep has several exact execution modes chosen at run time by how many levels the pre-pass flags
+    (sparse pending-level tracking / dense over the natural levels / dense over the narrow table; tables in LDS or
+    streamed from L2) and the collision pre-check has two data sources. Each mode is forced in turn (debug
+    environment variables read at clothhip_create) and must reproduce the reference's lift-and-pull trajectory,
+    whose pull phase over-stretches hundreds of springs, bit for bit."""
+    from gym_cloth_amd import ClothBatch
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)
+    g = oracle_lib.load_golden("g_traj_lift_pull_25.npz")
+    b = ClothBatch(cfg_from_golden(g), n_envs=2, precision="f64")
+    rp = BatchReplay(b)
+    bad = []
+
+    def cp(k):
+        pos, prev, pin = b.get_state()
+        for e in range(b.E):
+            if not (np.array_equal(pos[e], g["cp_pos"][k]) and np.array_equal(prev[e], g["cp_prev"][k])):
+                bad.append((k, e, max_abs(pos[e], g["cp_pos"][k])))
+    oracle_lib.replay_ops(rp, g["ops"], cp)
+    st = b.debug_stats()
+    b.close()
+    assert not bad, (mode, bad[:4])
+    if env.get("CLOTHHIP_DEBUG_DENSE") == "100000":
+        assert st[:, 1].sum() == 0, "the sparse-only run must not have used the dense sweep"
