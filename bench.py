@@ -9,6 +9,9 @@ A "step" = ClothVecEnv.step over the whole batch = Gripper.grab_top + the fused 
 (~1430 + iters_pull substeps per env, cloth_env.py:472-515) + metrics.  State is resident in HBM; the timed
 region contains no state upload.  value = executed Cloth.update()-equivalents (all envs, all ranks) / wall time.
 
+`--init tier2` starts every env from the reference's tier-2 reset instead (BASELINE configs[3] names it; the default
+keeps ONE workload at every GPU count so that the per-N values are comparable).
+
 Multi-GPU (one process per GPU, torch.distributed 'nccl' = RCCL over xGMI): env blocks are sharded, rank 0's
 action table is broadcast every step and per-env results are all-gathered; there is no other collective
 because cloths never interact.
@@ -29,7 +32,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def bench_cfg(n_side, thickness):
+def bench_cfg(n_side, thickness, tier="tier1"):
     return {
         "cloth": {"damping": 2.0, "density": 200.0, "ks": 10000.0, "width": 1, "height": 1,
                   "num_width_points": n_side, "num_height_points": n_side, "thickness": thickness,
@@ -40,7 +43,7 @@ def bench_cfg(n_side, thickness):
                 "reduce_factor": 0.002, "grip_radius": 0.003, "reward_type": "coverage-delta",
                 "force_grab": False, "clip_act_space": True, "delta_actions": True, "obs_type": "1d",
                 "oracle_reveal": "False", "use_depth": "False", "use_dom_rand": "False", "use_rgbd": "False"},
-        "init": {"type": "tier1", "debug_matplotlib": False, "render_opengl": False},
+        "init": {"type": tier, "debug_matplotlib": False, "render_opengl": False},
         "log": {"level": "info", "file": "logs/bench.log"}, "seed": 1000}
 
 
@@ -100,6 +103,8 @@ def main():
     ap.add_argument("--n-side", type=int, default=25)
     ap.add_argument("--thickness", type=float, default=None)
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--init", default="tier1", choices=["tier1", "tier2", "tier3"],
+                    help="start state of every env (BASELINE configs[3] names tier2; reset draws come from RandomState(1000+e))")
     ap.add_argument("--gather-obs", action="store_true", help="all-gather the '1d' observations every step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -117,7 +122,7 @@ def main():
 
     E = args.envs
     thickness = args.thickness if args.thickness is not None else (0.02 if args.n_side <= 25 else 0.0095)
-    cfg = bench_cfg(args.n_side, thickness)
+    cfg = bench_cfg(args.n_side, thickness, args.init)
     env = ClothVecEnv(cfg, n_envs=E, device=local_rank, precision=args.precision, consume_domrand_draws=False)
     g0 = rank * E                                            # first global env index of this rank
     for e in range(E):                                       # reset draws from RandomState(1000+e)
@@ -191,8 +196,9 @@ def main():
             "value": n_sub_all / dt, "unit": "cloth-substeps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "%d batched %dx%d cloths per GPU, tier-1 start, random pick-and-place actions "
-                                   "(BASELINE configs[2]; configs[3] = 8 x this)" % (E, args.n_side, args.n_side),
+            "config": {"workload": "%d batched %dx%d cloths per GPU, %s start, random pick-and-place actions "
+                                   "(BASELINE configs[2]; configs[3] = 8 x this)" % (E, args.n_side, args.n_side,
+                                                                                    args.init.replace("tier", "tier-")),
                        "envs_per_gpu": E, "n_side": args.n_side, "exact_order": True,
                        "env_steps_per_s": world * E * args.steps / dt,
                        "substeps_per_env_step": n_sub_all / (world * E * args.steps)},
