@@ -6,13 +6,19 @@
 // (compiled with -ffp-contract=off) and the float instantiation is the same algorithm in fp32.
 //
 //   phase            reference                parallelisation (exact-order preserving)
-//   adjust/release   gripper.pyx:55-73        per point
+//   adjust/release   gripper.pyx:55-73        per point (owner thread)
 //   gravity+Hooke    cloth.pyx:216-237        per-point gather of <=12 springs in ascending list index
 //   Verlet           cloth.pyx:239-256        per point (fused with the gather)
-//   spatial map      cloth.pyx:298-311        sort of (cell key, point index) -> cells are contiguous runs
-//   self-collision   cloth.pyx:313-343        one lane per cell, Gauss-Seidel in ascending index inside it
-//   plane            cloth.pyx:345-370        per point (done by the cell's lane after its sweep)
-//   strain limit     cloth.pyx:258-296        dependency-level schedule, one wave, levels in order
+//   spatial map      cloth.pyx:298-311        LDS hash table keyed by the exact cell key + occupied-cell list; members
+//                                             of a cell stored contiguously (rank from the counting atomic)
+//   self-collision   cloth.pyx:313-343        parallel seed test, then an exact Gauss-Seidel sweep of the cells that
+//                                             have a seed: to-visit set = seeds + later neighbours of members that moved;
+//                                             four small cells per wave / one wave per large cell, LDS tickets
+//   plane            cloth.pyx:345-370        per point (owner thread: it holds the previous position)
+//   strain limit     cloth.pyx:258-296        dependency-level schedule walked by ONE wave: sparse (pending-level
+//                                             tracking) or dense (8 / 4 levels speculated per pass, first correcting
+//                                             level commits)
+// DESIGN.md section 4 has the exactness argument of every phase.
 #pragma once
 
 #include <hip/hip_runtime.h>
