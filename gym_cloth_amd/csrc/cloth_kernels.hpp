@@ -834,7 +834,14 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                             const bool act = (g & (HK_VALID | HK_ASB)) == (HK_VALID | HK_ASB) &&
                                              !(cme_ != 0 && w_cnt(nb.w) != 0) &&
                                              (len2 > tmin * tmin * ((T)1 - filt_slack<T>()));
-                            if (act) { atomicOr(&abits32[pos_ >> 5], 1u << (pos_ & 31)); nact++; }
+                            if (act) {
+                                // inside the slack band around the limit the sweep's exact test (:270-275) decides: a spring
+                                // that sits exactly ON its limit (left there by an earlier substep's correction) is then
+                                // not flagged, and a cloth at rest skips the sweep altogether
+                                bool flag = len2 > tmin * tmin * ((T)1 + filt_slack<T>());
+                                if (!flag) { const T len = dev_sqrt<T>(len2); flag = len > t11 || len > tt; }
+                                if (flag) { atomicOr(&abits32[pos_ >> 5], 1u << (pos_ & 31)); nact++; }
+                            }
                         }
                     }
                 }
@@ -967,28 +974,64 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                         if (lvflag[Lm]) { want = true; lvflag[Lm] = 0; }        // pending mark from an earlier correction
                     }
                     unsigned long long need = ballot64(want);
-                    int pj = -1;                                 // level whose springs are already fetched into (pen, pr)
-                    uint32_t pen = 0u; T pr = (T)0;
+                    // Up to WG = 64/lvw needed levels are evaluated per pass, one per lane group, against the same particle
+                    // state (as in the dense sweep): levels before the first correcting one are provably no-ops, that one
+                    // commits (and marks the later levels its particles touch), later ones are retried by the next pass.
+                    const int wsh = A.lvw_shift, WG = 64 >> wsh, wsub = lane & ((1 << wsh) - 1), wgrp = lane >> wsh;
                     while (need) {
 #ifdef CLOTHHIP_SWEEP_STAMPS
                         unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
                         if (timing) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts0)::"memory"); }
 #endif
-                        const int j = __ffsll((long long)need) - 1;
-                        need &= need - 1ull;
-                        const int o0 = __builtin_amdgcn_readlane(myoff, j), o1 = __builtin_amdgcn_readlane(myoff1, j);
-                        const int idx = o0 + lane;
-                        const bool on = idx < o1;
-                        uint32_t en = pen; T r = pr;
-                        if (j != pj && on) { en = ent[idx]; r = rest[idx]; }
-                        if (need) {                              // fetch the NEXT level that has to run
-                            pj = __ffsll((long long)need) - 1;
-                            const int q0 = __builtin_amdgcn_readlane(myoff, pj) + lane;
-                            if (q0 < __builtin_amdgcn_readlane(myoff1, pj)) { pen = ent[q0]; pr = rest[q0]; }
-                        } else pj = -1;
+                        unsigned long long nd = need;
+                        int o0 = 0, o1 = 0, myj = -1;            // my group's level: spring range and chunk-relative index
+                        unsigned long long taken = 0ull;         // the levels of this pass
+                        for (int g = 0; g < WG && nd; g++) {
+                            const int j = __ffsll((long long)nd) - 1;
+                            nd &= nd - 1ull;
+                            taken |= 1ull << j;
+                            const int a0 = __builtin_amdgcn_readlane(myoff, j), a1 = __builtin_amdgcn_readlane(myoff1, j);
+                            if (wgrp == g) { o0 = a0; o1 = a1; myj = j; }
+                        }
+                        const int idx = o0 + wsub;
+                        const bool on = myj >= 0 && idx < o1;
+                        uint32_t en = 0u; T r = (T)0;
+                        if (on) { en = ent[idx]; r = rest[idx]; }
+                        const int pa = (int)(en & 0xFFFFu), pb = (int)(en >> 16);
+                        const Pt<T> PA = cur[pa], PB = cur[pb];
+                        const uint32_t ca = w_cnt(PA.w), cb = w_cnt(PB.w);
+                        const T dx = PA.x - PB.x, dy = PA.y - PB.y, dz = PA.z - PB.z;
+                        const T len2 = dx * dx + dy * dy + dz * dz;
+                        const T t11 = r * k.c11, tt = r * k.tear_thresh;
+                        const T tmin = t11 < tt ? t11 : tt;
+                        bool trig = false, tearl = false;
+                        T len = (T)0;
+                        if (on && !(ca != 0 && cb != 0) && (len2 > tmin * tmin * ((T)1 - filt_slack<T>()))) {   // :268
+                            len = dev_sqrt<T>(len2);                                            // :270
+                            tearl = len > tt;                                                   // :272
+                            trig = len > t11;                                                   // :275
+                        }
+                        const unsigned long long tb = ballot64(trig);
+                        const int gq = tb ? (__ffsll((long long)tb) - 1) >> wsh : WG;            // first correcting group
+                        if (tearl && wgrp <= gq) tear = 1;
                         int moved = 0;
-                        if (on) moved = strain_spring<T>(cur, en, r, k, tear);
-                        st_levels++;
+                        if (trig && wgrp == gq) {
+                            const T ux = dev_div<T>(dx, len), uy = dev_div<T>(dy, len), uz = dev_div<T>(dz, len);   // :276-278
+                            const T extra = len - t11;                                          // :279
+                            const T wa = ca != 0 ? (T)0 : (cb != 0 ? (T)1 : (T)0.5);
+                            const T wb = cb != 0 ? (T)0 : (ca != 0 ? (T)1 : (T)0.5);
+                            const T ea = extra * wa, eb = extra * wb;
+                            if (ca == 0) cur[pa] = Pt<T>{PA.x - ux * ea, PA.y - uy * ea, PA.z - uz * ea, PA.w};
+                            if (cb == 0) cur[pb] = Pt<T>{PB.x + ux * eb, PB.y + uy * eb, PB.z + uz * eb, PB.w};
+                            moved = (ca == 0 ? 1 : 0) | (cb == 0 ? 2 : 0);
+                        }
+                        // done: every level of the pass up to and including the first correcting one
+                        int jq = -1;                             // chunk-relative index of the committing level
+                        if (gq < WG) {
+                            jq = __builtin_amdgcn_readlane(myj, gq << wsh);
+                            need &= ~(taken & ((2ull << jq) - 1ull));
+                        } else need &= ~taken;
+                        st_levels += gq < WG ? gq + 1 : (int)__popcll(taken);
                         unsigned long long mm = ballot64(moved != 0);
                         st_trig += mm ? 1 : 0;
 #ifdef CLOTHHIP_SWEEP_STAMPS
@@ -1000,7 +1043,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                             // read ONE entry of the incident-level table of ptA (12) / ptB (12). Marks inside the
                             // current 64-level chunk are OR-reduced with DPP straight into `need`; marks beyond it
                             // go to LDS flags that the later chunk consumes on entry.
-                            const int Lcur = L0 + j;
+                            const int Lcur = L0 + jq;
                             while (mm) {
                                 const int t1 = __ffsll((long long)mm) - 1;
                                 mm &= mm - 1ull;
@@ -1031,11 +1074,9 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
 #ifdef CLOTHHIP_SWEEP_STAMPS
                         if (timing && did_mark) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts2)::"memory"); tph[9] += ts2 - ts1; }
 #endif
-                        // the next level's lanes read what this level's lanes wrote: same wave, LDS is in order;
-                        // the fences only stop the compiler from moving LDS accesses across the level boundary.
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        // the next level's lanes read what this level's lanes wrote: same wave, LDS operations execute
+                        // in program order; the barrier only pins the compiler's ordering
                         __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     }
                 }
                 if (__any(tear) && lane == 0) misc[0] = 1;

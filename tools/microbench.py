@@ -64,6 +64,9 @@ def main():
             if mask & 32 and st[4 + 10] > 0:      # library built with -DCLOTHHIP_CELL_STAMPS
                 print("    cells phase of wave 0: scan %.0f  small-cell groups %.0f cycles, %.2f small cells/substep" %
                       (st[4 + 10] * 64, st[4 + 11] * 64, st[4 + 9]))
+            if mask & 32 and os.environ.get("CLOTHHIP_SWEEP_STAMPS_LIB"):     # library built with -DCLOTHHIP_SWEEP_STAMPS
+                print("    sparse sweep stamps: marking %.0f  no-op level visits %.0f  correcting level visits %.0f cycles/substep" %
+                      (st[4 + 9] * 64, st[4 + 10] * 64, st[4 + 11] * 64))
             print("%-12s mask %2d: %8.2f us/substep  (%6.2f M substeps/s at E=%d)  per substep: sweeps %.2f dense %.2f levels %.1f corrected %.1f" %
                   (name, mask, ms * 1e3 / args.sub, args.envs * args.sub / ms / 1e3, args.envs, st[0], st[1], st[2], st[3]), flush=True)
             b.close()
