@@ -826,7 +826,9 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                             asm volatile("" : "+v"(g));
                             const Pt<T> nb = cur[g & HK_NBR_MASK];
                             const uint32_t pos_ = (g >> HK_POS_SHIFT) & HK_POS_MASK;
-                            const T r = REST_REG ? rr[REST_REG ? q : 0][sl] : rest[pos_];
+                            T r = REST_REG ? rr[REST_REG ? q : 0][sl] : rest[pos_];
+                            asm volatile("" : "+v"(r));     // or the thresholds below are hoisted out of the substep loop
+                                                            // for all 18 springs and live in scratch
                             const T dx = nb.x - me.x, dy = nb.y - me.y, dz = nb.z - me.z;   // (ptA - ptB), as :270
                             const T len2 = dx * dx + dy * dy + dz * dz;
                             const T t11 = r * k.c11, tt = r * k.tear_thresh;

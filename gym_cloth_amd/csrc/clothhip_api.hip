@@ -280,6 +280,7 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
             if (LdsLayout(tsz, h->Ppad, h->Spad, h->lv.n_levels, h->n_levels8, h->HT, t, 0).total <= budget) { h->tab = t; break; }
         if (const char *t = getenv("CLOTHHIP_DEBUG_TAB_LDS")) h->tab = std::min(h->tab, atoi(t));
         h->rest_reg = (h->nt == 256 && precision == CLOTHHIP_F32 && h->tab == 2);
+        if (const char *t = getenv("CLOTHHIP_DEBUG_REST_REG")) h->rest_reg = h->rest_reg && atoi(t);
         // the cell-ordered record copy for the collision pre-check is taken only if it costs no table tier
         h->cell_copy = LdsLayout(tsz, h->Ppad, h->Spad, h->lv.n_levels, h->n_levels8, h->HT, h->tab, 1).total <= budget ? 1 : 0;
         if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) h->cell_copy = h->cell_copy && atoi(t);

@@ -39,9 +39,9 @@ def test_deterministic_across_envs_and_runs(prec, oracle_lib):
 def test_async_run_and_device_schedule_and_obs(oracle_lib):
     """clothhip_run_async + clothhip_sync, clothhip_run_device_sched_async (schedule table already on the device,
     as after an RCCL broadcast) and clothhip_write_obs_f32_device give the same result as the synchronous path."""
-    import torch
     from gym_cloth_amd import ClothBatch, make_schedules
     from gym_cloth_amd._lib import SCHED_DTYPE
+    from helpers import DeviceBuffer
     g, st = _pull_state(oracle_lib)
     E = 8
     s = make_schedules(E, active=1, break_on_tear=1, n_pull_end=40, n_griprest_end=60, n_total=100,
@@ -53,13 +53,15 @@ def test_async_run_and_device_schedule_and_obs(oracle_lib):
     a.run_async(s); ex_a = a.sync()
     assert np.array_equal(ex_a, ex_ref) and ex_ref[3] == 0 and np.array_equal(a.positions(), pos_ref)
     d = ClothBatch(base_cfg("tier1", 1), n_envs=E, precision="f32"); d.set_state(*st)
-    dev_s = torch.from_numpy(np.frombuffer(s.tobytes(), dtype=np.uint8).copy()).cuda()
-    assert s.dtype == SCHED_DTYPE and dev_s.numel() == 64 * E
-    d.run_device_sched_async(dev_s.data_ptr()); ex_d = d.sync()
+    assert s.dtype == SCHED_DTYPE and s.nbytes == 64 * E
+    dev_s = DeviceBuffer(s.nbytes)                      # the schedule table as a collective would leave it: on the device
+    dev_s.upload(np.frombuffer(s.tobytes(), dtype=np.uint8))
+    d.run_device_sched_async(dev_s.ptr); ex_d = d.sync()
     assert np.array_equal(ex_d, ex_ref) and np.array_equal(d.positions(), pos_ref)
-    obs = torch.empty((E, 3 * 625), dtype=torch.float32, device="cuda")
-    d.write_obs_f32_device(obs.data_ptr()); d.sync(False)
-    assert np.array_equal(obs.cpu().numpy().reshape(E, 625, 3), pos_ref.astype(np.float32))
+    obs = DeviceBuffer(E * 3 * 625 * 4)
+    d.write_obs_f32_device(obs.ptr); d.sync(False)
+    assert np.array_equal(obs.download(np.float32, (E, 625, 3)), pos_ref.astype(np.float32))
+    dev_s.free(); obs.free()
     assert d.last_kernel_ms > 0
     for x in (ref, a, d):
         x.close()
