@@ -430,7 +430,10 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
     const int pm = A.phase_mask;
 
     T pvx[PPT], pvy[PPT], pvz[PPT];         // previous positions of the owned particles
-    uint32_t gt[PPT][HK_SLOTS];             // their incident-spring gather entries (static)
+    // their incident-spring gather entries (static): in registers for fp32; the fp64 instantiation has no room
+    // (they ended up in scratch, reloaded one by one) and re-reads the L2-resident table, 12 loads in flight
+    constexpr bool GT_REG = sizeof(T) == 4;
+    uint32_t gt[GT_REG ? PPT : 1][HK_SLOTS];
     T rr[REST_REG ? PPT : 1][HK_SLOTS];     // and those springs' rest lengths
     {   // HBM -> LDS / registers, coalesced
         const T *gp = A.pos + (size_t)e * 3 * Ppad, *gq = A.prev + (size_t)e * 3 * Ppad;
@@ -444,8 +447,9 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
             pvx[q] = ok ? gq[i] : (T)0; pvy[q] = ok ? gq[Ppad + i] : (T)0; pvz[q] = ok ? gq[2 * Ppad + i] : (T)0;
 #pragma unroll
             for (int sl = 0; sl < HK_SLOTS; sl++) {
-                gt[q][sl] = ok ? A.gather[sl * Ppad + i] : 0u;
-                if (REST_REG) rr[q][sl] = g_rest[(gt[q][sl] >> HK_POS_SHIFT) & HK_POS_MASK];
+                const uint32_t g0 = ok ? A.gather[sl * Ppad + i] : 0u;
+                if (GT_REG) gt[GT_REG ? q : 0][sl] = g0;
+                if (REST_REG) rr[q][sl] = g_rest[(g0 >> HK_POS_SHIFT) & HK_POS_MASK];
             }
         }
         if (TAB >= 1) {
@@ -539,9 +543,12 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                     const Pt<T> me = cur[tid + q * NT];
                     wme[q] = w_cnt(me.w);
                     T fx = (T)0 + (T)0, fy = (T)0 + (T)0, fz = (T)0 + k.mg;
+                    uint32_t gl[HK_SLOTS];
+#pragma unroll
+                    for (int sl = 0; sl < HK_SLOTS; sl++) gl[sl] = GT_REG ? gt[GT_REG ? q : 0][sl] : A.gather[sl * Ppad + tid + q * NT];
 #pragma unroll
                     for (int sl = 0; sl < HK_SLOTS; sl++) {
-                        uint32_t g = gt[q][sl];
+                        uint32_t g = gl[sl];
                         asm volatile("" : "+v"(g));         // opaque: keeps the address math inside the substep loop
                         const Pt<T> nb = cur[g & HK_NBR_MASK];
                         const T r = REST_REG ? rr[REST_REG ? q : 0][sl] : rest[(g >> HK_POS_SHIFT) & HK_POS_MASK];
@@ -820,9 +827,12 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                     if (tid + q * NT < P) {
                         const Pt<T> me = cur[tid + q * NT];
                         const uint32_t cme_ = w_cnt(me.w);
+                        uint32_t gl[HK_SLOTS / 2];
+#pragma unroll
+                        for (int sl = 0; sl < HK_SLOTS / 2; sl++) gl[sl] = GT_REG ? gt[GT_REG ? q : 0][sl] : A.gather[sl * Ppad + tid + q * NT];
 #pragma unroll
                         for (int sl = 0; sl < HK_SLOTS / 2; sl++) {       // own springs come first in ascending list order
-                            uint32_t g = gt[q][sl];
+                            uint32_t g = gl[sl];
                             asm volatile("" : "+v"(g));
                             const Pt<T> nb = cur[g & HK_NBR_MASK];
                             const uint32_t pos_ = (g >> HK_POS_SHIFT) & HK_POS_MASK;
