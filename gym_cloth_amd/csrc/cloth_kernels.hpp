@@ -669,9 +669,6 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                 bool hit[PPT];
 #pragma unroll
                 for (int q = 0; q < PPT; q++) hit[q] = false;
-#ifdef CLOTHHIP_EXP_NOPRE
-                nmax = 0;
-#endif
                 if (A.cell_copy) {
                     constexpr int CU = 2;
                     // a read past the cell's range (another cell's record or the padding behind the array) is masked out
