@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """Kernel micro-benchmark / phase ablation on harvested reference states (dev tool, GPU only).
+Mask bit 32 (e.g. --masks 47) prints per-phase shader-cycle stamps; that needs the profiling build of the library.
 
   python tools/microbench.py [--envs 512] [--precision f32] [--sub 200]
 Regimes: 'rest' (settled cloth, nothing pinned), 'pull' (mid lateral pull, strain limiter busy),
@@ -58,15 +59,15 @@ def main():
             b.update(args.sub, delta=delta)
             ms = b.last_kernel_ms
             st = b.debug_stats()[0] / float(args.sub)
-            if mask & 32:
-                names = ["adjust", "hooke", "insert", "prefix", "fill", "precheck", "cells", "reset+plane", "prepass", "sweep"]
-                print("    cycles/substep: " + "  ".join("%s %.0f" % (n, st[4 + i] * 64) for i, n in enumerate(names)))
-            if mask & 32 and st[4 + 10] > 0:      # library built with -DCLOTHHIP_CELL_STAMPS
-                print("    cells phase of wave 0: scan %.0f  small-cell groups %.0f cycles, %.2f small cells/substep" %
-                      (st[4 + 10] * 64, st[4 + 11] * 64, st[4 + 9]))
-            if mask & 32 and os.environ.get("CLOTHHIP_SWEEP_STAMPS_LIB"):     # library built with -DCLOTHHIP_SWEEP_STAMPS
-                print("    sparse sweep stamps: marking %.0f  no-op level visits %.0f  correcting level visits %.0f cycles/substep" %
-                      (st[4 + 9] * 64, st[4 + 10] * 64, st[4 + 11] * 64))
+            if mask & 32:       # needs the profiling build: make -C gym_cloth_amd/csrc stamps; CLOTHHIP_LIB=.../libclothhip_stamps.so
+                names = ["adjust", "hooke", "insert", "ranges", "fill", "precheck", "cells: wait at barrier", "reset+plane", "prepass"]
+                print("    cycles/substep (wave 0): " + "  ".join("%s %.0f" % (n, st[4 + i] * 64) for i, n in enumerate(names)))
+                if os.environ.get("CLOTHHIP_SWEEP_STAMPS_LIB"):     # library built with -DCLOTHHIP_SWEEP_STAMPS instead of CELL_STAMPS
+                    print("    sparse sweep (wave 0): marking %.0f  passes without a correction %.0f  passes with one %.0f cycles/substep" %
+                          (st[4 + 9] * 64, st[4 + 10] * 64, st[4 + 11] * 64))
+                else:
+                    print("    cells sweep (wave 0): cells over 16 members %.0f  small cells (four per pass) %.0f cycles/substep" %
+                          (st[4 + 10] * 64, st[4 + 11] * 64))
             print("%-12s mask %2d: %8.2f us/substep  (%6.2f M substeps/s at E=%d)  per substep: sweeps %.2f dense %.2f levels %.1f corrected %.1f" %
                   (name, mask, ms * 1e3 / args.sub, args.envs * args.sub / ms / 1e3, args.envs, st[0], st[1], st[2], st[3]), flush=True)
             b.close()
