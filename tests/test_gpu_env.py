@@ -176,3 +176,47 @@ def test_device_metrics_large_grid():
     cov, vinv, oob, tear = b.metrics()
     assert np.allclose(cov, 1.0, atol=1e-6) and (vinv == 1000.0).all() and not oob.any() and not tear.any()
     b.close()
+
+
+def test_bench_workload_action_matches_oracle_f64(oracle_lib):
+    """The benchmarked workload itself (bench.py: tier-1 reset drawn from RandomState(1000+e), one uniformly random
+    pick-and-place per env from RandomState(2000+e)) in fp64: these are the hard cases -- cloths dragged over the
+    floor and out of bounds, hundreds of strain levels correcting per substep, crowded collision cells -- and every
+    env must end bit-identical to the CPU oracle started from the same post-reset state."""
+    import bench
+    from gym_cloth_amd.envs import ClothVecEnv, decode_actions
+    E = 24
+    cfg = bench.bench_cfg(25, 0.02)
+    env = ClothVecEnv(cfg, n_envs=E, precision="f64", consume_domrand_draws=False)
+    for e in range(E):
+        env.np_randoms[e] = np.random.RandomState(1000 + e)
+    env.reset()
+    acts = np.stack([np.random.RandomState(2000 + e).uniform(-1, 1, size=4) for e in range(E)])
+    pos0, prev0, pin0 = env.batch.get_state()
+    env.step(acts)
+    pos1, prev1, pin1 = env.batch.get_state()
+    ex = env.last_executed
+    ev = cfg["env"]
+    d = decode_actions(acts, [-1.] * 4, [1.] * 4, True, True, ev["reduce_factor"], ev["iters_up"], ev["iters_up_rest"],
+                       ev["iters_pull_max"], ev["iters_grip_rest"], ev["iters_rest"])
+    c = cfg["cloth"]
+    ocfg = {"n_side": 25, "width": c["width"], "height": c["height"], "density": c["density"], "ks": c["ks"],
+            "damping": c["damping"], "thickness": c["thickness"], "plane_friction": c["plane_friction"],
+            "tear_thresh": c["tear_thresh"], "frames_per_sec": cfg["frames_per_sec"],
+            "simulation_steps": cfg["simulation_steps"], "gravity": -9.8, "minimum_z": 0.0,
+            "grip_radius": ev["grip_radius"]}
+    busy = 0
+    for e in range(E):
+        oc = oracle_lib.OracleCloth(ocfg)
+        oc.set_state(pos0[e], prev0[e], pin0[e])
+        ng = oc.grab_top(float(d["x"][e]), float(d["y"][e]))
+        n = oc.run_schedule(d["bounds"][e] if ng > 0 else np.zeros(5, dtype=np.int32), 0.0025,
+                            float(d["x_dir_r"][e]), float(d["y_dir_r"][e]), True) if ng > 0 else 0
+        assert n == ex[e], (e, n, ex[e])
+        op, oq, opin = oc.get_state()
+        assert np.array_equal(pos1[e], op) and np.array_equal(prev1[e], oq), (e, float(np.abs(pos1[e] - op).max()))
+        busy += int(n > 0)
+    assert busy >= E // 2
+    st = env.batch.debug_stats()
+    assert st[:, 1].sum() > 0, "the workload must have exercised the dense strain sweep"
+    env.close()
