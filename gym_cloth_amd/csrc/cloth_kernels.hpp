@@ -729,6 +729,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
             // the bpermute broadcasts cost what the pairing saves).
             {
                 const int na = __builtin_amdgcn_readfirstlane(misc[2]);
+                if (na) __builtin_amdgcn_s_setprio(2);     // serial per-cell sweeps: latency-critical like the strain sweep
                 int tkb = -1, tks = -1, bbase = 0, sbase = 0;       // outstanding tickets, tickets used up by earlier chunks
                 for (int c0 = 0; c0 < na; c0 += 64) {
                     const int ei = c0 + lane;
@@ -779,6 +780,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
 #endif
                 }
             }
+            __builtin_amdgcn_s_setprio(0);
             __syncthreads();
             TSTAMP(6)
             for (int t = tid; t < nocc; t += NT) { const int h = (int)olist[t]; hkey[h] = KEY_EMPTY; hco[h] = 0; }   // ready for the next substep
