@@ -2,25 +2,35 @@
 """bench.py -- cloth-substeps/s of the HIP stepper on BASELINE.json's batched workload.
 
 Workload (BASELINE.json configs[2], SURVEY.md 8d "C3"; weak-scaled to configs[3]'s 512 envs per GPU):
-  E = 512 cloths of 25x25 per GPU, tier-1 start (flat grid + two scripted reset pulls drawn per env as in
+  E = 512 cloths of 25x25 per GPU, tier-1 start (flat grid + the scripted reset pulls drawn per env as in
   cloth_env.py:851-877 from RandomState(1000+e)), then one random pick-and-place action per env per step,
-  a ~ U(-1,1)^4 in clip space from RandomState(2000+e), delta actions.
-A "step" = ClothVecEnv.step over the whole batch = Gripper.grab_top + the fused schedule kernel
-(~1430 + iters_pull substeps per env, cloth_env.py:472-515) + metrics.  State is resident in HBM; the timed
-region contains no state upload.  value = executed Cloth.update()-equivalents (all envs, all ranks) / wall time.
+  a ~ U(-1,1)^4 in clip space from RandomState(2000+e), delta actions, EPISODES AS IN THE REFERENCE'S LOOP
+  (examples/analytic.py:872-882): an env whose episode ends (out of bounds, tear, coverage > 0.92, max_actions = 10) is
+  reset and goes on, so every env executes an action in every step.
+A "step" = ClothEnv.step for every env of the batch = decode + Gripper.grab_top + the substep loop
+(~1430 + iters_pull Cloth.update() per env, cloth_env.py:472-515) + metrics + terminal test.
 
-`--init tier2` starts every env from the reference's tier-2 reset instead (BASELINE configs[3] names it; the default
-keeps ONE workload at every GPU count so that the per-N values are comparable).
+Two execution modes (both reported; `value` is the fused one unless --mode step):
+  fused  ClothVecEnv.step_many: T steps per kernel launch (clothhip_run_actions), episode resets INSIDE the launch
+         (their Cloth.update() calls are executed by the same kernel, inside the timed region, and are counted),
+         envs never wait for each other.
+  step   ClothVecEnv.step: one launch sequence per step (grab, schedule kernel, metrics), the clock is STOPPED around the
+         host-driven episode resets between steps (SURVEY 8d excludes reset from the timed region).
+value = executed Cloth.update()-equivalents of all envs and ranks / timed wall time. State is resident in HBM; the timed
+region contains no state upload.
 
-Multi-GPU (one process per GPU, torch.distributed 'nccl' = RCCL over xGMI): env blocks are sharded, rank 0's
-action table is broadcast every step and per-env results are all-gathered; there is no other collective
-because cloths never interact.
+Multi-GPU: one process per GPU (launched by the driver with torch.distributed.run, or by this script itself with
+--gpus N when no launcher environment is present); env blocks are sharded, rank 0's action table is broadcast and the
+per-env results are all-gathered with RCCL bound directly through ctypes (gym_cloth_amd/rccl.py) -- no torch.
+Cloths never interact, so there is no other collective.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
+import math
 import os
+import subprocess
 import sys
 import time
 
@@ -49,8 +59,8 @@ def bench_cfg(n_side, thickness, tier="tier1"):
 
 def cpu_baseline(cfg, acts0, states, budget_s=15.0):
     """The CPU oracle (oracle/, exact-order fp64 C port of the reference) timed on this box's host cores on a
-    bounded sample of the SAME workload: the first timed bench step of the first n envs, started from the very
-    cloth states the GPU path started that step from (downloaded before the timed region)."""
+    bounded sample of the SAME workload: one bench action of the first n envs, started from the very cloth states the
+    GPU path held at the start of the timed region (downloaded before it)."""
     from oracle import pyoracle
     pyoracle.build()
     cores = len(os.sched_getaffinity(0))
@@ -89,131 +99,232 @@ def cpu_baseline(cfg, acts0, states, budget_s=15.0):
     ex1 = oc.run_schedule(sched[k1], 0.0025, float(d["x_dir_r"][k1]), float(d["y_dir_r"][k1]), True)
     dt1 = time.perf_counter() - t1
     return {"value": float(ex.sum() / dt), "unit": "cloth-substeps/s", "cores": int(threads), "kind": "port",
-            "sample": "first timed step of the first %d envs (same start states and actions as the GPU run, %d substeps "
-                      "in total), OpenMP one cloth per thread" % (n, int(ex.sum())),
+            "sample": "one bench action of the first %d envs (start states and actions of the first timed step of the GPU "
+                      "run, %d substeps in total), OpenMP one cloth per thread" % (n, int(ex.sum())),
             "single_core_value": float(ex1 / dt1) if dt1 > 0 and ex1 > 0 else None}
+
+
+def pick_fuse(steps, warmup, fuse_max):
+    """steps per launch in fused mode: the largest T <= fuse_max that divides both the timed and the warm-up step count."""
+    for t in range(max(1, fuse_max), 0, -1):
+        if steps % t == 0 and warmup % t == 0:
+            return t
+    return 1
+
+
+def load_traffic(mode, E, n_side, precision, fuse):
+    """HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/r02_traffic.json, produced by
+    tools/collect_profiles.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950
+    correction of MI355X_MICROARCH.md). None when no record matches this configuration."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as fh:
+            for r in json.load(fh)["records"]:
+                if (r["mode"], r["envs"], r["n_side"], r["precision"], r.get("fuse", 1)) == (mode, E, n_side, precision, fuse):
+                    return r["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
+def run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, rank, world, local_rank, thickness=None,
+                 want_cpu=False):
+    """One bench configuration on this rank's GPU; returns the result record (rank 0) or None."""
+    from gym_cloth_amd.dist import LocalTransport, RcclTransport, StepExchange
+    from gym_cloth_amd.envs import ClothVecEnv
+    thickness = thickness if thickness is not None else (0.02 if n_side <= 25 else 0.0095)
+    cfg = bench_cfg(n_side, thickness, init)
+    env = ClothVecEnv(cfg, n_envs=E, device=local_rank, precision=precision, consume_domrand_draws=False)
+    xch = StepExchange(E, RcclTransport(rank, world, env.batch) if world > 1 else LocalTransport())
+    g0 = rank * E                                            # first global env index of this rank
+    for e in range(E):                                       # SURVEY 8d: reset draws from RandomState(1000+e)
+        env.np_randoms[e] = np.random.RandomState(1000 + g0 + e)
+    env.reset()
+    P = env.P
+    fuse = 1
+    if mode == "fused":
+        fuse = pick_fuse(steps, warmup, fuse_max)
+        if not env.batch.fused_supported:                    # grid too large for the in-kernel metrics: report the step mode
+            if rank == 0:
+                print("bench: fused mode unavailable for %dx%d; using step mode" % (n_side, n_side), file=sys.stderr)
+            mode, fuse = "step", 1
+    total = warmup + steps
+    acts_all = None
+    if rank == 0:                                            # actions for ALL envs of the job, RandomState(2000+e)
+        acts_all = np.stack([np.random.RandomState(2000 + e).uniform(-1, 1, size=(total, 4))
+                             for e in range(world * E)], axis=1)          # [total, world*E, 4]
+
+    def fence():
+        env.batch.sync(False)
+        xch.barrier()                                        # RCCL all-reduce on the handle's stream + stream sync
+        env.batch.sync(False)
+
+    stat = {"sub": 0, "act_sub": 0, "kms": 0.0, "launches": 0, "ran": 0, "slots": 0, "resets": 0}
+    cpu_states = None
+    t_timed = 0.0
+    if mode == "step":
+        auto_reset_host = init in ("tier1", "tier2", "tier3")
+        for t in range(total):
+            a = xch.broadcast_actions(acts_all[t] if rank == 0 else None)
+            if t == warmup and want_cpu and rank == 0:
+                cpu_states = env.batch.get_state(0, min(E, 512))
+            fence()
+            t0 = time.perf_counter()
+            obs, rew, done, info = env.step(a)
+            xch.gather_results(rew, done, info["actual_coverage"], env.last_executed)
+            fence()
+            dt = time.perf_counter() - t0
+            if t >= warmup:
+                t_timed += dt
+                s = int(env.last_executed.sum())
+                stat["sub"] += s; stat["act_sub"] += s; stat["kms"] += env.batch.last_kernel_ms; stat["launches"] += 1
+                stat["ran"] += int((env.last_executed > 0).sum()); stat["slots"] += E
+            if auto_reset_host and done.any():               # the reference's episode loop; clock stopped (SURVEY 8d)
+                stat["resets"] += int(done.sum()) if t >= warmup else 0
+                env.reset(mask=done)
+    else:
+        n_warm, n_timed = warmup // fuse, steps // fuse
+        for w in range(n_warm + n_timed):
+            tbl = xch.broadcast_actions(acts_all[w * fuse:(w + 1) * fuse] if rank == 0 else None, n_actions=fuse)
+            if w == n_warm:
+                if want_cpu and rank == 0:
+                    cpu_states = env.batch.get_state(0, min(E, 512))
+                fence()
+                t0 = time.perf_counter()
+            out = env.step_many(tbl, auto_reset=True)
+            xch.gather_results(out["rew"][-1], out["done"][-1], out["actual_coverage"][-1], out["executed"].sum(axis=0))
+            if w >= n_warm:
+                a_sub, r_sub = int(out["executed"].sum()), int(out["reset_substeps"].sum())
+                stat["sub"] += a_sub + r_sub; stat["act_sub"] += a_sub
+                stat["kms"] += env.batch.last_kernel_ms; stat["launches"] += 1
+                stat["ran"] += int((out["executed"] > 0).sum()); stat["slots"] += fuse * E
+                stat["resets"] += int((out["reset_before"] > 0).sum())
+        fence()
+        t_timed = time.perf_counter() - t0
+    dt = xch.max_over_ranks(t_timed)
+    n_sub_all = xch.sum_over_ranks(stat["sub"])
+    n_act_all = xch.sum_over_ranks(stat["act_sub"])
+    rec = None
+    if rank == 0:
+        b_alg = 49 * P                                        # SURVEY 8d: algorithmic bytes per cloth-substep (fp32)
+        ach = (stat["sub"] * b_alg / 1e9) / (stat["kms"] / 1e3) if stat["kms"] > 0 else 0.0
+        rec = {
+            "value": n_sub_all / dt, "ms_per_step": dt / steps * 1e3, "dtype": precision,
+            "config": {"workload": "%d batched %dx%d cloths per GPU, %s start, random pick-and-place actions, episodes "
+                                   "reset as in the reference's loop (BASELINE configs[2]; configs[3] = 8 x this)"
+                                   % (E, n_side, n_side, init.replace("tier", "tier-")),
+                       "mode": "fused: %d steps per launch, episode resets inside the launch (counted)" % fuse
+                               if mode == "fused" else "step: one launch sequence per step, clock stopped around host-driven resets",
+                       "envs_per_gpu": E, "n_side": n_side, "init": init, "exact_order": True, "steps_per_launch": fuse,
+                       "env_steps_per_s": world * E * steps / dt,
+                       "substeps_per_env_step": n_sub_all / (world * E * steps),
+                       "action_substeps_per_s": n_act_all / dt,
+                       "active_env_frac": stat["ran"] / max(stat["slots"], 1),
+                       "episode_resets_in_timed_region": stat["resets"]},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": load_traffic(mode, E, n_side, precision, fuse),
+                         "kernel": "k_run_schedule", "kernel_ms_avg": stat["kms"] / max(stat["launches"], 1),
+                         "launches": stat["launches"], "alg_bytes_per_substep": b_alg,
+                         "substeps_per_launch": stat["sub"] / max(stat["launches"], 1)},
+        }
+        if want_cpu and cpu_states is not None:
+            rec["cpu_baseline"] = cpu_baseline(cfg, acts_all[warmup][:len(cpu_states[0])], cpu_states)
+    xch.barrier()
+    xch.t.close()
+    env.close()
+    return rec
+
+
+def self_launch(args):
+    """--gpus N without a launcher environment: start one child process per GPU (fresh processes: nothing in THIS process
+    has touched the GPU, and no process is ever replaced by exec), relay rank 0's JSON line."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    rdzv = os.path.join(os.environ.get("TMPDIR", "/tmp"), "clothhip_rccl_%d_%d.id" % (port, os.getpid()))
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), CLOTHHIP_RDZV_FILE=rdzv, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = max(rc, p.wait())
+    sys.stdout.write(out0.decode())
+    return rc
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--envs", type=int, default=512, help="cloths per GPU")
     ap.add_argument("--n-side", type=int, default=25)
     ap.add_argument("--thickness", type=float, default=None)
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
     ap.add_argument("--init", default="tier1", choices=["tier1", "tier2", "tier3"],
-                    help="start state of every env (BASELINE configs[3] names tier2; reset draws come from RandomState(1000+e))")
-    ap.add_argument("--gather-obs", action="store_true", help="all-gather the '1d' observations every step")
+                    help="start state of every env (reset draws come from RandomState(1000+e))")
+    ap.add_argument("--mode", default="fused", choices=["fused", "step"])
+    ap.add_argument("--fuse", type=int, default=5, help="fused mode: at most this many steps per launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the companion records (f64, step mode, tier-2, 50x50, 2048 cloths)")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:     # launched by torch.distributed.run: one rank per GPU
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    from gym_cloth_amd.envs import ClothVecEnv
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    from gym_cloth_amd.dist import env_from_launcher
+    rank, local_rank, world = env_from_launcher()
+    if args.gpus > 1 and world != args.gpus and rank == 0:
+        print("bench: --gpus %d but the launcher started %d ranks; using %d" % (args.gpus, world, world), file=sys.stderr)
 
-    E = args.envs
-    thickness = args.thickness if args.thickness is not None else (0.02 if args.n_side <= 25 else 0.0095)
-    cfg = bench_cfg(args.n_side, thickness, args.init)
-    env = ClothVecEnv(cfg, n_envs=E, device=local_rank, precision=args.precision, consume_domrand_draws=False)
-    g0 = rank * E                                            # first global env index of this rank
-    for e in range(E):                                       # reset draws from RandomState(1000+e)
-        env.np_randoms[e] = np.random.RandomState(1000 + g0 + e)
-    env.reset()
-    total_steps = args.warmup + args.steps
-    P = env.P
-    if rank == 0:                                            # actions for ALL envs of the job, RandomState(2000+e)
-        acts_all = np.stack([np.random.RandomState(2000 + e).uniform(-1, 1, size=(total_steps, 4))
-                             for e in range(world * E)], axis=1)          # [steps, world*E, 4]
-    else:
-        acts_all = None
-
-    from gym_cloth_amd.dist import StepExchange
-    if dist is not None:
-        import torch
-        dev = torch.device("cuda", local_rank)
-    else:
-        dev = None
-    xch = StepExchange(E, obs_dim=(3 * P if args.gather_obs else 0), device=dev) if dist is not None else None
-
-    def one_step(t):
-        # RCCL broadcast of the action table (rank 0 -> all), each rank keeps its env block
-        a = xch.broadcast_actions(acts_all[t] if rank == 0 else None) if xch else acts_all[t]
-        obs, rew, done, info = env.step(a)
-        kms = env.batch.last_kernel_ms
-        if xch:
-            xch.gather_results(rew, done, info["actual_coverage"], env.last_executed)   # RCCL all-gather
-            if args.gather_obs:
-                env.batch.write_obs_f32_device(xch.obs_loc.data_ptr())
-                env.batch.sync(False)
-                xch.gather_obs()
-        return int(env.last_executed.sum()), kms
-
-    def fence():
-        env.batch.sync(False)
-        if dist is not None:
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for t in range(args.warmup):
-        one_step(t)
-    fence()
-    cpu_states = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # start states of the first timed step (untimed copy)
-        ncpu = min(E, 512)
-        cpu_states = env.batch.get_state(0, ncpu)
-        fence()
-    t0 = time.perf_counter()
-    n_sub, k_ms, k_sub = 0, 0.0, 0
-    for t in range(args.warmup, total_steps):
-        s, kms = one_step(t)
-        n_sub += s
-        k_ms += kms
-        k_sub += s
-    fence()
-    dt = time.perf_counter() - t0
-    if xch:
-        dt = xch.max_over_ranks(dt)
-        n_sub_all = xch.sum_over_ranks(n_sub)
-    else:
-        n_sub_all = float(n_sub)
-
+    head = run_workload(args.n_side, args.envs, args.precision, args.init, args.mode, args.steps, args.warmup, args.fuse,
+                        rank, world, local_rank, thickness=args.thickness,
+                        want_cpu=(world == 1 and not args.no_cpu_baseline))
+    extra = []
+    if world == 1 and not args.no_extra:
+        def companion(label, **kw):
+            t0 = time.perf_counter()
+            try:
+                r = run_workload(**kw)
+            except Exception as exc:                         # a companion must never cost the headline
+                r = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            r["label"], r["wall_s"] = label, time.perf_counter() - t0
+            extra.append(r)
+        k5 = dict(rank=0, world=1, local_rank=local_rank, fuse_max=args.fuse)
+        other = "f64" if args.precision == "f32" else "f32"
+        companion("same workload, %s instantiation%s" % (other, " (bit-exact vs the reference)" if other == "f64" else ""),
+                  n_side=args.n_side, E=args.envs, precision=other, init=args.init, mode=args.mode, steps=5, warmup=5, **k5)
+        companion("same workload, the other execution mode", n_side=args.n_side, E=args.envs, precision=args.precision,
+                  init=args.init, mode="step" if args.mode == "fused" else "fused", steps=10, warmup=5, **k5)
+        if args.init != "tier2":
+            companion("BASELINE configs[3] shape: tier-2 start, 512 cloths per GPU (per-env rest tables; resets on the host)",
+                      n_side=25, E=512, precision=args.precision, init="tier2", mode="step", steps=5, warmup=1, **k5)
+        if args.envs < 2048 and args.n_side == 25:
+            companion("2048 cloths per GPU (4 resident generations of workgroups per launch)", n_side=25, E=2048,
+                      precision=args.precision, init="tier1", mode="fused", steps=5, warmup=5, **k5)
+        if args.n_side == 25:
+            companion("BASELINE configs[4]: 50x50 x 1024 cloths, thickness 0.0095", n_side=50, E=1024,
+                      precision=args.precision, init="tier1", mode="fused", steps=2, warmup=0, want_cpu=not args.no_cpu_baseline,
+                      **k5)
     if rank == 0:
-        b_alg = 49 * P                                        # algorithmic bytes per cloth-substep (fp32)
-        ach = (k_sub * b_alg / 1e9) / (k_ms / 1e3) if k_ms > 0 else 0.0
         out = {
             "metric": "cloth substeps/sec (25x25 grid, batched envs)" if args.n_side == 25 else
                       "cloth substeps/sec (%dx%d grid, batched envs)" % (args.n_side, args.n_side),
-            "value": n_sub_all / dt, "unit": "cloth-substeps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "value": head["value"], "unit": "cloth-substeps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "%d batched %dx%d cloths per GPU, %s start, random pick-and-place actions "
-                                   "(BASELINE configs[2]; configs[3] = 8 x this)" % (E, args.n_side, args.n_side,
-                                                                                    args.init.replace("tier", "tier-")),
-                       "envs_per_gpu": E, "n_side": args.n_side, "exact_order": True,
-                       "env_steps_per_s": world * E * args.steps / dt,
-                       "substeps_per_env_step": n_sub_all / (world * E * args.steps)},
-            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_run_schedule", "kernel_ms_avg": k_ms / max(args.steps, 1),
-                         "alg_bytes_per_substep": b_alg},
+            "config": head["config"], "roofline": head["roofline"],
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, acts_all[args.warmup], cpu_states)
+        if "cpu_baseline" in head:
+            out["cpu_baseline"] = head["cpu_baseline"]
+        if extra:
+            out["config"]["extra"] = extra
+            f64 = next((r for r in extra if r.get("dtype") == "f64" and "value" in r), None)
+            if f64:
+                out["f64"] = {"value": f64["value"], "ms_per_step": f64["ms_per_step"], "frac": f64["roofline"]["frac"],
+                              "note": "the bit-exact instantiation on the same workload (%d timed steps)" % 5}
         print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    env.close()
 
 
 if __name__ == "__main__":

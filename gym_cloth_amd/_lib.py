@@ -4,7 +4,6 @@ The HIP library is the ONLY compute path of this package: there is no CPU fallba
 is missing, or no HIP device is visible, the calls below raise -- loudly -- instead of degrading.
 """
 import ctypes as C
-import importlib.util
 import os
 
 import numpy as np
@@ -14,6 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CLOTHHIP_LIB") or os.path.join(_HERE, "libclothhip.so")
 
 F64, F32 = 0, 1
+REST_SHARED, KEEP_TEAR = 1, 2           # clothhip_set_state flags
+ABI_VERSION = 2
 
 OK, EINVAL, ENODEV, EHIP, ENOMEM, ESTATE = 0, -1, -2, -3, -4, -5
 
@@ -43,6 +44,33 @@ SCHED_DTYPE = np.dtype([("n_up_end", "<i4"), ("n_uprest_end", "<i4"), ("n_pull_e
                         ("dy_pull", "<f8"), ("dz_pull", "<f8")])
 assert SCHED_DTYPE.itemsize == C.sizeof(ClothSchedule) == 64
 
+
+
+class ClothEpisodeParams(C.Structure):
+    _fields_ = [("max_actions", C.c_int32), ("iters_up_rest", C.c_int32), ("iters_grip_rest", C.c_int32),
+                ("iters_rest", C.c_int32), ("clip_act_space", C.c_int32), ("force_grab", C.c_int32),
+                ("_pad", C.c_int32 * 2), ("iters_up", C.c_double), ("reduce_factor", C.c_double),
+                ("grip_radius", C.c_double), ("radius_inc", C.c_double), ("dz_up", C.c_double),
+                ("act_low", C.c_double * 4), ("act_high", C.c_double * 4), ("coverage_done", C.c_double)]
+
+
+POLICY_TABLE, POLICY_ORACLE_CORNER = 0, 1
+
+RESET_PULL_DTYPE = np.dtype([("point", "<i4"), ("need_coverage", "<i4"), ("x", "<f8"), ("y", "<f8"), ("dx", "<f8"),
+                             ("dy", "<f8"), ("iters_up", "<f8"), ("coverage_min", "<f8")])
+RESET_SCRIPT_DTYPE = np.dtype([("valid", "<i4"), ("n_pulls", "<i4"), ("settle_after", "<i4"), ("_pad", "<i4"),
+                               ("pull", RESET_PULL_DTYPE, (3,))])
+STEP_RECORD_DTYPE = np.dtype([("action", "<f8", (4,)), ("coverage", "<f8"), ("variance_inv", "<f8"),
+                              ("executed", "<i4"), ("n_grabbed", "<i4"), ("iters_pull", "<i4"),
+                              ("n_below_half_thickness", "<i4"), ("ran", "u1"), ("oob", "u1"), ("tear", "u1"),
+                              ("done", "u1"), ("reset_before", "u1"), ("_pad", "u1", (3,))])
+RESET_RECORD_DTYPE = np.dtype([("consumed", "<i4"), ("pulls_run", "<i4"), ("executed", "<i4", (3,)),
+                               ("settle_executed", "<i4"), ("tear", "<i4"), ("_pad", "<i4"),
+                               ("start_coverage", "<f8"), ("start_variance_inv", "<f8"), ("action", "<f8", (3, 4))])
+assert RESET_PULL_DTYPE.itemsize == 56 and RESET_SCRIPT_DTYPE.itemsize == 184
+assert STEP_RECORD_DTYPE.itemsize == 72 and RESET_RECORD_DTYPE.itemsize == 144
+assert C.sizeof(ClothEpisodeParams) == 144
+
 # every symbol include/clothhip.h declares: (name, restype, argtypes)
 _vp, _dp, _u8p, _i32p = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
 _PP = C.POINTER(ClothParams)
@@ -60,6 +88,8 @@ SYMBOLS = [
     ("clothhip_spring_topology", C.c_int, [_PP, _i32p, _i32p, _u8p]),
     ("clothhip_set_state", C.c_int, [_vp, C.c_int32, C.c_int32, _dp, _dp, _u8p, _dp, C.c_int32]),
     ("clothhip_get_state", C.c_int, [_vp, C.c_int32, C.c_int32, _dp, _dp, _u8p]),
+    ("clothhip_get_rest", C.c_int, [_vp, C.c_int32, C.c_int32, _dp]),
+    ("clothhip_reset_flat", C.c_int, [_vp, _u8p]),
     ("clothhip_get_tear", C.c_int, [_vp, _u8p]),
     ("clothhip_set_tear", C.c_int, [_vp, _u8p]),
     ("clothhip_grab_top", C.c_int, [_vp, _dp, _dp, _u8p, _i32p]),
@@ -69,11 +99,19 @@ SYMBOLS = [
     ("clothhip_run", C.c_int, [_vp, _vp, _i32p]),
     ("clothhip_run_async", C.c_int, [_vp, _vp]),
     ("clothhip_sync", C.c_int, [_vp, _i32p]),
+    ("clothhip_fused_supported", C.c_int, [_vp]),
+    ("clothhip_run_actions", C.c_int, [_vp, C.POINTER(ClothEpisodeParams), C.c_int32, C.c_int32, _vp, C.c_int32, _i32p, _vp,
+                                       _i32p, _u8p, _vp, _vp, _vp, _vp]),
     ("clothhip_update", C.c_int, [_vp, C.c_int32, _dp]),
     ("clothhip_metrics", C.c_int, [_vp, _dp, _dp, _u8p, _u8p]),
+    ("clothhip_metrics_ex", C.c_int, [_vp, _dp, _dp, _u8p, _u8p, _i32p]),
     ("clothhip_hull_area", C.c_double, [_dp, C.c_int32]),
     ("clothhip_write_obs_f32_device", C.c_int, [_vp, _vp]),
     ("clothhip_run_device_sched_async", C.c_int, [_vp, _vp]),
+    ("clothhip_device_alloc", C.c_int, [_vp, C.c_uint64, C.POINTER(_vp)]),
+    ("clothhip_device_free", C.c_int, [_vp, _vp]),
+    ("clothhip_device_upload", C.c_int, [_vp, _vp, _vp, C.c_uint64]),
+    ("clothhip_device_download", C.c_int, [_vp, _vp, _vp, C.c_uint64]),
     ("clothhip_stream", _vp, [_vp]),
     ("clothhip_last_kernel_ms", C.c_double, [_vp]),
     ("clothhip_debug_stats", C.c_int, [_vp, _i32p]),
@@ -81,30 +119,6 @@ SYMBOLS = [
 ]
 
 _lib = None
-
-
-def _preload_shared_hip_runtime():
-    """One HIP runtime per process. PyTorch-ROCm wheels bundle their own libamdhip64/libhsa-runtime64 and ask for
-    them by file name, so if the system ROCm copy gets loaded first (by libclothhip.so), a later `import torch`
-    brings in a SECOND runtime that cannot see the GPU. When torch is installed, load its bundled runtime first
-    (no `import torch`): libclothhip's NEEDED libamdhip64.so.7 then binds to that same copy by SONAME. torch is
-    only the transport for the multi-GPU collectives (dist.py); without it the system ROCm runtime is used."""
-    if os.environ.get("CLOTHHIP_SYSTEM_HIP"):
-        return
-    try:
-        spec = importlib.util.find_spec("torch")
-    except (ImportError, ValueError):
-        spec = None
-    if not spec or not spec.submodule_search_locations:
-        return
-    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
-    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
-        path = os.path.join(libdir, name)
-        if os.path.exists(path):
-            try:
-                C.CDLL(path, mode=C.RTLD_GLOBAL)
-            except OSError:
-                return
 
 
 def load():
@@ -116,7 +130,6 @@ def load():
         raise ClothHipError(
             "libclothhip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C gym_cloth_amd/csrc`. There is no CPU fallback." % LIB_PATH)
-    _preload_shared_hip_runtime()
     try:
         L = C.CDLL(LIB_PATH)
     except OSError as e:
@@ -125,8 +138,8 @@ def load():
         fn = getattr(L, name)          # AttributeError here = header/library mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
-    if L.clothhip_abi_version() != 1:
-        raise ClothHipError("libclothhip ABI version %d, expected 1" % L.clothhip_abi_version())
+    if L.clothhip_abi_version() != ABI_VERSION:
+        raise ClothHipError("libclothhip ABI version %d, expected %d" % (L.clothhip_abi_version(), ABI_VERSION))
     _lib = L
     return L
 

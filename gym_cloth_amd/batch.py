@@ -80,7 +80,10 @@ class ClothBatch(object):
         return a, b, t
 
     # ---- state -----------------------------------------------------------------------------------------
-    def set_state(self, pos=None, prev=None, pinned=None, rest=None, env0=0, n=None, rest_shared=None):
+    def set_state(self, pos=None, prev=None, pinned=None, rest=None, env0=0, n=None, rest_shared=None,
+                  keep_tear=False):
+        """Upload state of envs [env0, env0+n). keep_tear: a write into a live cloth (the reference's tear flag is
+        sticky, cloth.pyx:272-273); without it the call is the Cloth(...) rebuild of a reset and clears the flag."""
         n = self.E - env0 if n is None else n
         f = lambda a, shp: None if a is None else np.ascontiguousarray(
             np.broadcast_to(np.asarray(a, dtype=np.float64), shp))
@@ -92,8 +95,21 @@ class ClothBatch(object):
             if rest_shared is None:
                 rest_shared = rest.ndim == 1
             rest = np.ascontiguousarray(rest if rest_shared else np.broadcast_to(rest, (n, self.S)))
+        flags = (_lib.REST_SHARED if rest_shared else 0) | (_lib.KEEP_TEAR if keep_tear else 0)
         check(self._L.clothhip_set_state(self._h, env0, n, _lib.dp(pos), _lib.dp(prev), _lib.u8p(pin),
-                                         _lib.dp(rest), int(bool(rest_shared))))
+                                         _lib.dp(rest), flags))
+
+    def get_rest(self, env0=0, n=None):
+        """Spring.rest_length per env in reference list order, [n, S]."""
+        n = self.E - env0 if n is None else n
+        rest = np.empty((n, self.S))
+        check(self._L.clothhip_get_rest(self._h, env0, n, _lib.dp(rest)))
+        return rest
+
+    def reset_flat(self, mask=None):
+        """Cloth(...) rebuild of the flat tiers (1, 3) on the device for the masked envs (None = all)."""
+        m = None if mask is None else np.ascontiguousarray(np.broadcast_to(np.asarray(mask, dtype=np.uint8), (self.E,)))
+        check(self._L.clothhip_reset_flat(self._h, _lib.u8p(m)))
 
     def get_state(self, env0=0, n=None, want_prev=True, want_pinned=True):
         n = self.E - env0 if n is None else n
@@ -117,12 +133,17 @@ class ClothBatch(object):
         t = np.ascontiguousarray(np.broadcast_to(np.asarray(v, dtype=np.uint8), (self.E,)))
         check(self._L.clothhip_set_tear(self._h, _lib.u8p(t)))
 
-    def metrics(self):
+    def metrics(self, want_height=False):
         """(coverage[E], variance_inv[E], out_of_bounds[E], tear[E]) as ClothEnv computes them
-        (cloth_env.py:1020-1098)."""
+        (cloth_env.py:1020-1098); with want_height also the 'height' reward's fraction of points with
+        z < thickness/2 (cloth_env.py:603-609)."""
         cov = np.empty(self.E); vinv = np.empty(self.E)
         oob = np.empty(self.E, dtype=np.uint8); tear = np.empty(self.E, dtype=np.uint8)
-        check(self._L.clothhip_metrics(self._h, _lib.dp(cov), _lib.dp(vinv), _lib.u8p(oob), _lib.u8p(tear)))
+        nlow = np.empty(self.E, dtype=np.int32) if want_height else None
+        check(self._L.clothhip_metrics_ex(self._h, _lib.dp(cov), _lib.dp(vinv), _lib.u8p(oob), _lib.u8p(tear),
+                                          _lib.i32p(nlow)))
+        if want_height:
+            return cov, vinv, oob.astype(bool), tear.astype(bool), nlow / float(self.P)
         return cov, vinv, oob.astype(bool), tear.astype(bool)
 
     # ---- gripper ---------------------------------------------------------------------------------------
@@ -172,6 +193,44 @@ class ClothBatch(object):
         check(self._L.clothhip_sync(self._h, _lib.i32p(ex)))
         return ex
 
+    @property
+    def fused_supported(self):
+        return bool(check(self._L.clothhip_fused_supported(self._h)))
+
+    def run_actions(self, ep, n_actions, num_steps, done, actions=None, policy=None, policy_arg=None, scripts=None,
+                    want_resets=True, want_obs=False, actions_device_ptr=None):
+        """clothhip_run_actions: `n_actions` whole ClothEnv.step calls per env in one launch (see include/clothhip.h).
+        ep: _lib.ClothEpisodeParams; num_steps int32[E] and done uint8[E] are updated in place.
+        Returns (records[T, E], resets[E, 2] or None, obs float32[T, E, 3P] or None, reset_obs float32[E, 2, 3P] or
+        None: the first observation of every episode started inside the launch)."""
+        T = int(n_actions)
+        pol = _lib.POLICY_TABLE if policy is None else int(policy)
+        on_dev = 0
+        ap = None
+        if pol == _lib.POLICY_TABLE:
+            if actions_device_ptr is not None:
+                ap, on_dev = C.c_void_p(int(actions_device_ptr)), 1
+            else:
+                actions = np.ascontiguousarray(actions, dtype=np.float64)
+                if actions.shape != (T, self.E, 4):
+                    raise ValueError("actions must have shape (%d, %d, 4)" % (T, self.E))
+                ap = actions.ctypes.data_as(C.c_void_p)
+        assert num_steps.dtype == np.int32 and num_steps.shape == (self.E,) and num_steps.flags['C_CONTIGUOUS']
+        assert done.dtype == np.uint8 and done.shape == (self.E,) and done.flags['C_CONTIGUOUS']
+        parg = None if policy_arg is None else np.ascontiguousarray(policy_arg, dtype=np.int32)
+        if scripts is not None:
+            scripts = np.ascontiguousarray(scripts, dtype=_lib.RESET_SCRIPT_DTYPE)
+            if scripts.shape != (self.E, 3):
+                raise ValueError("scripts must have shape (%d, 3)" % self.E)
+        rec = np.zeros((T, self.E), dtype=_lib.STEP_RECORD_DTYPE)
+        rst = np.zeros((self.E, 2), dtype=_lib.RESET_RECORD_DTYPE) if (want_resets and scripts is not None) else None
+        obs = np.empty((T, self.E, 3 * self.P), dtype=np.float32) if want_obs else None
+        robs = np.empty((self.E, 2, 3 * self.P), dtype=np.float32) if (want_obs and scripts is not None) else None
+        vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        check(self._L.clothhip_run_actions(self._h, C.byref(ep), T, pol, ap, on_dev, _lib.i32p(parg), vp(scripts),
+                                           _lib.i32p(num_steps), _lib.u8p(done), vp(rec), vp(rst), vp(obs), vp(robs)))
+        return rec, rst, obs, robs
+
     def update(self, n=1, delta=None):
         """n x Cloth.update() (cloth.pyx:169), each preceded by Gripper.adjust(*delta) if delta is given."""
         d = None if delta is None else np.ascontiguousarray(delta, dtype=np.float64)
@@ -198,3 +257,20 @@ class ClothBatch(object):
     @property
     def stream(self):
         return self._L.clothhip_stream(self._h)
+
+    def device_alloc(self, nbytes):
+        p = C.c_void_p()
+        check(self._L.clothhip_device_alloc(self._h, int(nbytes), C.byref(p)))
+        return p.value
+
+    def device_free(self, ptr):
+        check(self._L.clothhip_device_free(self._h, C.c_void_p(ptr)))
+
+    def device_upload(self, ptr, arr):
+        a = np.ascontiguousarray(arr)
+        check(self._L.clothhip_device_upload(self._h, C.c_void_p(ptr), a.ctypes.data_as(C.c_void_p), a.nbytes))
+
+    def device_download(self, out, ptr):
+        assert out.flags['C_CONTIGUOUS']
+        check(self._L.clothhip_device_download(self._h, out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), out.nbytes))
+        return out

@@ -44,6 +44,39 @@ template <typename T> struct DevConsts {
     T c11;             // 1.1                                    cloth.pyx:275
 };
 
+template <typename T> struct FusedArgs {
+    int32_t nT, policy, NS, NH;       // action slots per launch, CLOTHHIP_POLICY_*, metrics sort / hull buffer sizes
+    const double *actions;            // [nT][E][4]
+    const int32_t *policy_arg;        // [E] or nullptr
+    const ClothResetScript *scripts;  // [E][3] or nullptr
+    int32_t *num_steps;               // [E]
+    uint8_t *done;                    // [E]
+    ClothStepRecord *records;         // [nT][E]
+    ClothResetRecord *resets;         // [E][2] or nullptr
+    float *obs;                       // [nT][E][3P] or nullptr
+    float *reset_obs;                 // [E][2][3P] or nullptr
+    const T *flat;                    // [3][Ppad] flat grid
+    const double *levels;             // Gripper.grab_top curZ table
+    int32_t n_glevels, E;
+    double two_thickness, half_thickness;
+    ClothEpisodeParams ep;
+};
+
+// episode state of one cloth between the operations of the fused loop: kept in LDS, not in registers, so that nothing of it
+// is live across the substep loop
+struct EpState {
+    int32_t t_slot;        // next action slot of this launch
+    int32_t rp;            // reset stage: -1 none; 2p = coverage condition of pull p, 2p+1 = pull p, 6 = settle, 7 = end
+    int32_t n_resets;      // resets done in this launch
+    int32_t first_pulls;   // pulls the first one ran (selects the RNG fork of the second script, see clothhip.h)
+    int32_t rs_pulls;      // pulls run by the reset in progress
+    int32_t reset_mark;    // the next executed action record gets reset_before = this
+    int32_t ep_steps, ep_done;
+    int32_t op, n_grab, iters_pull, decode_err;
+    int32_t done_total, _pad;
+    double act[4];
+};
+
 template <typename T> struct StepArgs {
     T *pos;                  // [E][3][Ppad]   (HBM layout: SoA, coalesced)
     T *prev;                 // [E][3][Ppad]
@@ -70,6 +103,10 @@ template <typename T> struct StepArgs {
     int32_t narrow_thresh;   // dense sweep: at most this many flagged levels -> narrow table (8 levels per pass)
     int32_t phase_mask;      // debug/ablation: bit0 hooke+verlet, bit1 collide, bit2 plane, bit3 strain, bit4 no-skip
     DevConsts<T> k;
+    // whole episodes on the device (clothhip_run_actions): a DEVICE pointer to the episode arguments, or nullptr = one
+    // externally decoded schedule per env (clothhip_run). By pointer, not by value: kernel arguments are invariant loads
+    // that the compiler hoists to the kernel entry and keeps in SGPRs across the substep loop, which has none to spare.
+    const struct FusedArgs<T> *fz;
 };
 
 constexpr int KEY_SHIFT = 12;
@@ -155,11 +192,12 @@ template <typename T> __device__ __forceinline__ uint32_t cell_key(const DevCons
 // LDS carve-up (dynamic shared memory), all offsets in bytes, 16-byte aligned.
 // tab: 0 = static tables stay in global memory, 1 = ent/rest/off in LDS, 2 = + per-point level table
 struct LdsLayout {
-    int cur, ent, rest, off, off8, plev, flag, abits, hkey, hco, memb, slot, misc, alist, olist, cpos, total;
+    int cur, eps, ent, rest, off, off8, plev, flag, abits, hkey, hco, memb, slot, misc, alist, olist, cpos, total;
     __host__ __device__ LdsLayout(int tsz, int Ppad, int Spad, int nL, int nL8, int HT, int tab, int cp) {
         int o = 0;
         auto take = [&](int bytes) { int r = o; o += (bytes + 15) / 16 * 16; return r; };
         cur = take(4 * Ppad * tsz);
+        eps = take(96);              // EpState (fused episodes)
         ent = take(tab >= 1 ? Spad * 4 : 0);
         rest = take(tab >= 1 ? Spad * tsz : 0);
         off = take(tab >= 1 ? (nL + 40) * 2 : 0);       // padded: levels past the end are empty
@@ -393,21 +431,147 @@ __device__ __forceinline__ void collide_cell_serial(Pt<T> *cur, uint16_t *m, int
     }
 }
 
+// ---- per-env metrics (cloth_env.py:1020-1098): coverage = area of the convex hull of the clipped (x,y) (same
+// monotone-chain + shoelace arithmetic, in double, as clothhip_hull_area on the host), variance_inv of z, out-of-bounds,
+// #(z < thickness/2). ONE workgroup of NT threads; `src(i, x, y, z)` yields particle i as doubles. Scratch (LDS):
+// sx/sy[NS] sort buffers + hx/hy[NH] hull stack (NH >= P + 2) + 64 doubles = (2 NS + 2 NH + 64) * 8 bytes.
+// The reductions are done by the first 256 threads in a fixed tree, so the result does not depend on NT: the stand-alone
+// kernel (256 threads) and the in-kernel call of the episode stepper give the same bits.
+// Results: out[0] coverage, out[1] variance_inv, out[2] out-of-bounds (0/1), out[3] #(z < half_thick); valid for ALL
+// threads on return (the function ends with a barrier).
+template <int NT, typename Src>
+__device__ __forceinline__ void metrics_block(const Src &src, int P, int NS, int NH, unsigned char *scr, int tid, double half_thick,
+                                              double out[4]) {
+    double *sx = reinterpret_cast<double *>(scr), *sy = sx + NS, *hx = sy + NS, *hy = hx + NH;
+    double *red = hy + NH;                                    // [64] reduction scratch
+    const int lane = tid & 63, wave = tid >> 6;
+    const double INF = __longlong_as_double(0x7ff0000000000000LL);
+    double mnx = INF, mxx = -INF, mny = INF, mxy = -INF, mnz = INF, mxz = -INF, sum = 0.0;
+    int nlow = 0;                                               // compute_height (cloth_env.py:603-609): #(z < thickness/2)
+    if (NT == 256 || tid < 256) {
+        for (int i = tid; i < NS; i += 256) {
+            double x = INF, y = INF;
+            if (i < P) {
+                double z;
+                src(i, x, y, z);
+                nlow += z < half_thick ? 1 : 0;
+                mnx = fmin(mnx, x); mxx = fmax(mxx, x); mny = fmin(mny, y); mxy = fmax(mxy, y);
+                mnz = fmin(mnz, z); mxz = fmax(mxz, z); sum += z;
+                x = fmin(fmax(x, 0.0), 1.0); y = fmin(fmax(y, 0.0), 1.0);                         // cloth_env.py:629
+            }
+            sx[i] = x; sy[i] = y;
+        }
+    }
+    // block reductions (min/max exact; the z-sum order differs from numpy's pairwise sum only in the last bits)
+    auto wred = [&](double v, int op) {
+        for (int o = 32; o > 0; o >>= 1) {
+            const double w = __shfl_xor(v, o);
+            v = op == 0 ? fmin(v, w) : (op == 1 ? fmax(v, w) : v + w);
+        }
+        return v;
+    };
+    double vals[7] = {mnx, mxx, mny, mxy, mnz, mxz, sum};
+    const int ops[7] = {0, 1, 0, 1, 0, 1, 2};
+    if (NT == 256 || tid < 256)
+        for (int q = 0; q < 7; q++) { const double r = wred(vals[q], ops[q]); if (lane == 0) red[q * 4 + wave] = r; }
+    __syncthreads();
+    for (int q = 0; q < 7; q++) {
+        double r = red[q * 4];
+        for (int w = 1; w < 4; w++) r = ops[q] == 0 ? fmin(r, red[q * 4 + w]) : (ops[q] == 1 ? fmax(r, red[q * 4 + w]) : r + red[q * 4 + w]);
+        vals[q] = r;
+    }
+    __syncthreads();
+    const double mean = vals[6] / P;
+    if (NT == 256 || tid < 256) {
+        double acc = 0.0;
+        for (int i = tid; i < P; i += 256) { double x, y, z; src(i, x, y, z); const double d = z - mean; acc += d * d; }
+        acc = wred(acc, 2);
+        if (lane == 0) red[wave] = acc;
+        for (int o = 32; o > 0; o >>= 1) nlow += __shfl_xor(nlow, o);
+        if (lane == 0) reinterpret_cast<int *>(red + 32)[wave] = nlow;
+    }
+    // bitonic sort of the clipped points, lexicographic (x, y); padding (+inf,+inf) sinks to the end
+    for (int kk = 2; kk <= NS; kk <<= 1)
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            __syncthreads();
+            for (int t = tid; t < (NS >> 1); t += NT) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+                const double ax = sx[i], ay = sy[i], bx = sx[l], by = sy[l];
+                const bool gt = ax > bx || (ax == bx && ay > by);
+                if (gt == ((i & kk) == 0)) { sx[i] = bx; sy[i] = by; sx[l] = ax; sy[l] = ay; }
+            }
+        }
+    __syncthreads();
+    if (tid == 0) {
+        const double var = (red[0] + red[1] + red[2] + red[3]) / P;                            // np.var
+        red[41] = var < 0.000001 ? 1000.0 : 0.001 / var;                                       // cloth_env.py:1081-1084
+        const int *nl = reinterpret_cast<const int *>(red + 32);
+        red[43] = (double)(nl[0] + nl[1] + nl[2] + nl[3]);
+        const double slack = 0.25;                                                             // cloth_env.py:1031-1036
+        red[42] = (vals[1] >= 1.0 + slack || vals[0] < -slack || vals[3] >= 1.0 + slack || vals[2] < -slack ||
+                   vals[5] >= 1.0 || vals[4] < 0) ? 1.0 : 0.0;
+        // dedupe (in place), then Andrew's monotone chain exactly as clothhip_hull_area
+        int m = 0;
+        for (int i = 0; i < P; i++)
+            if (m == 0 || sx[i] != sx[m - 1] || sy[i] != sy[m - 1]) { sx[m] = sx[i]; sy[m] = sy[i]; m++; }
+        double area = 0.0;
+        if (m >= 3) {
+            auto cross = [](double ox, double oy, double ax, double ay, double bx, double by) {
+                return (ax - ox) * (by - oy) - (ay - oy) * (bx - ox);
+            };
+            int k = 0;
+            for (int i = 0; i < m; i++) {
+                while (k >= 2 && cross(hx[k - 2], hy[k - 2], hx[k - 1], hy[k - 1], sx[i], sy[i]) <= 0) k--;
+                hx[k] = sx[i]; hy[k] = sy[i]; k++;
+            }
+            for (int i = m - 2, t = k + 1; i >= 0; i--) {
+                while (k >= t && cross(hx[k - 2], hy[k - 2], hx[k - 1], hy[k - 1], sx[i], sy[i]) <= 0) k--;
+                hx[k] = sx[i]; hy[k] = sy[i]; k++;
+            }
+            k--;
+            if (k >= 3) {
+                double a2 = 0.0;
+                for (int i = 0; i < k; i++) {
+                    const int n = (i + 1) % k;
+                    a2 += (hx[i] - hx[0]) * (hy[n] - hy[0]) - (hx[n] - hx[0]) * (hy[i] - hy[0]);
+                }
+                area = 0.5 * fabs(a2);
+            }
+        }
+        red[40] = area;
+    }
+    __syncthreads();
+    out[0] = red[40]; out[1] = red[41]; out[2] = red[42]; out[3] = red[43];
+    __syncthreads();
+}
+
 // Particle i is owned by thread (i % NT); a thread owns PPT particles i = tid + q*NT. The previous position
 // of a particle is only ever touched by its owner (adjust, Verlet, plane), so it lives in the owner's
 // registers for the whole schedule, as do the particle's static gather entries (and, with REST_REG, the rest
 // lengths of its incident springs). Only the current positions are shared, through LDS.
 //   TAB: 0 static tables in global memory, 1 ent/rest/offsets in LDS, 2 also the per-point level table.
-template <typename T, int NT, int PPT, int TAB, bool REST_REG>
+//   FUSED: whole episodes per launch (clothhip_run_actions); false = one externally decoded schedule per env (clothhip_run).
+template <typename T, int NT, int PPT, int TAB, bool REST_REG, bool FUSED>
 __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule(StepArgs<T> A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int e = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const ClothSchedule sc = A.sched[e];
-    if (!sc.active || sc.n_total <= 0) {
-        if (tid == 0) A.executed[e] = 0;
-        return;
+    // fz == nullptr: ONE externally decoded schedule per env (clothhip_run). Otherwise: nT whole ClothEnv.step calls per env with
+    // action decoding, grab_top, metrics, terminal test and episode resets in the kernel (clothhip_run_actions).
+    const FusedArgs<T> *const Fp = A.fz;
+    constexpr bool fused = FUSED;
+    ClothSchedule sc;
+    if (!fused) {
+        sc = A.sched[e];
+        if (!sc.active || sc.n_total <= 0) {
+            if (tid == 0) A.executed[e] = 0;
+            return;
+        }
+    } else {
+        sc.n_up_end = sc.n_uprest_end = sc.n_pull_end = sc.n_griprest_end = sc.n_total = 0;
+        sc.break_on_tear = 1; sc.active = 1; sc._pad = 0;
+        sc.dz_up = sc.dx_pull = sc.dy_pull = sc.dz_pull = 0.0;
     }
     const int P = A.P, Ppad = A.Ppad, nL = A.n_levels, HT = A.HT;
     const LdsLayout lay((int)sizeof(T), Ppad, A.Spad, nL, A.n_levels8, HT, TAB, A.cell_copy);
@@ -452,6 +616,10 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                 if (REST_REG) rr[q][sl] = g_rest[(g0 >> HK_POS_SHIFT) & HK_POS_MASK];
             }
         }
+    }
+    // everything in LDS behind the particle records: static tables, hash table, sweep flags (also re-run after the in-kernel
+    // metrics, which borrow that region as scratch)
+    auto init_lds = [&](int tear_flag) {
         if (TAB >= 1) {
             uint32_t *d0 = reinterpret_cast<uint32_t *>(smem + lay.ent);
             T *d1 = reinterpret_cast<T *>(smem + lay.rest);
@@ -468,12 +636,11 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
         for (int h = tid; h < HT; h += NT) { hkey[h] = KEY_EMPTY; hco[h] = 0; }
         for (int i = tid; i < nL + 64; i += NT) lvflag[i] = 0;
         for (int i = tid; i < (A.Spad / 64 + 2) * 2; i += NT) reinterpret_cast<uint32_t *>(smem + lay.abits)[i] = 0u;
-        if (tid == 0) { misc[0] = A.tear[e]; misc[1] = 0; misc[2] = 0; misc[3] = 0; misc[4] = 0; misc[5] = 0; misc[6] = 0; }
-    }
+        if (tid == 0) { misc[0] = tear_flag; misc[1] = 0; misc[2] = 0; misc[3] = 0; misc[4] = 0; misc[5] = 0; misc[6] = 0; }
+    };
+    init_lds(A.tear[e]);
     __syncthreads();
 
-    const T dz_up = (T)sc.dz_up, dxp = (T)sc.dx_pull, dyp = (T)sc.dy_pull, dzp = (T)sc.dz_pull;
-    int done = 0;
     int st_sweeps = 0, st_dense = 0, st_levels = 0, st_trig = 0;      // wave 0 only (uniform)
     unsigned long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0, tstart = 0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tstart)::"memory");   // whole-schedule clock of this cloth (stats[15])
@@ -491,6 +658,234 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
         tph[slot_] += tn_ - tlast; tlast = tn_;                                \
     }
     if (timing) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory"); }
+
+    // ---- episode state machine (fused mode). Every trip of the loop below is ONE operation, so that a single copy of the
+    // action decoding, of the grab, of the substep loop and of the metrics serves actions, reset pulls and settling:
+    //   OP_SCHED        the externally decoded schedule of clothhip_run (not fused): run, then leave
+    //   OP_ACTION       ClothEnv.step: action -> decode -> grab_top -> run -> metrics -> record, terminal test
+    //   OP_RESET_COND   tier-1 reset: "third pull only if coverage >= 0.90" (cloth_env.py:866): metrics, then decide
+    //   OP_RESET_PULL   step(action, initialize=True) of a scripted reset pull: decode -> grab_top -> run
+    //   OP_RESET_SETTLE bare update() calls after the pulls (tier 3)
+    //   OP_RESET_END    start coverage / variance of the new episode (cloth_env.py:780-782)
+    // All control decisions derive from values every thread holds identically (kernel arguments, global tables, LDS
+    // broadcasts), so the whole workgroup takes the same path through every barrier.
+    enum { OP_SCHED = 0, OP_ACTION, OP_RESET_COND, OP_RESET_PULL, OP_RESET_SETTLE, OP_RESET_END };
+    EpState *const eps = reinterpret_cast<EpState *>(smem + lay.eps);
+    if (fused) {
+        if (tid == 0) {
+            eps->t_slot = 0; eps->rp = -1; eps->n_resets = 0; eps->first_pulls = 0; eps->rs_pulls = 0; eps->reset_mark = 0;
+            eps->ep_steps = Fp->num_steps[e]; eps->ep_done = Fp->done[e] ? 1 : 0; eps->done_total = 0;
+        }
+        __syncthreads();
+    }
+    int done_nf = 0;                   // executed substeps of the external schedule (not fused)
+    for (;;) {
+        bool do_run = true;
+        if (fused) {
+            // ---- plan the next operation. Every thread evaluates the same transitions on the same LDS-resident state.
+            const FusedArgs<T> &F = *Fp;
+            int t_slot = eps->t_slot, rp = eps->rp;
+            const int n_resets = eps->n_resets, first_pulls = eps->first_pulls;
+            const int slot = n_resets == 0 ? 0 : (n_resets == 1 ? (first_pulls >= 3 ? 2 : 1) : -1);
+            const ClothResetScript *scr = (F.scripts != nullptr && slot >= 0) ? F.scripts + ((size_t)e * 3 + slot) : nullptr;
+            int op = OP_ACTION;
+            bool do_decode = false;
+            double act[4] = {0.0, 0.0, 0.0, 0.0};
+            double run_iters_up = F.ep.iters_up;
+            do_run = false;
+            if (rp < 0) {
+                if (t_slot >= F.nT) break;
+                if (eps->ep_done) {
+                    __syncthreads();                     // everyone has read the state
+                    if (scr != nullptr && scr->valid) {
+                        // the Cloth(...) rebuild of ClothEnv.reset (cloth_env.py:737-746): flat grid, nothing pinned, no tear
+                        for (int i = tid; i < Ppad; i += NT)
+                            cur[i] = Pt<T>{F.flat[i], F.flat[Ppad + i], F.flat[2 * Ppad + i], w_make<T>(0u)};
+#pragma unroll
+                        for (int q = 0; q < PPT; q++) {
+                            const int i = tid + q * NT;
+                            if (i < P) { pvx[q] = F.flat[i]; pvy[q] = F.flat[Ppad + i]; pvz[q] = F.flat[2 * Ppad + i]; }
+                        }
+                        if (tid == 0) {
+                            misc[0] = 0;
+                            eps->rp = 0; eps->rs_pulls = 0; eps->ep_steps = 0; eps->ep_done = 0;
+                            if (F.resets) {
+                                ClothResetRecord *rr_ = F.resets + ((size_t)e * 2 + n_resets);
+                                rr_->consumed = 1; rr_->pulls_run = 0; rr_->executed[0] = rr_->executed[1] = rr_->executed[2] = 0;
+                                rr_->settle_executed = 0; rr_->tear = 0;
+                            }
+                        }
+                    } else if (tid == 0) {               // episode over and no script left: the slot stays empty
+                        ClothStepRecord *r_ = F.records + ((size_t)t_slot * F.E + e);
+                        r_->ran = 0; r_->executed = 0; r_->n_grabbed = 0; r_->done = 1; r_->reset_before = 0;
+                        eps->t_slot = t_slot + 1;
+                    }
+                    __syncthreads();
+                    continue;
+                }
+                do_decode = true;
+                if (F.policy == CLOTHHIP_POLICY_ORACLE_CORNER) {
+                    // examples/analytic.py:105-155 ('distance' method, delta actions): pull the inset corner that is
+                    // farthest from its plane corner; candidates in the order ur, lr, ll, ul, the first maximum wins
+                    const bool sw = F.policy_arg != nullptr && F.policy_arg[e] != 0;     // tier 2, init_side False (:108-114)
+                    double best = -1.0;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const int ci = c == 0 ? (sw ? 48 : 598) : (c == 1 ? (sw ? 26 : 576) : (c == 2 ? (sw ? 576 : 26) : (sw ? 598 : 48)));
+                        const double tgx = c < 2 ? 1.0 : 0.0, tgy = (c == 0 || c == 3) ? 1.0 : 0.0;
+                        const Pt<T> pc = cur[ci];
+                        const double x = (double)pc.x, y = (double)pc.y;
+                        const double cx = (x - 0.5) * 2.0, cy = (y - 0.5) * 2.0;                 // analytic.py:53-54
+                        double dx = tgx - x, dy = tgy - y;                                        // :55-56
+                        const double dist = sqrt((x - tgx) * (x - tgx) + (y - tgy) * (y - tgy)); // :57
+                        dx = dx * 0.90; dy = dy * 0.90;                                           // :64-66
+                        if (dist > best) {
+                            best = dist;
+                            act[0] = F.ep.clip_act_space ? cx : x; act[1] = F.ep.clip_act_space ? cy : y;   // :151-154
+                            act[2] = dx; act[3] = dy;
+                        }
+                    }
+                } else {
+                    const double *ap = F.actions + ((size_t)t_slot * F.E + e) * 4;
+                    act[0] = ap[0]; act[1] = ap[1]; act[2] = ap[2]; act[3] = ap[3];
+                }
+            } else {
+                for (;;) {                               // skip the stages this script does not have
+                    if (rp < 6) {
+                        const int p_ = rp >> 1;
+                        if (p_ >= scr->n_pulls) { rp = 6; continue; }
+                        if (!(rp & 1) && !scr->pull[p_].need_coverage) { rp++; continue; }
+                    }
+                    if (rp == 6 && scr->settle_after <= 0) { rp = 7; continue; }
+                    break;
+                }
+                if (rp < 6 && !(rp & 1)) op = OP_RESET_COND;
+                else if (rp < 6) {
+                    op = OP_RESET_PULL; do_decode = true;
+                    const ClothResetPull *pl = &scr->pull[rp >> 1];
+                    double px_ = pl->x, py_ = pl->y;
+                    const int pt_ = pl->point;
+                    if (pt_ >= 0) { const Pt<T> pp = cur[pt_ < P ? pt_ : 0]; px_ = (double)pp.x; py_ = (double)pp.y; }
+                    // _prevent_oob (cloth_env.py:834-840)
+                    double dx0 = pl->dx, dy0 = pl->dy;
+                    if (px_ + dx0 < 0.0) dx0 = 0.0 - px_; else if (px_ + dx0 > 1.0) dx0 = 1.0 - px_;
+                    if (py_ + dy0 < 0.0) dy0 = 0.0 - py_; else if (py_ + dy0 > 1.0) dy0 = 1.0 - py_;
+                    // _convert_action_to_clip_space (cloth_env.py:1207-1215), delta actions
+                    act[0] = F.ep.clip_act_space ? (px_ - 0.5) * 2 : px_;
+                    act[1] = F.ep.clip_act_space ? (py_ - 0.5) * 2 : py_;
+                    act[2] = dx0; act[3] = dy0;
+                    run_iters_up = pl->iters_up;
+                } else if (rp == 6) {
+                    op = OP_RESET_SETTLE; do_run = true;
+                    sc.n_up_end = sc.n_uprest_end = sc.n_pull_end = 0;
+                    sc.n_griprest_end = sc.n_total = scr->settle_after;
+                    sc.break_on_tear = 0;
+                } else {
+                    op = OP_RESET_END;
+                }
+            }
+            int n_grab = 0, iters_pull = 0, decode_err = 0;
+            if (do_decode) {
+                // ---- action -> schedule (cloth_env.py:396-475), in double, every thread the same arithmetic
+                const ClothEpisodeParams &ep = F.ep;
+                double a0 = fmax(fmin(act[0], ep.act_high[0]), ep.act_low[0]);                    // :402-415
+                double a1 = fmax(fmin(act[1], ep.act_high[1]), ep.act_low[1]);
+                const double c2 = fmax(fmin(act[2], ep.act_high[2]), ep.act_low[2]);
+                const double c3 = fmax(fmin(act[3], ep.act_high[3]), ep.act_low[3]);
+                if (ep.clip_act_space) { a0 = (a0 / 2.0) + 0.5; a1 = (a1 / 2.0) + 0.5; }          // :417-426
+                const double tl = sqrt(c2 * c2 + c3 * c3);                                        // :449
+                const double xd = c2 / (tl + 1e-5), yd = c3 / (tl + 1e-5);                        // :450-451
+                const double xr = xd * ep.reduce_factor, yr = yd * ep.reduce_factor;              // :455-456
+                const double stp = sqrt(xr * xr + yr * yr);
+                double cl = 0.0;
+                int ii = 0;
+                for (;;) {                                                                        // :461-468
+                    cl = cl + stp;
+                    if (cl >= tl) break;
+                    ii++;
+                    if (ii >= 200000) { decode_err = 1; break; }      // non-finite action: the host wrapper raises
+                }
+                iters_pull = ii;
+                const double iu = run_iters_up;                                                   // :472-475, left to right
+                const double b1 = iu, b2 = iu + ep.iters_up_rest, b3 = iu + ep.iters_up_rest + ii;
+                const double b4 = iu + ep.iters_up_rest + ii + ep.iters_grip_rest;
+                const double b5 = iu + ep.iters_up_rest + ii + ep.iters_grip_rest + ep.iters_rest;
+                sc.n_up_end = (int)ceil(b1); sc.n_uprest_end = (int)ceil(b2); sc.n_pull_end = (int)ceil(b3);
+                sc.n_griprest_end = (int)ceil(b4); sc.n_total = (int)ceil(b5);
+                sc.break_on_tear = 1;
+                sc.dz_up = ep.dz_up; sc.dx_pull = xr; sc.dy_pull = yr; sc.dz_pull = 0.0;
+                // ---- Gripper.grab_top (gripper.pyx:23-42) on the LDS-resident state, + force_grab (cloth_env.py:434-444)
+                const T gx = (T)a0, gy = (T)a1, tt = (T)F.two_thickness;
+                double radius = ep.grip_radius;
+                for (int tries = 0;; tries++) {
+                    const T rad = (T)radius;
+                    __syncthreads();
+                    if (tid == 0) { misc[8] = 0x7fffffff; misc[9] = 0; }
+                    __syncthreads();
+                    int best = 0x7fffffff;
+                    bool incyl[PPT];
+#pragma unroll
+                    for (int q = 0; q < PPT; q++) {
+                        const int i = tid + q * NT;
+                        incyl[q] = false;
+                        if (i < P) {
+                            const Pt<T> c = cur[i];
+                            const T dx = c.x - gx, dy = c.y - gy;
+                            if (dx * dx + dy * dy < rad) {                                        // gripper.pyx:35 (radius not squared)
+                                incyl[q] = true;
+                                for (int l = 0; l < F.n_glevels && l < best; l++) {
+                                    T d = c.z - (T)F.levels[l]; d = d < 0 ? -d : d;
+                                    if (d < tt) { best = l; break; }                              // gripper.pyx:36
+                                }
+                            }
+                        }
+                    }
+                    for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(best, o); best = v < best ? v : best; }
+                    if (lane == 0 && best != 0x7fffffff) atomicMin(&misc[8], best);
+                    __syncthreads();
+                    best = misc[8];
+                    int n = 0;
+                    if (best != 0x7fffffff) {
+                        const T lz = (T)F.levels[best];
+#pragma unroll
+                        for (int q = 0; q < PPT; q++) {
+                            if (incyl[q]) {
+                                const int i = tid + q * NT;
+                                Pt<T> c = cur[i];
+                                T d = c.z - lz; d = d < 0 ? -d : d;
+                                if (d < tt) {                                                     // pinned = True ; grabbed_pts.append
+                                    uint32_t w = w_cnt(c.w);
+                                    if ((w & CNT_GRAB_MASK) < CNT_GRAB_MASK) w++;
+                                    c.w = w_make<T>(w); cur[i] = c; n++;
+                                }
+                            }
+                        }
+                        for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+                        if (lane == 0 && n) atomicAdd(&misc[9], n);
+                    }
+                    __syncthreads();
+                    n_grab = misc[9];
+                    if (n_grab > 0 || !ep.force_grab || tries >= 10000) break;
+                    radius += ep.radius_inc;                                                      // cloth_env.py:439
+                }
+                do_run = n_grab > 0 && !decode_err;                                               // cloth_env.py:490-493
+            }
+            // park the plan in LDS: nothing of it stays in registers across the substep loop
+            if (tid == 0) {
+                eps->rp = rp; eps->op = op; eps->n_grab = n_grab; eps->iters_pull = iters_pull; eps->decode_err = decode_err;
+                eps->act[0] = act[0]; eps->act[1] = act[1]; eps->act[2] = act[2]; eps->act[3] = act[3];
+            }
+            // uniform copies of the schedule for the loop's phase tests
+            sc.n_up_end = __builtin_amdgcn_readfirstlane(sc.n_up_end);
+            sc.n_uprest_end = __builtin_amdgcn_readfirstlane(sc.n_uprest_end);
+            sc.n_pull_end = __builtin_amdgcn_readfirstlane(sc.n_pull_end);
+            sc.n_griprest_end = __builtin_amdgcn_readfirstlane(sc.n_griprest_end);
+            sc.n_total = __builtin_amdgcn_readfirstlane(do_run ? sc.n_total : 0);
+            sc.break_on_tear = __builtin_amdgcn_readfirstlane(sc.break_on_tear);
+        }
+        int done = 0;
+        {
+        const T dz_up = (T)sc.dz_up, dxp = (T)sc.dx_pull, dyp = (T)sc.dy_pull, dzp = (T)sc.dz_pull;
     for (int it = 0; it < sc.n_total; it++) {
         // ---- ClothEnv._pull (cloth_env.py:352-367): adjust / nothing / release -------------------
         int mode = 0; T ax = 0, ay = 0, az = 0;
@@ -1102,6 +1497,73 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
         done++;
         if (sc.break_on_tear && misc[0]) break;                                            // cloth_env.py:511-514
     }
+        }   // the run
+        if (!fused) { done_nf = done; break; }
+        // ---- after the run: everything is re-read from LDS -----------------------------------------------------------
+        {
+            const FusedArgs<T> &F = *Fp;
+            __syncthreads();
+            const int tear_now = __builtin_amdgcn_readfirstlane(misc[0]);
+            const int op = eps->op, rp = eps->rp, t_slot = eps->t_slot, n_resets = eps->n_resets;
+            double mo[4] = {0.0, 0.0, 0.0, 0.0};
+            if (op == OP_ACTION || op == OP_RESET_COND || op == OP_RESET_END) {
+                // cloth_env.py:1020-1098 on the LDS-resident state; the sort buffers borrow the LDS behind the particle records
+                auto src = [&](int i, double &x, double &y, double &z) { const Pt<T> c = cur[i]; x = (double)c.x; y = (double)c.y; z = (double)c.z; };
+                metrics_block<NT>(src, P, F.NS, F.NH, smem + lay.ent, tid, F.half_thickness, mo);
+                init_lds(tear_now);
+                __syncthreads();
+            }
+            if (op == OP_ACTION && F.obs) {                                                       // '1d' observation, cloth_env.py:196-200
+                float *o_ = F.obs + ((size_t)t_slot * F.E + e) * 3 * P;
+                for (int i = tid; i < P; i += NT) { const Pt<T> c = cur[i]; o_[3 * i] = (float)c.x; o_[3 * i + 1] = (float)c.y; o_[3 * i + 2] = (float)c.z; }
+            }
+            if (op == OP_RESET_END && F.reset_obs) {                                              // what env.reset() returns
+                float *o_ = F.reset_obs + ((size_t)e * 2 + n_resets) * 3 * P;
+                for (int i = tid; i < P; i += NT) { const Pt<T> c = cur[i]; o_[3 * i] = (float)c.x; o_[3 * i + 1] = (float)c.y; o_[3 * i + 2] = (float)c.z; }
+            }
+            if (tid == 0) {
+                eps->done_total += done;
+                if (op == OP_ACTION) {
+                    const int ep_steps = eps->ep_steps + 1;
+                    const bool oob_ = mo[2] != 0.0;
+                    // _terminal (cloth_env.py:684-715)
+                    const bool dn = ep_steps >= F.ep.max_actions || tear_now != 0 || oob_ || mo[0] > F.ep.coverage_done;
+                    ClothStepRecord *r_ = F.records + ((size_t)t_slot * F.E + e);
+                    r_->action[0] = eps->act[0]; r_->action[1] = eps->act[1]; r_->action[2] = eps->act[2]; r_->action[3] = eps->act[3];
+                    r_->coverage = mo[0]; r_->variance_inv = mo[1];
+                    r_->executed = done; r_->n_grabbed = eps->n_grab; r_->iters_pull = eps->iters_pull;
+                    r_->n_below_half_thickness = (int32_t)mo[3];
+                    r_->ran = eps->decode_err ? 2 : 1; r_->oob = oob_ ? 1 : 0; r_->tear = tear_now ? 1 : 0; r_->done = dn ? 1 : 0;
+                    r_->reset_before = (uint8_t)eps->reset_mark;
+                    eps->reset_mark = 0; eps->ep_steps = ep_steps; eps->ep_done = dn ? 1 : 0; eps->t_slot = t_slot + 1;
+                } else {
+                    const int slot = n_resets == 0 ? 0 : (eps->first_pulls >= 3 ? 2 : 1);
+                    const ClothResetScript *scr = F.scripts + ((size_t)e * 3 + slot);
+                    ClothResetRecord *rr_ = F.resets ? F.resets + ((size_t)e * 2 + n_resets) : nullptr;
+                    if (op == OP_RESET_COND) {
+                        eps->rp = mo[0] >= scr->pull[rp >> 1].coverage_min ? rp + 1 : 6;        // cloth_env.py:866
+                    } else if (op == OP_RESET_PULL) {
+                        const int p_ = rp >> 1;
+                        if (rr_) {
+                            rr_->executed[p_] = done; rr_->pulls_run = eps->rs_pulls + 1;
+                            rr_->action[p_][0] = eps->act[0]; rr_->action[p_][1] = eps->act[1];
+                            rr_->action[p_][2] = eps->act[2]; rr_->action[p_][3] = eps->act[3];
+                        }
+                        eps->rs_pulls += 1; eps->rp = rp + 1;
+                    } else if (op == OP_RESET_SETTLE) {
+                        if (rr_) rr_->settle_executed = done;
+                        eps->rp = 7;
+                    } else {                                                                      // OP_RESET_END
+                        if (rr_) { rr_->start_coverage = mo[0]; rr_->start_variance_inv = mo[1]; rr_->tear = tear_now; }
+                        if (n_resets == 0) eps->first_pulls = eps->rs_pulls;
+                        eps->n_resets = n_resets + 1; eps->reset_mark = n_resets + 1; eps->rp = -1;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const int done = fused ? eps->done_total : done_nf;
 
 #undef TSTAMP
     {   // LDS / registers -> HBM
@@ -1117,6 +1579,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
             const int i = tid + q * NT;
             if (i < P) { gq[i] = pvx[q]; gq[Ppad + i] = pvy[q]; gq[2 * Ppad + i] = pvz[q]; }
         }
+        if (tid == 0 && fused) { Fp->num_steps[e] = eps->ep_steps; Fp->done[e] = (uint8_t)eps->ep_done; }
         if (tid == 0) {
             A.tear[e] = misc[0]; A.executed[e] = done;
             if (A.stats) {
@@ -1203,100 +1666,35 @@ template <typename T> __global__ void k_write_obs(const T *pos, float *out, int 
     }
 }
 
-// ---- per-env metrics on the device (cloth_env.py:1020-1098): coverage = area of the convex hull of the clipped
-// (x,y) (same monotone-chain + shoelace arithmetic, in double, as clothhip_hull_area on the host), variance_inv of z,
-// out-of-bounds. One 256-thread workgroup per env. LDS: sx/sy[NS] sort buffers + hx/hy[NH] hull stack (NH >= P + 2).
+// ---- per-env metrics kernel: one 256-thread workgroup per env over the SoA state in HBM (metrics_block above)
 template <typename T>
-__global__ __launch_bounds__(256) void k_metrics(const T *pos, int P, int Ppad, int NS, int NH, double *cov, double *vinv, uint8_t *oob) {
+__global__ __launch_bounds__(256) void k_metrics(const T *pos, int P, int Ppad, int NS, int NH, double *cov, double *vinv, uint8_t *oob,
+                                                 int32_t *hcnt, double half_thick) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double *sx = reinterpret_cast<double *>(smem), *sy = sx + NS, *hx = sy + NS, *hy = hx + NH;
-    double *red = hy + NH;                                    // [64] reduction scratch
-    const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int e = blockIdx.x;
     const T *px = pos + (size_t)e * 3 * Ppad, *py = px + Ppad, *pz = py + Ppad;
-    const double INF = __longlong_as_double(0x7ff0000000000000LL);
-    double mnx = INF, mxx = -INF, mny = INF, mxy = -INF, mnz = INF, mxz = -INF, sum = 0.0;
-    for (int i = tid; i < NS; i += 256) {
-        double x = INF, y = INF;
-        if (i < P) {
-            x = (double)px[i]; y = (double)py[i];
-            const double z = (double)pz[i];
-            mnx = fmin(mnx, x); mxx = fmax(mxx, x); mny = fmin(mny, y); mxy = fmax(mxy, y);
-            mnz = fmin(mnz, z); mxz = fmax(mxz, z); sum += z;
-            x = fmin(fmax(x, 0.0), 1.0); y = fmin(fmax(y, 0.0), 1.0);                         // cloth_env.py:629
-        }
-        sx[i] = x; sy[i] = y;
+    auto src = [&](int i, double &x, double &y, double &z) { x = (double)px[i]; y = (double)py[i]; z = (double)pz[i]; };
+    double out[4];
+    metrics_block<256>(src, P, NS, NH, smem, (int)threadIdx.x, half_thick, out);
+    if (threadIdx.x == 0) {
+        cov[e] = out[0]; vinv[e] = out[1]; oob[e] = out[2] != 0.0 ? 1 : 0;
+        if (hcnt) hcnt[e] = (int32_t)out[3];
     }
-    // block reductions (min/max exact; the z-sum order differs from numpy's pairwise sum only in the last bits)
-    auto wred = [&](double v, int op) {
-        for (int o = 32; o > 0; o >>= 1) {
-            const double w = __shfl_xor(v, o);
-            v = op == 0 ? fmin(v, w) : (op == 1 ? fmax(v, w) : v + w);
-        }
-        return v;
-    };
-    double vals[7] = {mnx, mxx, mny, mxy, mnz, mxz, sum};
-    const int ops[7] = {0, 1, 0, 1, 0, 1, 2};
-    for (int q = 0; q < 7; q++) { const double r = wred(vals[q], ops[q]); if (lane == 0) red[q * 4 + wave] = r; }
-    __syncthreads();
-    for (int q = 0; q < 7; q++) {
-        double r = red[q * 4];
-        for (int w = 1; w < 4; w++) r = ops[q] == 0 ? fmin(r, red[q * 4 + w]) : (ops[q] == 1 ? fmax(r, red[q * 4 + w]) : r + red[q * 4 + w]);
-        vals[q] = r;
-    }
-    __syncthreads();
-    const double mean = vals[6] / P;
-    double acc = 0.0;
-    for (int i = tid; i < P; i += 256) { const double d = (double)pz[i] - mean; acc += d * d; }
-    acc = wred(acc, 2);
-    if (lane == 0) red[wave] = acc;
-    // bitonic sort of the clipped points, lexicographic (x, y); padding (+inf,+inf) sinks to the end
-    for (int kk = 2; kk <= NS; kk <<= 1)
-        for (int j = kk >> 1; j > 0; j >>= 1) {
-            __syncthreads();
-            for (int t = tid; t < (NS >> 1); t += 256) {
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
-                const double ax = sx[i], ay = sy[i], bx = sx[l], by = sy[l];
-                const bool gt = ax > bx || (ax == bx && ay > by);
-                if (gt == ((i & kk) == 0)) { sx[i] = bx; sy[i] = by; sx[l] = ax; sy[l] = ay; }
-            }
-        }
-    __syncthreads();
-    if (tid == 0) {
-        const double var = (red[0] + red[1] + red[2] + red[3]) / P;                            // np.var
-        vinv[e] = var < 0.000001 ? 1000.0 : 0.001 / var;                                       // cloth_env.py:1081-1084
-        const double slack = 0.25;                                                             // cloth_env.py:1031-1036
-        oob[e] = (vals[1] >= 1.0 + slack || vals[0] < -slack || vals[3] >= 1.0 + slack || vals[2] < -slack ||
-                  vals[5] >= 1.0 || vals[4] < 0) ? 1 : 0;
-        // dedupe (in place), then Andrew's monotone chain exactly as clothhip_hull_area
-        int m = 0;
-        for (int i = 0; i < P; i++)
-            if (m == 0 || sx[i] != sx[m - 1] || sy[i] != sy[m - 1]) { sx[m] = sx[i]; sy[m] = sy[i]; m++; }
-        double area = 0.0;
-        if (m >= 3) {
-            auto cross = [](double ox, double oy, double ax, double ay, double bx, double by) {
-                return (ax - ox) * (by - oy) - (ay - oy) * (bx - ox);
-            };
-            int k = 0;
-            for (int i = 0; i < m; i++) {
-                while (k >= 2 && cross(hx[k - 2], hy[k - 2], hx[k - 1], hy[k - 1], sx[i], sy[i]) <= 0) k--;
-                hx[k] = sx[i]; hy[k] = sy[i]; k++;
-            }
-            for (int i = m - 2, t = k + 1; i >= 0; i--) {
-                while (k >= t && cross(hx[k - 2], hy[k - 2], hx[k - 1], hy[k - 1], sx[i], sy[i]) <= 0) k--;
-                hx[k] = sx[i]; hy[k] = sy[i]; k++;
-            }
-            k--;
-            if (k >= 3) {
-                double a2 = 0.0;
-                for (int i = 0; i < k; i++) {
-                    const int n = (i + 1) % k;
-                    a2 += (hx[i] - hx[0]) * (hy[n] - hy[0]) - (hx[n] - hx[0]) * (hy[i] - hy[0]);
-                }
-                area = 0.5 * fabs(a2);
-            }
-        }
-        cov[e] = area;
-    }
+}
+
+// Cloth(...) rebuilt on reset (cloth_env.py:737-746) for the flat tiers 1/3: masked envs <- the flat grid (pos = prev),
+// nothing pinned, tear flag cleared; with per-env rest tables also the flat rest lengths.
+template <typename T>
+__global__ void k_reset_flat(T *pos, T *prev, uint8_t *cnt, int32_t *tear, const T *flat, const uint8_t *mask, int Ppad,
+                             T *rest, const T *flat_rest, int rest_stride, int Spad) {
+    const int e = blockIdx.x;
+    if (mask && !mask[e]) return;
+    T *p = pos + (size_t)e * 3 * Ppad, *q = prev + (size_t)e * 3 * Ppad;
+    for (int i = threadIdx.x; i < 3 * Ppad; i += blockDim.x) { const T v = flat[i]; p[i] = v; q[i] = v; }
+    for (int i = threadIdx.x; i < Ppad; i += blockDim.x) cnt[(size_t)e * Ppad + i] = 0;
+    if (rest_stride)
+        for (int i = threadIdx.x; i < Spad; i += blockDim.x) rest[(size_t)e * rest_stride + i] = flat_rest[i];
+    if (threadIdx.x == 0) tear[e] = 0;
 }
 
 __global__ void k_selftest(int op, const double *a, const double *b, double *out, long long n) {

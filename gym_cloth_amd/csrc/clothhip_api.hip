@@ -46,6 +46,7 @@ struct clothhip_handle {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool have_timing = false, pending_exec = false;
     void *d_pos = nullptr, *d_prev = nullptr, *d_rest = nullptr;
+    void *d_flat = nullptr, *d_flat_rest = nullptr;   // flat tier-1 grid [3][Ppad] and its rest table [Spad] (level order), handle precision
     uint8_t *d_cnt = nullptr, *d_active = nullptr;
     int rest_stride = 0;
     int32_t *d_tear = nullptr, *d_exec = nullptr, *d_ngrab = nullptr, *d_stats = nullptr;
@@ -59,7 +60,13 @@ struct clothhip_handle {
     bool rest_reg = false;
     double *d_levels = nullptr, *d_xy = nullptr, *d_radius = nullptr, *d_cov = nullptr, *d_vinv = nullptr;
     uint8_t *d_oob = nullptr;
+    int32_t *d_hcnt = nullptr;      // per env: #points with z < thickness/2 (height reward, cloth_env.py:1047-1073)
     int n_grab_levels = 0;
+    // clothhip_run_actions staging (device), grown on demand
+    void *d_fz = nullptr, *d_fact = nullptr, *d_fscr = nullptr, *d_frec = nullptr, *d_frst = nullptr, *d_fobs = nullptr, *d_frobs = nullptr;
+    int32_t *d_fsteps = nullptr, *d_fparg = nullptr;
+    uint8_t *d_fdone = nullptr;
+    size_t cap_fact = 0, cap_frec = 0, cap_fobs = 0;
     Topology topo;
     LevelSchedule lv;
     std::vector<unsigned char> stage;   // host staging for layout conversion
@@ -154,7 +161,7 @@ static void free_handle(clothhip_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_pos, h->d_prev, h->d_rest, h->d_cnt, h->d_active, h->d_tear, h->d_exec, h->d_ngrab, h->d_stats,
-                    h->d_sched, h->d_gather, h->d_lv_ent, h->d_lv_off, h->d_lv_off8, h->d_pt_lev, h->d_levels, h->d_xy, h->d_radius, h->d_cov, h->d_vinv, h->d_oob};
+                    h->d_sched, h->d_flat, h->d_flat_rest, h->d_hcnt, h->d_fz, h->d_fact, h->d_fscr, h->d_frec, h->d_frst, h->d_fobs, h->d_frobs, h->d_fsteps, h->d_fparg, h->d_fdone, h->d_gather, h->d_lv_ent, h->d_lv_off, h->d_lv_off8, h->d_pt_lev, h->d_levels, h->d_xy, h->d_radius, h->d_cov, h->d_vinv, h->d_oob};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->h_sched) (void)hipHostFree(h->h_sched);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -163,7 +170,7 @@ static void free_handle(clothhip_handle *h) {
     delete h;
 }
 
-static const void *stepper_fn(const clothhip_handle *h);
+static const void *stepper_fn(const clothhip_handle *h, bool fused);
 
 extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_t device, int32_t precision,
                                clothhip_handle **out) {
@@ -234,6 +241,9 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
     HC(hipMalloc(&h->d_cov, E * 8));
     HC(hipMalloc(&h->d_vinv, E * 8));
     HC(hipMalloc(&h->d_oob, E));
+    HC(hipMalloc(&h->d_hcnt, E * 4));
+    HC(hipMalloc(&h->d_flat, (size_t)3 * h->Ppad * h->tsz));
+    HC(hipMalloc(&h->d_flat_rest, (size_t)h->Spad * h->tsz));
     HC(hipMemcpy(h->d_gather, gather.data(), gather.size() * 4, hipMemcpyHostToDevice));
     HC(hipMemset(h->d_lv_ent, 0, (size_t)h->Spad * 4));
     HC(hipMemcpy(h->d_lv_ent, h->lv.ent.data(), (size_t)h->S * 4, hipMemcpyHostToDevice));
@@ -286,9 +296,12 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
         if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) h->cell_copy = h->cell_copy && atoi(t);
         h->lds_bytes = LdsLayout(tsz, h->Ppad, h->Spad, h->lv.n_levels, h->n_levels8, h->HT, h->tab, h->cell_copy).total;
         if (h->lds_bytes > 160 * 1024) { free_handle(h); return fail(CLOTHHIP_EINVAL, "n_side %d needs %d B of LDS (> 160 KiB)", h->N, h->lds_bytes); }
-        const void *fn = stepper_fn(h);
-        if (!fn) { free_handle(h); return fail(CLOTHHIP_EINVAL, "no stepper variant for n_side %d", h->N); }
-        HC(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes));
+        const void *fn = stepper_fn(h, false), *fnf = stepper_fn(h, true);
+        if (!fn || !fnf) { free_handle(h); return fail(CLOTHHIP_EINVAL, "no stepper variant for n_side %d", h->N); }
+        HC(hipFuncSetAttribute(fnf, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        // the attribute is per kernel function and process-global: always the CU's full 160 KiB, so that a later handle
+        // with a smaller footprint can never lower it under an earlier one
+        HC(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
 #undef HC
     // initial state: flat tier-1 grid for every env, shared rest table
@@ -299,8 +312,14 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
     std::vector<double> all((size_t)h->E * h->P * 3);
     for (int e = 0; e < h->E; e++) memcpy(all.data() + (size_t)e * h->P * 3, pos.data(), sizeof(double) * h->P * 3);
     std::vector<uint8_t> pin((size_t)h->E * h->P, 0);
-    rc = clothhip_set_state(h, 0, h->E, all.data(), all.data(), pin.data(), rest.data(), 1);
+    rc = clothhip_set_state(h, 0, h->E, all.data(), all.data(), pin.data(), rest.data(), CLOTHHIP_REST_SHARED);
     if (rc) { free_handle(h); return rc; }
+    // the flat grid and its rest table stay on the device for clothhip_reset_flat / the in-kernel episode reset
+    if (hipMemcpy(h->d_flat, h->d_pos, (size_t)3 * h->Ppad * h->tsz, hipMemcpyDeviceToDevice) != hipSuccess ||
+        hipMemcpy(h->d_flat_rest, h->d_rest, (size_t)h->Spad * h->tsz, hipMemcpyDeviceToDevice) != hipSuccess) {
+        free_handle(h);
+        return fail(CLOTHHIP_EHIP, "copying the flat-grid template failed");
+    }
     *out = h;
     return 0;
 }
@@ -343,8 +362,9 @@ template <typename T> static void soa_to_aos(const T *src, double *dst, int n, i
 }
 
 extern "C" int clothhip_set_state(clothhip_handle *h, int32_t env0, int32_t n, const double *pos, const double *prev,
-                                  const uint8_t *pinned, const double *rest, int32_t rest_shared) {
+                                  const uint8_t *pinned, const double *rest, int32_t flags) {
     if (int rc = check_range(h, env0, n)) return rc;
+    const bool rest_shared = (flags & CLOTHHIP_REST_SHARED) != 0;
     HIPCHECK(hipSetDevice(h->device));
     HIPCHECK(hipStreamSynchronize(h->stream));
     const size_t per = (size_t)3 * h->Ppad * h->tsz;
@@ -357,7 +377,7 @@ extern "C" int clothhip_set_state(clothhip_handle *h, int32_t env0, int32_t n, c
         char *dst = (char *)(pass == 0 ? h->d_pos : h->d_prev) + per * env0;
         HIPCHECK(hipMemcpy(dst, h->stage.data(), per * n, hipMemcpyHostToDevice));
     }
-    if (pos) HIPCHECK(hipMemset(h->d_tear + env0, 0, (size_t)n * 4));
+    if (pos && !(flags & CLOTHHIP_KEEP_TEAR)) HIPCHECK(hipMemset(h->d_tear + env0, 0, (size_t)n * 4));
     if (pinned) {
         std::vector<uint8_t> c((size_t)n * h->Ppad, 0);
         for (int e = 0; e < n; e++)
@@ -407,6 +427,39 @@ extern "C" int clothhip_get_state(clothhip_handle *h, int32_t env0, int32_t n, d
         for (int e = 0; e < n; e++)
             for (int i = 0; i < h->P; i++) pinned[(size_t)e * h->P + i] = c[(size_t)e * h->Ppad + i] ? 1 : 0;
     }
+    return 0;
+}
+
+extern "C" int clothhip_get_rest(clothhip_handle *h, int32_t env0, int32_t n, double *rest) {
+    if (int rc = check_range(h, env0, n)) return rc;
+    if (!rest) return fail(CLOTHHIP_EINVAL, "rest is NULL");
+    HIPCHECK(hipSetDevice(h->device));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    std::vector<unsigned char> buf((size_t)h->Spad * h->tsz);
+    for (int e = 0; e < n; e++) {
+        const char *src = (const char *)h->d_rest + (size_t)(env0 + e) * h->rest_stride * h->tsz;   // stride 0: the shared table
+        if (e == 0 || h->rest_stride) HIPCHECK(hipMemcpy(buf.data(), src, buf.size(), hipMemcpyDeviceToHost));
+        for (int p = 0; p < h->S; p++)          // level order -> list order (Spring.rest_length of cloth.springs[s])
+            rest[(size_t)e * h->S + h->lv.order[p]] = h->precision == CLOTHHIP_F64 ? ((const double *)buf.data())[p]
+                                                                                  : (double)((const float *)buf.data())[p];
+    }
+    return 0;
+}
+
+extern "C" int clothhip_reset_flat(clothhip_handle *h, const uint8_t *mask) {
+    if (!h) return fail(CLOTHHIP_EINVAL, "handle is NULL");
+    HIPCHECK(hipSetDevice(h->device));
+    if (mask) HIPCHECK(hipMemcpyAsync(h->d_active, mask, (size_t)h->E, hipMemcpyHostToDevice, h->stream));
+    if (h->precision == CLOTHHIP_F64)
+        hipLaunchKernelGGL(k_reset_flat<double>, dim3(h->E), dim3(256), 0, h->stream, (double *)h->d_pos, (double *)h->d_prev, h->d_cnt,
+                           h->d_tear, (const double *)h->d_flat, mask ? h->d_active : nullptr, h->Ppad, (double *)h->d_rest,
+                           (const double *)h->d_flat_rest, h->rest_stride, h->Spad);
+    else
+        hipLaunchKernelGGL(k_reset_flat<float>, dim3(h->E), dim3(256), 0, h->stream, (float *)h->d_pos, (float *)h->d_prev, h->d_cnt,
+                           h->d_tear, (const float *)h->d_flat, mask ? h->d_active : nullptr, h->Ppad, (float *)h->d_rest,
+                           (const float *)h->d_flat_rest, h->rest_stride, h->Spad);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(h->stream));
     return 0;
 }
 
@@ -496,6 +549,7 @@ template <typename T> static StepArgs<T> make_args(clothhip_handle *h, const Clo
     a.HT = h->HT; a.ht_bits = h->ht_bits; a.lvw_shift = h->lvw_shift;
     a.rest_stride = h->rest_stride; a.phase_mask = h->phase_mask;
     a.k = make_consts<T>(h->prm);
+    a.fz = nullptr;
     return a;
 }
 
@@ -504,22 +558,24 @@ template <typename T> static StepArgs<T> make_args(clothhip_handle *h, const Clo
     X(T, 256, 3, 2, true) X(T, 256, 3, 2, false) X(T, 256, 3, 1, false) X(T, 256, 3, 0, false)   \
     X(T, 512, 5, 0, false) X(T, 512, 5, 1, false) X(T, 1024, 3, 0, false) X(T, 1024, 3, 1, false) X(T, 1024, 4, 0, false)
 
-template <typename T> static const void *stepper_fn_t(const clothhip_handle *h) {
+template <typename T, bool FUSED> static const void *stepper_fn_t(const clothhip_handle *h) {
 #define X(T_, NT, PPT, TAB, RR) \
-    if (h->nt == NT && h->ppt == PPT && h->tab == TAB && h->rest_reg == RR) return (const void *)k_run_schedule<T_, NT, PPT, TAB, RR>;
+    if (h->nt == NT && h->ppt == PPT && h->tab == TAB && h->rest_reg == RR) return (const void *)k_run_schedule<T_, NT, PPT, TAB, RR, FUSED>;
     CLOTH_VARIANTS(X, T)
 #undef X
     return nullptr;
 }
-static const void *stepper_fn(const clothhip_handle *h) {
-    return h->precision == CLOTHHIP_F64 ? stepper_fn_t<double>(h) : stepper_fn_t<float>(h);
+static const void *stepper_fn(const clothhip_handle *h, bool fused) {
+    if (fused) return h->precision == CLOTHHIP_F64 ? stepper_fn_t<double, true>(h) : stepper_fn_t<float, true>(h);
+    return h->precision == CLOTHHIP_F64 ? stepper_fn_t<double, false>(h) : stepper_fn_t<float, false>(h);
 }
 
-template <typename T> static void launch_run(clothhip_handle *h, const ClothSchedule *d_sched) {
+template <typename T, bool FUSED> static void launch_run(clothhip_handle *h, const ClothSchedule *d_sched, const void *d_fz) {
     StepArgs<T> a = make_args<T>(h, d_sched);
+    a.fz = (const FusedArgs<T> *)d_fz;
 #define X(T_, NT, PPT, TAB, RR)                                                                         \
     if (h->nt == NT && h->ppt == PPT && h->tab == TAB && h->rest_reg == RR) {                           \
-        hipLaunchKernelGGL((k_run_schedule<T_, NT, PPT, TAB, RR>), dim3(h->E), dim3(NT), h->lds_bytes, h->stream, a); \
+        hipLaunchKernelGGL((k_run_schedule<T_, NT, PPT, TAB, RR, FUSED>), dim3(h->E), dim3(NT), h->lds_bytes, h->stream, a); \
         return;                                                                                         \
     }
     CLOTH_VARIANTS(X, T)
@@ -528,8 +584,8 @@ template <typename T> static void launch_run(clothhip_handle *h, const ClothSche
 
 static int run_common(clothhip_handle *h, const ClothSchedule *d_sched) {
     HIPCHECK(hipEventRecord(h->ev0, h->stream));
-    if (h->precision == CLOTHHIP_F64) launch_run<double>(h, d_sched);
-    else launch_run<float>(h, d_sched);
+    if (h->precision == CLOTHHIP_F64) launch_run<double, false>(h, d_sched, nullptr);
+    else launch_run<float, false>(h, d_sched, nullptr);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipEventRecord(h->ev1, h->stream));
     h->have_timing = true;
@@ -570,6 +626,124 @@ extern "C" int clothhip_sync(clothhip_handle *h, int32_t *executed) {
 extern "C" int clothhip_run(clothhip_handle *h, const ClothSchedule *sched, int32_t *executed) {
     if (int rc = clothhip_run_async(h, sched)) return rc;
     return clothhip_sync(h, executed);
+}
+
+
+// ---- whole episodes on the device ---------------------------------------------------------------------------------
+template <typename T> static void fill_fused(clothhip_handle *h, FusedArgs<T> &f, const ClothEpisodeParams *ep, int T_, int policy,
+                                             const double *d_actions, bool have_parg, bool have_scripts, bool have_resets, bool have_obs,
+                                             bool have_robs, int NS, int NH) {
+    memset(&f, 0, sizeof(f));
+    f.nT = T_; f.policy = policy; f.NS = NS; f.NH = NH;
+    f.actions = d_actions;
+    f.policy_arg = have_parg ? h->d_fparg : nullptr;
+    f.scripts = have_scripts ? (const ClothResetScript *)h->d_fscr : nullptr;
+    f.num_steps = h->d_fsteps; f.done = h->d_fdone;
+    f.records = (ClothStepRecord *)h->d_frec;
+    f.resets = have_resets ? (ClothResetRecord *)h->d_frst : nullptr;
+    f.obs = have_obs ? (float *)h->d_fobs : nullptr;
+    f.reset_obs = have_robs ? (float *)h->d_frobs : nullptr;
+    f.flat = (const T *)h->d_flat;
+    f.levels = h->d_levels; f.n_glevels = h->n_grab_levels; f.E = h->E;
+    f.two_thickness = 2 * h->prm.thickness; f.half_thickness = h->prm.thickness / 2.0;
+    f.ep = *ep;
+}
+
+static int grow(void **p, size_t *cap, size_t need) {
+    if (*cap >= need) return 0;
+    if (*p) HIPCHECK(hipFree(*p));
+    *p = nullptr; *cap = 0;
+    HIPCHECK(hipMalloc(p, need));
+    *cap = need;
+    return 0;
+}
+
+static int fused_scratch(const clothhip_handle *h, int *need_out) {
+    int NS = 1; while (NS < h->P) NS <<= 1;
+    const int NH = h->Ppad + 8;
+    *need_out = (2 * NS + 2 * NH + 64) * 8;
+    const LdsLayout lay((int)h->tsz, h->Ppad, h->Spad, h->lv.n_levels, h->n_levels8, h->HT, h->tab, h->cell_copy);
+    return lay.total - lay.ent;
+}
+
+extern "C" int clothhip_fused_supported(const clothhip_handle *h) {
+    if (!h) return fail(CLOTHHIP_EINVAL, "handle is NULL");
+    int need = 0;
+    return fused_scratch(h, &need) >= need ? 1 : 0;
+}
+
+extern "C" int clothhip_run_actions(clothhip_handle *h, const ClothEpisodeParams *ep, int32_t T_, int32_t policy,
+                                    const double *actions, int32_t actions_on_device, const int32_t *policy_arg,
+                                    const ClothResetScript *scripts, int32_t *num_steps, uint8_t *done,
+                                    ClothStepRecord *records, ClothResetRecord *resets, float *obs, float *reset_obs) {
+    if (!h || !ep || !num_steps || !done || !records) return fail(CLOTHHIP_EINVAL, "NULL argument");
+    if (T_ < 1 || T_ > 4096) return fail(CLOTHHIP_EINVAL, "T must be in [1, 4096]");
+    if (policy != CLOTHHIP_POLICY_TABLE && policy != CLOTHHIP_POLICY_ORACLE_CORNER) return fail(CLOTHHIP_EINVAL, "unknown policy %d", policy);
+    if (policy == CLOTHHIP_POLICY_TABLE && !actions) return fail(CLOTHHIP_EINVAL, "the table policy needs actions[T][E][4]");
+    if (policy == CLOTHHIP_POLICY_ORACLE_CORNER && h->N != 25)
+        return fail(CLOTHHIP_ESTATE, "the oracle-corner policy is defined for 25x25 cloths only (analytic.py:106)");
+    if (scripts && h->rest_stride != 0)
+        return fail(CLOTHHIP_ESTATE, "in-kernel resets need the shared flat rest table (tiers 1 and 3); this handle has per-env rest lengths");
+    if (!(ep->reduce_factor > 0) || ep->max_actions < 1) return fail(CLOTHHIP_EINVAL, "bad episode parameters");
+    int NS = 1; while (NS < h->P) NS <<= 1;
+    const int NH = h->Ppad + 8;
+    int need = 0;
+    const int have = fused_scratch(h, &need);
+    if (have < need)
+        return fail(CLOTHHIP_ESTATE, "n_side %d: the in-kernel metrics need %d B of LDS scratch, this variant has %d", h->N, need, have);
+    HIPCHECK(hipSetDevice(h->device));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    const size_t E = h->E, nrec = (size_t)T_ * E;
+    if (!h->d_fz) {
+        HIPCHECK(hipMalloc(&h->d_fz, 1024));
+        HIPCHECK(hipMalloc(&h->d_fscr, E * 3 * sizeof(ClothResetScript)));
+        HIPCHECK(hipMalloc(&h->d_frst, E * 2 * sizeof(ClothResetRecord)));
+        HIPCHECK(hipMalloc(&h->d_fsteps, E * 4));
+        HIPCHECK(hipMalloc(&h->d_fparg, E * 4));
+        HIPCHECK(hipMalloc(&h->d_fdone, E));
+    }
+    if (int rc = grow(&h->d_frec, &h->cap_frec, nrec * sizeof(ClothStepRecord))) return rc;
+    const double *d_actions = nullptr;
+    if (policy == CLOTHHIP_POLICY_TABLE) {
+        if (actions_on_device) d_actions = actions;
+        else {
+            if (int rc = grow(&h->d_fact, &h->cap_fact, nrec * 4 * 8)) return rc;
+            HIPCHECK(hipMemcpyAsync(h->d_fact, actions, nrec * 4 * 8, hipMemcpyHostToDevice, h->stream));
+            d_actions = (const double *)h->d_fact;
+        }
+    }
+    if (obs) if (int rc = grow(&h->d_fobs, &h->cap_fobs, nrec * 3 * h->P * 4)) return rc;
+    if (reset_obs && !h->d_frobs) HIPCHECK(hipMalloc(&h->d_frobs, E * 2 * 3 * h->P * 4));
+    if (reset_obs) HIPCHECK(hipMemsetAsync(h->d_frobs, 0, E * 2 * 3 * h->P * 4, h->stream));
+    if (policy_arg) HIPCHECK(hipMemcpyAsync(h->d_fparg, policy_arg, E * 4, hipMemcpyHostToDevice, h->stream));
+    if (scripts) HIPCHECK(hipMemcpyAsync(h->d_fscr, scripts, E * 3 * sizeof(ClothResetScript), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(hipMemcpyAsync(h->d_fsteps, num_steps, E * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(hipMemcpyAsync(h->d_fdone, done, E, hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(hipMemsetAsync(h->d_frec, 0, nrec * sizeof(ClothStepRecord), h->stream));
+    if (resets) HIPCHECK(hipMemsetAsync(h->d_frst, 0, E * 2 * sizeof(ClothResetRecord), h->stream));
+    static_assert(sizeof(FusedArgs<double>) <= 1024 && sizeof(FusedArgs<float>) <= 1024, "fused argument block");
+    unsigned char fzbuf[1024];
+    if (h->precision == CLOTHHIP_F64)
+        fill_fused<double>(h, *reinterpret_cast<FusedArgs<double> *>(fzbuf), ep, T_, policy, d_actions, policy_arg != nullptr, scripts != nullptr, resets != nullptr, obs != nullptr, reset_obs != nullptr, NS, NH);
+    else
+        fill_fused<float>(h, *reinterpret_cast<FusedArgs<float> *>(fzbuf), ep, T_, policy, d_actions, policy_arg != nullptr, scripts != nullptr, resets != nullptr, obs != nullptr, reset_obs != nullptr, NS, NH);
+    HIPCHECK(hipMemcpyAsync(h->d_fz, fzbuf, 1024, hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));          // fzbuf is on this stack frame
+    HIPCHECK(hipEventRecord(h->ev0, h->stream));
+    if (h->precision == CLOTHHIP_F64) launch_run<double, true>(h, h->d_sched, h->d_fz);
+    else launch_run<float, true>(h, h->d_sched, h->d_fz);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipEventRecord(h->ev1, h->stream));
+    h->have_timing = true;
+    h->pending_exec = true;
+    HIPCHECK(hipMemcpyAsync(records, h->d_frec, nrec * sizeof(ClothStepRecord), hipMemcpyDeviceToHost, h->stream));
+    if (resets) HIPCHECK(hipMemcpyAsync(resets, h->d_frst, E * 2 * sizeof(ClothResetRecord), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipMemcpyAsync(num_steps, h->d_fsteps, E * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipMemcpyAsync(done, h->d_fdone, E, hipMemcpyDeviceToHost, h->stream));
+    if (obs) HIPCHECK(hipMemcpyAsync(obs, h->d_fobs, nrec * 3 * h->P * 4, hipMemcpyDeviceToHost, h->stream));
+    if (reset_obs) HIPCHECK(hipMemcpyAsync(reset_obs, h->d_frobs, E * 2 * 3 * h->P * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    return 0;
 }
 
 extern "C" int clothhip_update(clothhip_handle *h, int32_t n_sub, const double *delta) {
@@ -615,27 +789,39 @@ extern "C" double clothhip_hull_area(const double *xy, int32_t n) {
     return 0.5 * std::fabs(a2);
 }
 
-extern "C" int clothhip_metrics(clothhip_handle *h, double *coverage, double *variance_inv, uint8_t *oob, uint8_t *tear) {
-    if (!h) return fail(CLOTHHIP_EINVAL, "handle is NULL");
-    if (tear) if (int rc = clothhip_get_tear(h, tear)) return rc;
-    if (!coverage && !variance_inv && !oob) return 0;
-    HIPCHECK(hipSetDevice(h->device));
+static int launch_metrics(clothhip_handle *h) {
     int NS = 1; while (NS < h->P) NS <<= 1;
     const int NH = h->Ppad + 8;                 // the monotone chain holds at most m + 1 <= P + 1 points
     const int lds = (2 * NS + 2 * NH + 64) * 8;
+    const double half_thick = h->prm.thickness / 2.0;                                   // cloth_env.py:604
     if (h->precision == CLOTHHIP_F64) {
-        HIPCHECK(hipFuncSetAttribute((const void *)k_metrics<double>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL(k_metrics<double>, dim3(h->E), dim3(256), lds, h->stream, (const double *)h->d_pos, h->P, h->Ppad, NS, NH, h->d_cov, h->d_vinv, h->d_oob);
+        HIPCHECK(hipFuncSetAttribute((const void *)k_metrics<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL(k_metrics<double>, dim3(h->E), dim3(256), lds, h->stream, (const double *)h->d_pos, h->P, h->Ppad, NS, NH, h->d_cov, h->d_vinv, h->d_oob, h->d_hcnt, half_thick);
     } else {
-        HIPCHECK(hipFuncSetAttribute((const void *)k_metrics<float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL(k_metrics<float>, dim3(h->E), dim3(256), lds, h->stream, (const float *)h->d_pos, h->P, h->Ppad, NS, NH, h->d_cov, h->d_vinv, h->d_oob);
+        HIPCHECK(hipFuncSetAttribute((const void *)k_metrics<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL(k_metrics<float>, dim3(h->E), dim3(256), lds, h->stream, (const float *)h->d_pos, h->P, h->Ppad, NS, NH, h->d_cov, h->d_vinv, h->d_oob, h->d_hcnt, half_thick);
     }
     HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int clothhip_metrics_ex(clothhip_handle *h, double *coverage, double *variance_inv, uint8_t *oob, uint8_t *tear,
+                                   int32_t *n_below_half_thickness) {
+    if (!h) return fail(CLOTHHIP_EINVAL, "handle is NULL");
+    if (tear) if (int rc = clothhip_get_tear(h, tear)) return rc;
+    if (!coverage && !variance_inv && !oob && !n_below_half_thickness) return 0;
+    HIPCHECK(hipSetDevice(h->device));
+    if (int rc = launch_metrics(h)) return rc;
     if (coverage) HIPCHECK(hipMemcpyAsync(coverage, h->d_cov, (size_t)h->E * 8, hipMemcpyDeviceToHost, h->stream));
     if (variance_inv) HIPCHECK(hipMemcpyAsync(variance_inv, h->d_vinv, (size_t)h->E * 8, hipMemcpyDeviceToHost, h->stream));
     if (oob) HIPCHECK(hipMemcpyAsync(oob, h->d_oob, (size_t)h->E, hipMemcpyDeviceToHost, h->stream));
+    if (n_below_half_thickness) HIPCHECK(hipMemcpyAsync(n_below_half_thickness, h->d_hcnt, (size_t)h->E * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(hipStreamSynchronize(h->stream));
     return 0;
+}
+
+extern "C" int clothhip_metrics(clothhip_handle *h, double *coverage, double *variance_inv, uint8_t *oob, uint8_t *tear) {
+    return clothhip_metrics_ex(h, coverage, variance_inv, oob, tear, nullptr);
 }
 
 extern "C" int clothhip_write_obs_f32_device(clothhip_handle *h, void *d_out) {
@@ -646,6 +832,37 @@ extern "C" int clothhip_write_obs_f32_device(clothhip_handle *h, void *d_out) {
     else
         hipLaunchKernelGGL(k_write_obs<float>, dim3(h->E), dim3(256), 0, h->stream, (const float *)h->d_pos, (float *)d_out, h->P, h->Ppad);
     HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+// ---- raw device buffers on the handle's device (collective staging of the multi-GPU driver) ------------------
+extern "C" int clothhip_device_alloc(clothhip_handle *h, uint64_t nbytes, void **d_out) {
+    if (!h || !d_out || nbytes == 0) return fail(CLOTHHIP_EINVAL, "bad argument");
+    HIPCHECK(hipSetDevice(h->device));
+    hipError_t err = hipMalloc(d_out, (size_t)nbytes);
+    if (err != hipSuccess) return fail(err == hipErrorOutOfMemory ? CLOTHHIP_ENOMEM : CLOTHHIP_EHIP, "hipMalloc(%llu) failed: %s",
+                                       (unsigned long long)nbytes, hipGetErrorString(err));
+    return 0;
+}
+extern "C" int clothhip_device_free(clothhip_handle *h, void *d) {
+    if (!h) return fail(CLOTHHIP_EINVAL, "handle is NULL");
+    HIPCHECK(hipSetDevice(h->device));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    if (d) HIPCHECK(hipFree(d));
+    return 0;
+}
+extern "C" int clothhip_device_upload(clothhip_handle *h, void *d_dst, const void *src, uint64_t nbytes) {
+    if (!h || !d_dst || !src) return fail(CLOTHHIP_EINVAL, "NULL argument");
+    HIPCHECK(hipSetDevice(h->device));
+    HIPCHECK(hipMemcpyAsync(d_dst, src, (size_t)nbytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));      // the host buffer is never retained
+    return 0;
+}
+extern "C" int clothhip_device_download(clothhip_handle *h, void *dst, const void *d_src, uint64_t nbytes) {
+    if (!h || !dst || !d_src) return fail(CLOTHHIP_EINVAL, "NULL argument");
+    HIPCHECK(hipSetDevice(h->device));
+    HIPCHECK(hipMemcpyAsync(dst, d_src, (size_t)nbytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
     return 0;
 }
 

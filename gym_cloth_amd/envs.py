@@ -175,6 +175,8 @@ class ClothVecEnv(object):
         self.last_executed = np.zeros(E, dtype=np.int64)
         self.last_grabbed = np.zeros(E, dtype=np.int64)
         self.last_iters_pull = np.zeros(E, dtype=np.int64)
+        self._ep_done = np.zeros(E, dtype=bool)                      # episode over, reset pending (step_many's auto-reset)
+        self._pending = [None] * E                                   # pre-drawn reset scripts of step_many, per env
         self.total_substeps = 0                                      # executed update() calls, all envs
 
     def close(self):
@@ -193,6 +195,7 @@ class ClothVecEnv(object):
         for e, s in enumerate(seeds):
             self.np_randoms[e], s2 = seeding.np_random(s)
             out.append(s2)
+        self._pending = [None] * self.E                                # reset scripts pre-drawn from the old generators
         return out
 
     @property
@@ -209,9 +212,13 @@ class ClothVecEnv(object):
                               self.iters_pull_max, self.iters_grip_rest, self.iters_rest)
 
     # ---- one action for every (active) env ----------------------------------------------------------------
-    def step(self, actions, initialize=False, active=None):
+    def step(self, actions, initialize=False, active=None, auto_reset=False):
         """ClothEnv.step (cloth_env.py:369-534) for all envs at once.
-        Returns (obs[E,3P], rew[E], done[E], info dict of arrays); with initialize=True returns None."""
+        Returns (obs[E,3P], rew[E], done[E], info dict of arrays); with initialize=True returns None.
+        auto_reset: envs that finish their episode in this step are reset before the call returns, as the
+        reference's episode loop does (`while not done: step` then `env.reset()`, examples/analytic.py:872-882);
+        their row of `obs` is then the first observation of the new episode, info['terminal_observation'] holds
+        the last one of the finished episode and info['reset_mask'] says which envs were reset."""
         E = self.E
         act_mask = np.ones(E, dtype=bool) if active is None else np.asarray(active, dtype=bool).copy()
         d = self.decode_actions(actions)
@@ -245,21 +252,230 @@ class ClothVecEnv(object):
         self.num_steps[act_mask] += 1
         rew = self._reward(actions, exit_early, cov, vinv, oob, act_mask)
         term = self._terminal(oob, act_mask)
+        self._ep_done = np.where(act_mask, term, self._ep_done)
         info = {
             'num_steps': self.num_steps.copy(), 'num_sim_steps': self.num_sim_steps.copy(),
             'actual_coverage': self._current_coverage.copy(), 'start_coverage': self._start_coverage.copy(),
             'variance_inv': vinv, 'start_variance_inv': self._start_variance_inv.copy(),
             'have_tear': self.have_tear.copy(), 'out_of_bounds': oob,
         }
-        return self.state, rew, term, info
+        obs = self.state
+        if auto_reset and term.any():
+            info['terminal_observation'] = obs
+            info['reset_mask'] = term.copy()
+            obs = self.reset(mask=term)
+        return obs, rew, term, info
+
+    # ---- whole episodes on the device (clothhip_run_actions) ------------------------------------------------------
+    def _episode_params(self):
+        from ._lib import ClothEpisodeParams
+        ep = ClothEpisodeParams()
+        ep.max_actions = int(self.max_actions)
+        ep.iters_up_rest, ep.iters_grip_rest, ep.iters_rest = int(self.iters_up_rest), int(self.iters_grip_rest), int(self.iters_rest)
+        ep.clip_act_space, ep.force_grab = int(bool(self._clip_act_space)), int(bool(self._force_grab))
+        ep.iters_up = float(self.iters_up)
+        ep.reduce_factor, ep.grip_radius = float(self.reduce_factor), float(self.grip_radius)
+        ep.radius_inc, ep.dz_up = float(self._radius_inc), 0.0025
+        for k in range(4):
+            ep.act_low[k], ep.act_high[k] = float(self.action_space.low[k]), float(self.action_space.high[k])
+        ep.coverage_done = float(_REWARD_THRESHOLDS[self.reward_type])
+        return ep
+
+    def _domrand_draws(self, rng):
+        """cloth_env.py:786-789: the draws every reset makes after the scripted actions."""
+        rng.uniform(low=40, high=50)
+        rng.uniform(low=0.7, high=1.3)
+        lim = rng.uniform(low=-15.0, high=15.0)
+        rng.uniform(low=-lim, high=lim, size=(self._wd, self._hd, 3))
+
+    def _draw_script(self, rng, tier, out):
+        """Draw ONE reset from `rng` in the reference's order (cloth.pyx:75; cloth_env.py:851-877 / :959-978) into the
+        script record `out`. Returns (init_side, rng state if the reset runs 2 pulls, rng state if it runs 3 (tier 1))."""
+        init_side = bool(rng.rand() > 0.5)                                               # cloth.pyx:75
+        out['valid'], out['_pad'] = 1, 0
+        if tier == 1:
+            lim = 0.20
+            out['n_pulls'], out['settle_after'] = 3, 0
+            s2 = None
+            for k in range(3):
+                if k == 2:
+                    s2 = rng.get_state()                          # the third pull's draws happen only if coverage >= 0.90
+                pl = out['pull'][k]
+                pl['point'] = rng.randint(self.P)
+                pl['dx'] = self._randval_minabs(rng, -lim, lim, 0.08)
+                pl['dy'] = self._randval_minabs(rng, -lim, lim, 0.08)
+                pl['x'] = pl['y'] = 0.0
+                pl['need_coverage'], pl['coverage_min'] = int(k == 2), 0.90
+                pl['iters_up'] = float(self.iters_up)
+            return init_side, s2, rng.get_state()
+        lim = 0.25                                                                       # tier 3
+        out['n_pulls'], out['settle_after'] = 1, 800
+        pl = out['pull'][0]
+        pl['iters_up'] = rng.uniform(low=200, high=280)
+        pl['x'] = self._randval_minabs(rng, 0.30, 0.70)
+        pl['y'] = self._randval_minabs(rng, 0.30, 0.70)
+        pl['dx'] = self._randval_minabs(rng, -lim, lim, 0.10)
+        pl['dy'] = self._randval_minabs(rng, -lim, lim, 0.10)
+        pl['point'], pl['need_coverage'], pl['coverage_min'] = -1, 0, 0.0
+        st = rng.get_state()
+        return init_side, st, st
+
+    def _drop_pending(self, e):
+        pend = self._pending[e]
+        if pend is not None:
+            self.np_randoms[e].set_state(pend['s0'])
+            self._pending[e] = None
+
+    def _prepare_scripts(self):
+        """Reset scripts of every env for the next launch, [E, 3]: slot 0 = the env's next reset, slots 1 / 2 = the one
+        after it when slot 0 ran 2 / 3 pulls (the RNG stream forks at tier 1's conditional third pull). The env RNGs are
+        left where they were; the draws are committed after the launch according to what the device consumed."""
+        from ._lib import RESET_SCRIPT_DTYPE
+        tier = {'tier1': 1, 'tier3': 3}[self._init_type]
+        scripts = np.zeros((self.E, 3), dtype=RESET_SCRIPT_DTYPE)
+        for e in range(self.E):
+            pend = self._pending[e]
+            if pend is None:
+                rng = self.np_randoms[e]
+                pend = {'s0': rng.get_state(), 'rec': np.zeros(3, dtype=RESET_SCRIPT_DTYPE), 'side': [False] * 3,
+                        'after': [None] * 3}
+                side, s2, s3 = self._draw_script(rng, tier, pend['rec'][0])
+                pend['side'][0], pend['after'][0] = side, (s2, s3)
+                for slot, st in ((1, s2), (2, s3)):
+                    if slot == 2 and tier != 1:
+                        break                                     # no fork: slot 1 is the only successor
+                    rng.set_state(st)
+                    if self._consume_domrand:
+                        self._domrand_draws(rng)
+                    side, a2, a3 = self._draw_script(rng, tier, pend['rec'][slot])
+                    pend['side'][slot], pend['after'][slot] = side, (a2, a3)
+                rng.set_state(pend['s0'])
+                self._pending[e] = pend
+            scripts[e] = pend['rec']
+        return scripts
+
+    def step_many(self, actions=None, n_actions=None, policy=None, auto_reset=True, want_obs=False, reset_tail=False,
+                  actions_device_ptr=None):
+        """T consecutive `step(a_t, auto_reset=auto_reset)` calls for every env in ONE device launch
+        (clothhip_run_actions): decoding, grab, the substep loop, metrics, the terminal test and the episode resets all
+        run in the kernel, envs never wait for each other, and the host only does the reward / info bookkeeping below.
+
+        actions: float64[T, E, 4], or policy='oracle_corner' (examples/analytic.py's oracle, evaluated on the device)
+        with n_actions=T. Resets inside the launch need init type tier1 or tier3 (tier 2 rebuilds per-env rest lengths
+        on the host): with tier2, or auto_reset=False, an env whose episode ends idles for the rest of the launch
+        (`ran` False). An env can be reset at most twice per launch. An episode that ends in the last slot is reset by the
+        NEXT launch, or here on the host with reset_tail=True (then the returned obs is what T sequential steps return).
+
+        Returns a dict of arrays [T, E] (rew, done, ran, executed, n_grabbed, reset_before, and the info keys of step())
+        plus 'obs' [E, 3P] (state after the launch), 'actions' [T, E, 4] and, with want_obs, 'obs_t' [T, E, 3P]."""
+        from . import _lib
+        E = self.E
+        if policy in (None, 'table'):
+            pol = _lib.POLICY_TABLE
+            if actions_device_ptr is None:
+                actions = np.ascontiguousarray(actions, dtype=np.float64)
+                T = actions.shape[0]
+            else:
+                T = int(n_actions)
+        elif policy == 'oracle_corner':
+            pol, T = _lib.POLICY_ORACLE_CORNER, int(n_actions)
+            assert self._delta_actions and self.num_points == 625                        # analytic.py:103-106
+        else:
+            raise ValueError(policy)
+        if not self._delta_actions:
+            raise NotImplementedError("non-delta actions are decoded on the host only (cos/sin, cloth_env.py:452-453)")
+        dev_reset = auto_reset and self._init_type in ('tier1', 'tier3')
+        scripts = self._prepare_scripts() if dev_reset else None
+        parg = None
+        if pol == _lib.POLICY_ORACLE_CORNER and self._init_type == 'tier2':
+            parg = (~self.init_side).astype(np.int32)                                    # analytic.py:108-114
+        nsteps = np.ascontiguousarray(self.num_steps, dtype=np.int32)
+        done_io = np.ascontiguousarray(self._ep_done, dtype=np.uint8)
+        rec, rst, obs_t, robs = self.batch.run_actions(self._episode_params(), T, nsteps, done_io, actions=actions, policy=pol,
+                                                 policy_arg=parg, scripts=scripts, want_obs=want_obs,
+                                                 actions_device_ptr=actions_device_ptr)
+        if (rec['ran'] == 2).any():
+            raise FloatingPointError("iters_pull does not terminate (non-finite action?)")
+        out = {k: np.zeros((T, E)) for k in ('rew', 'actual_coverage', 'start_coverage', 'variance_inv', 'start_variance_inv')}
+        for k in ('done', 'ran', 'have_tear', 'out_of_bounds'):
+            out[k] = np.zeros((T, E), dtype=bool)
+        for k in ('executed', 'n_grabbed', 'num_steps', 'num_sim_steps', 'reset_before', 'reset_substeps'):
+            out[k] = np.zeros((T, E), dtype=np.int64)
+        out['actions'] = rec['action'].copy()
+        n_consumed = np.zeros(E, dtype=np.int64)
+        for t in range(T):
+            r = rec[t]
+            rb = r['reset_before'].astype(np.int64)
+            for e in np.nonzero(rb)[0]:                               # ClothEnv.reset bookkeeping (cloth_env.py:717-790)
+                k = int(rb[e]) - 1
+                q = rst[e, k]
+                pend = self._pending[e]
+                slot = 0 if k == 0 else (2 if int(rst[e, 0]['pulls_run']) >= 3 else 1)
+                self.init_side[e] = pend['side'][slot]
+                n_consumed[e] = k + 1
+                sub = int(q['executed'].sum()) + int(q['settle_executed'])
+                out['reset_substeps'][t, e] = sub
+                self.total_substeps += sub
+                self.num_steps[e] = 0; self.num_sim_steps[e] = 0
+                self.have_tear[e] = bool(q['tear'])
+                self._prev_reward[e] = q['start_coverage']
+                self._start_coverage[e] = q['start_coverage']
+                self._start_variance_inv[e] = q['start_variance_inv']
+                self._current_coverage[e] = 0.0
+                self._ep_done[e] = False
+            ran = r['ran'] == 1
+            executed = np.where(ran, r['executed'], 0).astype(np.int64)
+            self.total_substeps += int(executed.sum())
+            self.have_tear |= ran & (r['tear'] != 0)
+            self.num_sim_steps[ran] += executed[ran]
+            self.num_steps[ran] += 1
+            oob = r['oob'] != 0
+            rew = self._reward(r['action'], ran & (r['n_grabbed'] == 0), r['coverage'], r['variance_inv'], oob, ran,
+                               height=r['n_below_half_thickness'] / float(self.P))
+            term = self._terminal(oob, ran)
+            if not np.array_equal(term[ran], (r['done'] != 0)[ran]):
+                raise RuntimeError("device and host disagree on the terminal test")
+            self._ep_done = np.where(ran, term, self._ep_done)
+            self.last_executed = np.where(ran, executed, self.last_executed)
+            self.last_grabbed = np.where(ran, r['n_grabbed'], self.last_grabbed)
+            self.last_iters_pull = np.where(ran, r['iters_pull'], self.last_iters_pull)
+            out['rew'][t], out['done'][t], out['ran'][t] = rew, term, ran
+            out['executed'][t], out['n_grabbed'][t], out['reset_before'][t] = executed, r['n_grabbed'], rb
+            out['num_steps'][t], out['num_sim_steps'][t] = self.num_steps, self.num_sim_steps
+            out['actual_coverage'][t], out['start_coverage'][t] = self._current_coverage, self._start_coverage
+            out['variance_inv'][t], out['start_variance_inv'][t] = r['variance_inv'], self._start_variance_inv
+            out['have_tear'][t], out['out_of_bounds'][t] = self.have_tear, oob
+        assert np.array_equal(self.num_steps.astype(np.int32), nsteps) and np.array_equal(self._ep_done, done_io != 0)
+        if dev_reset:                                                 # commit the RNG draws the device consumed
+            for e in np.nonzero(n_consumed)[0]:
+                pend = self._pending[e]
+                slot = 0
+                for k in range(int(n_consumed[e])):
+                    pulls3 = int(rst[e, k]['pulls_run']) >= 3
+                    st = pend['after'][slot][1 if pulls3 else 0]
+                    if k == 0:
+                        slot = 2 if (pulls3 and self._init_type == 'tier1') else 1
+                rng = self.np_randoms[e]
+                rng.set_state(st)
+                if self._consume_domrand:
+                    self._domrand_draws(rng)
+                self._pending[e] = None
+        obs = self.state
+        if reset_tail and auto_reset and self._ep_done.any():
+            obs = self.reset(mask=self._ep_done.copy())
+        out['obs'] = obs
+        if want_obs:
+            out['obs_t'], out['reset_obs'] = obs_t, robs
+        return out
 
     # ---- reward / terminal (cloth_env.py:536-715) ------------------------------------------------------------
     def _height_fraction(self):
-        z = self.batch.positions()[:, :, 2]
-        return np.sum(z < self.cfg['cloth']['thickness'] / 2.0, axis=1) / float(self.P)
+        """compute_height (cloth_env.py:603-609): the count comes from the device metrics kernel."""
+        return self.batch.metrics(want_height=True)[4]
 
-    def _reward(self, actions, exit_early, cov, vinv, oob, mask):
+    def _reward(self, actions, exit_early, cov, vinv, oob, mask, height=None):
         E = self.E
+        hf = (lambda: height) if height is not None else self._height_fraction
         rew = np.zeros(E)
         rew += np.where(self.have_tear, self._tear_penalty, np.where(oob, self._oob_penalty, 0.0))   # :557-562
         rew += np.where(exit_early, self._nogrip_penalty, 0.0)                                       # :563-565
@@ -283,9 +499,9 @@ class ClothVecEnv(object):
         elif rt == 'coverage-delta':
             rew += delta(cov)
         elif rt == 'height':
-            rew += self._height_fraction()
+            rew += hf()
         elif rt == 'height-delta':
-            rew += delta(self._height_fraction())
+            rew += delta(hf())
         elif rt == 'variance':
             rew += vinv
         elif rt == 'variance-delta':
@@ -345,33 +561,34 @@ class ClothVecEnv(object):
             raise ValueError(self._init_type)                         # cloth.pyx:131-132
         if not self._delta_actions:
             raise NotImplementedError()                               # cloth_env.py:862, :917, :968
+        for e in idx:                                                 # scripts pre-drawn for step_many: give the draws back
+            self._drop_pending(e)
         # ---- Cloth(...) construction: RNG draws in the reference's order (cloth.pyx:75, :101) --------------
-        pos0, rest0 = self.batch.init_grid(1)
-        pos_all = np.empty((len(idx), P, 3))
-        rest_all = np.empty((len(idx), self.batch.S)) if tier == 2 else None
-        for k, e in enumerate(idx):
-            rng = self.np_randoms[e]
-            self.init_side[e] = rng.rand() > 0.5
-            if tier == 2:
+        if tier == 2:
+            pos_all = np.empty((len(idx), P, 3))
+            rest_all = np.empty((len(idx), self.batch.S))
+            for k, e in enumerate(idx):
+                rng = self.np_randoms[e]
+                self.init_side[e] = rng.rand() > 0.5
                 draws = rng.rand(P)                                   # one rand() per point, r-major
                 pos_all[k], rest_all[k] = self.batch.init_grid(2, self.init_side[e], draws)
-            else:
-                pos_all[k] = pos0
-        zeros_pin = np.zeros((1, P), dtype=np.uint8)
-        if len(idx) == E:                                             # whole batch: one upload
-            self.batch.set_state(pos_all, pos_all, np.zeros((E, P), dtype=np.uint8),
-                                 rest_all if tier == 2 else rest0, rest_shared=(tier != 2))
+            zeros_pin = np.zeros((len(idx), P), dtype=np.uint8)
+            k = 0
+            while k < len(idx):                                       # one upload per run of consecutive envs
+                j = k
+                while j + 1 < len(idx) and idx[j + 1] == idx[j] + 1:
+                    j += 1
+                self.batch.set_state(pos_all[k:j + 1], pos_all[k:j + 1], zeros_pin[k:j + 1], rest_all[k:j + 1],
+                                     env0=int(idx[k]), n=j + 1 - k, rest_shared=False)
+                k = j + 1
         else:
-            for k, e in enumerate(idx):
-                self.batch.set_state(pos_all[k][None], pos_all[k][None], zeros_pin,
-                                     rest_all[k][None] if tier == 2 else None, env0=int(e), n=1,
-                                     rest_shared=False)
-        t = self.batch.tear
-        t[m] = False
-        self.batch.tear = t
+            for e in idx:
+                self.init_side[e] = self.np_randoms[e].rand() > 0.5
+            self.batch.reset_flat(None if len(idx) == E else m)       # flat grid, nothing pinned, no tear: on the device
         self.num_steps[m] = 0
         self.num_sim_steps[m] = 0
         self.have_tear[m] = False
+        self._ep_done[m] = False
         self._iters_up_env[m] = float(self.iters_up)
         self._reset_actions(m, idx, tier)
         cov, vinv, _, _ = self.batch.metrics()                        # cloth_env.py:780-782
@@ -535,12 +752,20 @@ class ClothEnv(object):
         if self._start_state is not None:                             # cloth_env.py:736-741, :771-772
             s = self._start_state
             v = self._vec
+            rng = v.np_randoms[0]
+            v.init_side[0] = rng.rand() > 0.5                          # Cloth(state=...) still draws init_side, cloth.pyx:75
+            self.cloth.init_side = bool(v.init_side[0])
             v.batch.set_state(s['pos'][None], s['prev'][None], s['pinned'][None],
-                              s['rest'] if 'rest' in s else None)
-            v.batch.tear = [False]
+                              s['rest'] if 'rest' in s else None, rest_shared=True if 'rest' in s else None)
             v.num_steps[:] = 0; v.num_sim_steps[:] = 0; v.have_tear[:] = False
             cov, vinv, _, _ = v.batch.metrics()
             v._prev_reward[:] = cov; v._start_coverage[:] = cov; v._start_variance_inv[:] = vinv
+            v._current_coverage[:] = 0.0
+            if v._consume_domrand:                                     # cloth_env.py:786-789, as in the normal reset
+                rng.uniform(low=40, high=50)
+                rng.uniform(low=0.7, high=1.3)
+                lim = rng.uniform(low=-15.0, high=15.0)
+                rng.uniform(low=-lim, high=lim, size=(v._wd, v._hd, 3))
             return self.state
         obs = self._vec.reset()[0]
         self.cloth.init_side = bool(self._vec.init_side[0])
@@ -563,7 +788,7 @@ class ClothEnv(object):
     def save_state(self, cloth_file):
         """cloth_env.py:343-350 (npz of SoA arrays instead of a pickle of Python objects)."""
         pos, prev, pin = self._vec.batch.get_state()
-        np.savez(cloth_file, pos=pos[0], prev=prev[0], pinned=pin[0])
+        np.savez(cloth_file, pos=pos[0], prev=prev[0], pinned=pin[0], rest=self._vec.batch.get_rest(0, 1)[0])
 
     def _compute_coverage(self):
         return float(self._vec._compute_coverage()[0])

@@ -51,7 +51,7 @@ class Point(object):
             self._c._invalidate()
         elif not v and h.pinned[self._i]:
             h.pinned[self._i] = 0
-            self._c._dirty = True
+            self._c._dirty = self._c._pin_dirty = True
 
     def __repr__(self):
         return "({:.3f}, {:.3f}, {:.3f})".format(self.x, self.y, self.z)     # point.pyx:53-55
@@ -108,7 +108,7 @@ class Cloth(object):
         self.bounds, self.minimum_z, self.gravity = bounds, minimum_z, gravity
         self.render = False
         self.iter = 0
-        self._mirror, self._dirty = None, False
+        self._mirror, self._dirty, self._pin_dirty = None, False, False
         self._orig = batch.positions(self.env, 1)[0].copy()
         self._pts = [Point(self, i) for i in range(batch.P)]
 
@@ -124,12 +124,14 @@ class Cloth(object):
     def _flush(self):
         if self._dirty and self._mirror is not None:
             m = self._mirror
-            # NB set_state marks pinned points as grabbed; keep device-side pin bookkeeping when unchanged
-            self.batch.set_state(m.pos[None], m.prev[None], None, None, env0=self.env, n=1)
-        self._dirty = False
+            # a write into a live cloth: the sticky tear flag survives (cloth.pyx:272-273). The device-side pin
+            # bookkeeping (grab multiplicity) is only overwritten when a point was un-pinned through `pt.pinned = False`.
+            self.batch.set_state(m.pos[None], m.prev[None], m.pinned[None] if self._pin_dirty else None, None,
+                                 env0=self.env, n=1, keep_tear=True)
+        self._dirty = self._pin_dirty = False
 
     def _invalidate(self):
-        self._mirror, self._dirty = None, False
+        self._mirror, self._dirty, self._pin_dirty = None, False, False
 
     # ---- reference API -----------------------------------------------------------------------------------
     @property
@@ -179,11 +181,27 @@ class Gripper(object):
         m[self.cloth.env] = 1
         return m
 
-    def _after_grab(self, before):
-        self.cloth._invalidate()
-        after = self.cloth._host().pinned.astype(bool)
-        new = np.nonzero(after & ~before)[0]
-        self._grabbed.extend(self.cloth.pts[i] for i in new)
+    def _after_grab(self, x, y, top):
+        """gripper.pyx:39-41 / :52-53 append every hit to grabbed_pts, also points that are already pinned (a later
+        adjust then moves them once per entry): rebuild the hit set of THIS call on the host from the state the
+        device kernel saw, with the same tests."""
+        c = self.cloth
+        c._invalidate()
+        h = c._host()
+        d2 = (h.pos[:, 0] - x) * (h.pos[:, 0] - x) + (h.pos[:, 1] - y) * (h.pos[:, 1] - y)
+        inside = d2 < self.grip_radius                                                   # gripper.pyx:35 (radius not squared)
+        hits = np.zeros(0, dtype=np.int64)
+        if top:
+            curz = self.height
+            while curz > 0:                                                              # gripper.pyx:31-41
+                sel = inside & (np.abs(h.pos[:, 2] - curz) < self.thickness * 2)
+                if sel.any():
+                    hits = np.nonzero(sel)[0]
+                    break
+                curz -= self.thickness
+        else:
+            hits = np.nonzero(inside)[0]
+        self._grabbed.extend(c.pts[i] for i in hits)
 
     @property
     def grabbed_pts(self):
@@ -192,20 +210,18 @@ class Gripper(object):
     def grab_top(self, x, y):
         c = self.cloth
         c._flush()
-        before = c._host().pinned.astype(bool)
         b = c.batch
         b.grab_top(np.broadcast_to([x, y], (b.E, 2)), radius=np.full(b.E, float(self.grip_radius)),
                    active=self._mask())
-        self._after_grab(before)
+        self._after_grab(x, y, True)
 
     def grab(self, x, y):
         c = self.cloth
         c._flush()
-        before = c._host().pinned.astype(bool)
         b = c.batch
         b.grab(np.broadcast_to([x, y], (b.E, 2)), radius=np.full(b.E, float(self.grip_radius)),
                active=self._mask())
-        self._after_grab(before)
+        self._after_grab(x, y, False)
 
     def adjust(self, x, y, z):
         """gripper.pyx:55-66 on the host mirror (compatibility path; ClothBatch.run fuses it on the device)."""

@@ -20,7 +20,7 @@ def _data_delta(x, y, targx, targy, shrink=True):
     if shrink:
         dx = dx * 0.90
         dy = dy * 0.90
-    return cx, cy, dx, dy, dist
+    return cx, cy, dx, dy, dist, x, y
 
 
 class OracleCornerPolicy(object):
@@ -46,12 +46,12 @@ class OracleCornerPolicy(object):
             maxdist = max(c[4] for c in cands)
             for c in cands:                                              # first match wins (analytic.py:143-150)
                 if c[4] == maxdist:
-                    cx, cy, dx, dy = c[:4]
+                    cx, cy, dx, dy, _, x, y = c
                     break
-            if self.env.cfg['env']['clip_act_space']:
+            if self.env.cfg['env']['clip_act_space']:                   # analytic.py:151-154
                 acts[e] = (cx, cy, dx, dy)
             else:
-                acts[e] = ((cx / 2.0) + 0.5, (cy / 2.0) + 0.5, dx, dy)
+                acts[e] = (x, y, dx, dy)
         return acts
 
 
@@ -70,7 +70,7 @@ class HighestPointPolicy(object):
         for e in range(E):
             order = np.argsort(-pos[e, :, 2], kind="stable")             # sorted(..., key=z, reverse=True)
             i = int(order[self.rngs[e].randint(self.top_k)])
-            cx, cy, dx, dy, _ = _data_delta(pos[e, i, 0], pos[e, i, 1], self.orig[i, 0], self.orig[i, 1])
+            cx, cy, dx, dy = _data_delta(pos[e, i, 0], pos[e, i, 1], self.orig[i, 0], self.orig[i, 1])[:4]
             acts[e] = (cx, cy, dx, dy)
         return acts
 

@@ -1,0 +1,141 @@
+"""ctypes binding of RCCL (librccl.so) for the sharded vector env: no torch, no MPI.
+
+One process per GPU. The communicator is created with ncclCommInitRank; the 128-byte ncclUniqueId travels from
+rank 0 to the other ranks of the node through a file (single node by construction: xGMI only). All collectives are
+enqueued on the cloth handle's own HIP stream, so they are ordered with the stepper launches without extra events.
+
+Only the three collectives the data path needs are bound, plus all-reduce for the bench's
+max-over-ranks clock and barrier:
+    ncclBroadcast   action / schedule tables, rank 0 -> all
+    ncclAllGather   per-env result records and (optionally) '1d' observations
+    ncclAllReduce   scalars (max / sum), barrier
+"""
+import ctypes as C
+import os
+import time
+
+NCCL_UNIQUE_ID_BYTES = 128
+# ncclDataType_t / ncclRedOp_t (nccl.h)
+UINT8, INT32, INT64, FLOAT32, FLOAT64 = 1, 2, 4, 7, 8
+SUM, PROD, MAX, MIN = 0, 1, 2, 3
+
+
+class RcclError(RuntimeError):
+    pass
+
+
+class _UniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * NCCL_UNIQUE_ID_BYTES)]
+
+
+_lib = None
+
+
+def load():
+    """dlopen librccl.so (ROCm's NCCL). Raises RcclError when it is not installed: there is no fallback transport on
+    the GPU path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    err = None
+    for name in (os.environ.get("CLOTHHIP_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"):
+        if not name:
+            continue
+        try:
+            L = C.CDLL(name)
+            break
+        except OSError as e:
+            err = e
+    else:
+        raise RcclError("librccl.so not found: %s" % err)
+    vp = C.c_void_p
+    L.ncclGetErrorString.restype = C.c_char_p
+    L.ncclGetErrorString.argtypes = [C.c_int]
+    L.ncclGetUniqueId.argtypes = [C.POINTER(_UniqueId)]
+    L.ncclCommInitRank.argtypes = [C.POINTER(vp), C.c_int, _UniqueId, C.c_int]
+    L.ncclCommDestroy.argtypes = [vp]
+    L.ncclBroadcast.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, vp, vp]
+    L.ncclAllGather.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, vp]
+    L.ncclAllReduce.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, vp, vp]
+    _lib = L
+    return L
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RcclError("%s failed: %s" % (what, load().ncclGetErrorString(rc).decode("utf8", "replace")))
+
+
+def rendezvous_path():
+    """Where rank 0 leaves the unique id. CLOTHHIP_RDZV_FILE wins (bench.py's own launcher sets it); under
+    torch.distributed.run the ranks share MASTER_PORT, the run id and their parent (the agent process)."""
+    p = os.environ.get("CLOTHHIP_RDZV_FILE")
+    if p:
+        return p
+    key = "%s_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid())
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"), "clothhip_rccl_%s.id" % key)
+
+
+def exchange_unique_id(rank, world, path=None, timeout_s=300.0):
+    """rank 0 creates the id and publishes it atomically (write + rename); the others poll for the file."""
+    L = load()
+    path = path or rendezvous_path()
+    uid = _UniqueId()
+    if rank == 0:
+        _check(L.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        tmp = "%s.tmp%d" % (path, os.getpid())
+        with open(tmp, "wb") as fh:
+            fh.write(bytes(uid.internal))
+        os.replace(tmp, path)
+    else:
+        t0 = time.time()
+        while True:
+            try:
+                with open(path, "rb") as fh:
+                    raw = fh.read()
+                if len(raw) == NCCL_UNIQUE_ID_BYTES:
+                    break
+            except OSError:
+                pass
+            if time.time() - t0 > timeout_s:
+                raise RcclError("rank %d: no RCCL unique id at %s after %.0f s" % (rank, path, timeout_s))
+            time.sleep(0.01)
+        C.memmove(C.byref(uid), raw, NCCL_UNIQUE_ID_BYTES)
+    return uid, path
+
+
+class Communicator(object):
+    """One RCCL communicator bound to a HIP stream (an opaque hipStream_t pointer value)."""
+
+    def __init__(self, rank, world, stream, rdzv_path=None):
+        self._L = load()
+        self.rank, self.world, self.stream = int(rank), int(world), C.c_void_p(stream)
+        uid, self._path = exchange_unique_id(self.rank, self.world, rdzv_path)
+        comm = C.c_void_p()
+        _check(self._L.ncclCommInitRank(C.byref(comm), self.world, uid, self.rank), "ncclCommInitRank")
+        self._comm = comm
+
+    def rendezvous_done(self):
+        """Call after the first collective has completed on every rank: rank 0 removes the id file."""
+        if self.rank == 0:
+            try:
+                os.remove(self._path)
+            except OSError:
+                pass
+
+    def broadcast(self, d_buf, nbytes, root=0):
+        _check(self._L.ncclBroadcast(C.c_void_p(d_buf), C.c_void_p(d_buf), int(nbytes), UINT8, int(root), self._comm,
+                                     self.stream), "ncclBroadcast")
+
+    def allgather(self, d_send, d_recv, nbytes_per_rank):
+        _check(self._L.ncclAllGather(C.c_void_p(d_send), C.c_void_p(d_recv), int(nbytes_per_rank), UINT8, self._comm,
+                                     self.stream), "ncclAllGather")
+
+    def allreduce_f64(self, d_buf, count, op):
+        _check(self._L.ncclAllReduce(C.c_void_p(d_buf), C.c_void_p(d_buf), int(count), FLOAT64, int(op), self._comm,
+                                     self.stream), "ncclAllReduce")
+
+    def close(self):
+        if getattr(self, "_comm", None):
+            self._L.ncclCommDestroy(self._comm)
+            self._comm = None

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CLOTHHIP_ABI_VERSION 1
+#define CLOTHHIP_ABI_VERSION 2
 
 enum {
     CLOTHHIP_OK = 0,
@@ -40,6 +40,14 @@ enum {
 };
 
 enum { CLOTHHIP_F64 = 0, CLOTHHIP_F32 = 1 };
+
+/* clothhip_set_state flags */
+enum {
+    CLOTHHIP_REST_SHARED = 1,   /* `rest` is ONE [S] table used by all envs of the handle (tiers 1 and 3) */
+    CLOTHHIP_KEEP_TEAR = 2      /* do not clear Cloth.cloth_have_tear (it is sticky in the reference, cloth.pyx:272-273):
+                                   for position writes into a live cloth (pts[i].x = ..., Gripper.adjust) as opposed to
+                                   the Cloth(...) rebuild of a reset */
+};
 
 /* Physics constants: the keys Cloth.__init__/Cloth.update read from the cfg dict
  * (cloth.pyx:53-56, :175-186) plus the Cloth() constructor defaults (cloth.pyx:24-26) and the
@@ -106,14 +114,21 @@ int clothhip_spring_topology(const ClothParams *params, int32_t *a, int32_t *b, 
 
 /* State upload/download for envs [env0, env0+n): the replacement for writing/reading
  * pts[i].x/.y/.z/.px/.py/.pz/.pinned (point.pyx:34-48; read at cloth_env.py:196-200, :629, :854-937).
- * Any pointer may be NULL (= leave untouched / do not fetch).  rest is [n][S] (Spring.rest_length);
- * rest_shared != 0 means rest is a single [S] table used by ALL envs of the handle (tier 1/3).
+ * Any pointer may be NULL (= leave untouched / do not fetch).  rest is [n][S] (Spring.rest_length), or with
+ * CLOTHHIP_REST_SHARED in `flags` a single [S] table used by ALL envs of the handle (tier 1/3).
  * pinned != 0 marks the point pinned and a member of gripper.grabbed_pts. set_state clears the tear flag
- * of the envs it touches when `pos` is given. */
+ * of the envs it touches when `pos` is given, unless CLOTHHIP_KEEP_TEAR is set. */
 int clothhip_set_state(clothhip_handle *h, int32_t env0, int32_t n, const double *pos, const double *prev,
-                       const uint8_t *pinned, const double *rest, int32_t rest_shared);
+                       const uint8_t *pinned, const double *rest, int32_t flags);
 int clothhip_get_state(clothhip_handle *h, int32_t env0, int32_t n, double *pos, double *prev,
                        uint8_t *pinned);
+/* Spring.rest_length (cloth.pyx:417) of envs [env0, env0+n) in reference list order: rest[n][S]
+ * (what the reference's save_state pickle keeps per spring, cloth_env.py:343-350). */
+int clothhip_get_rest(clothhip_handle *h, int32_t env0, int32_t n, double *rest);
+/* The Cloth(...) rebuild of ClothEnv.reset (cloth_env.py:737-746) for the flat tiers 1 and 3, on the device:
+ * every env with mask[e] != 0 (mask NULL = all) gets the flat grid (cloth.pyx:117-130) as position and previous
+ * position, nothing pinned, tear flag cleared, flat rest lengths. No host upload. */
+int clothhip_reset_flat(clothhip_handle *h, const uint8_t *mask);
 /* Cloth.have_tear (cloth.pyx:390-392) for every env: tear[E] (0/1). set: overwrite (Cloth() is rebuilt
  * per reset in the reference, which clears it). */
 int clothhip_get_tear(clothhip_handle *h, uint8_t *tear);
@@ -141,6 +156,95 @@ int clothhip_run_async(clothhip_handle *h, const ClothSchedule *sched);
 /* wait for the handle's stream; after an _async call also fetches executed[E] (may be NULL) */
 int clothhip_sync(clothhip_handle *h, int32_t *executed);
 
+/* ---- Whole episodes on the device -------------------------------------------------------------------------------
+ * clothhip_run_actions runs T consecutive ClothEnv.step calls (cloth_env.py:369-534) for every env in ONE launch, with
+ * the particle state resident on the CU: action source (table or scripted policy), the action -> schedule arithmetic
+ * (:396-475), Gripper.grab_top (+ force_grab, :434-444), the hot loop (:495-515), the per-action metrics
+ * (:1020-1098), the terminal test (:684-715) and -- when a reset script is supplied -- the ClothEnv.reset of an env whose
+ * episode ended (:717-987, tiers 1 and 3), i.e. the reference's episode loop `while not done: step` / `env.reset()`
+ * (examples/analytic.py:872-882) without a host round trip. Envs never wait for each other inside the launch.
+ * Reward and info bookkeeping stay on the host (gym_cloth_amd/envs.py::ClothVecEnv.step_many) and are computed from the
+ * records below. */
+
+/* constants of ClothEnv.__init__ / step / _terminal the device needs (cloth_env.py:87-186) */
+typedef struct ClothEpisodeParams {
+    int32_t max_actions;             /* env.max_actions */
+    int32_t iters_up_rest, iters_grip_rest, iters_rest;
+    int32_t clip_act_space;          /* env.clip_act_space */
+    int32_t force_grab;              /* env.force_grab */
+    int32_t _pad[2];
+    double iters_up;                 /* env.iters_up (tier 3 overrides it per reset pull with a float, cloth_env.py:960) */
+    double reduce_factor, grip_radius;
+    double radius_inc;               /* 0.02, cloth_env.py:131 */
+    double dz_up;                    /* 0.0025, cloth_env.py:359 */
+    double act_low[4], act_high[4];  /* action_space.low / .high (cloth_env.py:162-181) */
+    double coverage_done;            /* _REWARD_THRESHOLDS[reward_type] (cloth_env.py:42-50, :706) */
+} ClothEpisodeParams;
+
+enum { CLOTHHIP_POLICY_TABLE = 0,          /* actions[t][e][4] given by the caller (any policy run on the host, or random) */
+       CLOTHHIP_POLICY_ORACLE_CORNER = 1   /* examples/analytic.py:105-155, 'distance' method, delta actions, 25x25 only */ };
+
+/* One scripted pull of a reset (cloth_env.py:851-877 tier 1, :959-978 tier 3): the raw RNG draws; everything that
+ * depends on the particle state (the picked point's position, _prevent_oob) is evaluated on the device. */
+typedef struct ClothResetPull {
+    int32_t point;                   /* >= 0: pick at pts[point] (tier 1: np_random.randint(P)); < 0: pick at (x, y) */
+    int32_t need_coverage;           /* != 0: run this pull (and the later ones) only if coverage >= coverage_min (tier 1's 3rd) */
+    double x, y;                     /* pick point when point < 0 (tier 3: p0x, p0y) */
+    double dx, dy;                   /* drawn deltas BEFORE _prevent_oob (cloth_env.py:834-840, applied on the device) */
+    double iters_up;                 /* iters_up of this pull (tier 3: uniform(200, 280); else env.iters_up) */
+    double coverage_min;             /* 0.90 (cloth_env.py:866) */
+} ClothResetPull;
+
+typedef struct ClothResetScript {
+    int32_t valid;                   /* 0: no script in this slot */
+    int32_t n_pulls;                 /* <= 3 */
+    int32_t settle_after;            /* bare update() calls after the pulls (tier 3: 800, cloth_env.py:980-981) */
+    int32_t _pad;
+    ClothResetPull pull[3];
+} ClothResetScript;
+
+/* what happened in action slot t of env e */
+typedef struct ClothStepRecord {
+    double action[4];                /* the action taken, as passed to step() (clip space if clip_act_space) */
+    double coverage, variance_inv;   /* after the action (cloth_env.py:1075-1098) */
+    int32_t executed;                /* update() calls of this action (0: nothing grabbed) */
+    int32_t n_grabbed;               /* len(gripper.grabbed_pts) */
+    int32_t iters_pull;
+    int32_t n_below_half_thickness;  /* compute_height numerator (cloth_env.py:603-609) */
+    uint8_t ran;                     /* 0: slot not executed (episode over and no reset script left) */
+    uint8_t oob, tear, done;
+    uint8_t reset_before;            /* 1: the env was reset right before this action; 2: the 2nd reset of this launch */
+    uint8_t _pad[3];
+} ClothStepRecord;
+
+/* one consumed reset script */
+typedef struct ClothResetRecord {
+    int32_t consumed;                /* 0 / 1 */
+    int32_t pulls_run;               /* scripted pulls executed (tier 1: 2 or 3) */
+    int32_t executed[3];             /* update() calls of each pull */
+    int32_t settle_executed;
+    int32_t tear;                    /* Cloth.have_tear after the reset */
+    int32_t _pad;
+    double start_coverage, start_variance_inv;   /* cloth_env.py:780-782 */
+    double action[3][4];             /* the reset actions in clip space, as the reference passes them to step(initialize=True) */
+} ClothResetRecord;
+
+/* T action slots for every env. policy: CLOTHHIP_POLICY_*. actions: [T][E][4] (TABLE), a HOST pointer unless
+ * actions_on_device != 0 (a device table, e.g. after an RCCL broadcast). policy_arg[E] or NULL (ORACLE_CORNER: != 0 =
+ * tier-2 cloth with init_side False, corner indices swapped, analytic.py:108-114). scripts: [E][3] or NULL -- slot 0 is
+ * the env's next reset, slot 1 / slot 2 the one after it if slot 0 ran 2 / 3 pulls (the reference's RNG stream forks
+ * there). num_steps[E], done[E]: in/out episode state (ClothEnv.num_steps; episode over). records: [T][E].
+ * resets: [E][2] or NULL. obs: [T][E][3P] float32 '1d' observation after each executed slot, or NULL. reset_obs:
+ * [E][2][3P] float32 first observation of each episode started inside the launch (what env.reset() returns), or NULL.
+ * Returns CLOTHHIP_ESTATE when the handle's variant cannot run fused (per-env rest tables with reset scripts,
+ * non-25x25 oracle policy, grid too large for the in-kernel metrics). Synchronous. */
+/* 1 if this handle's kernel variant has the LDS room for the in-kernel metrics of clothhip_run_actions, else 0 */
+int clothhip_fused_supported(const clothhip_handle *h);
+int clothhip_run_actions(clothhip_handle *h, const ClothEpisodeParams *ep, int32_t T, int32_t policy,
+                         const double *actions, int32_t actions_on_device, const int32_t *policy_arg,
+                         const ClothResetScript *scripts, int32_t *num_steps, uint8_t *done,
+                         ClothStepRecord *records, ClothResetRecord *resets, float *obs, float *reset_obs);
+
 /* Convenience: n x Cloth.update() on every env (cloth_env.py:902-903, :948-949, :980-981), optionally
  * preceded each time by Gripper.adjust(delta) when delta != NULL ([3] doubles, same for all envs). */
 int clothhip_update(clothhip_handle *h, int32_t n_sub, const double *delta);
@@ -153,6 +257,10 @@ int clothhip_update(clothhip_handle *h, int32_t n_sub, const double *delta);
  *   tear[E]          Cloth.have_tear
  * Any pointer may be NULL. */
 int clothhip_metrics(clothhip_handle *h, double *coverage, double *variance_inv, uint8_t *oob, uint8_t *tear);
+/* the same plus n_below_half_thickness[E] = #points with z < thickness/2, the numerator of the 'height' reward's
+ * compute_height (cloth_env.py:603-609) */
+int clothhip_metrics_ex(clothhip_handle *h, double *coverage, double *variance_inv, uint8_t *oob, uint8_t *tear,
+                        int32_t *n_below_half_thickness);
 /* the same hull-area routine on caller-supplied points xy[n][2] (pure host function; used by tests to pin it
  * against scipy's Qhull on the golden states) */
 double clothhip_hull_area(const double *xy, int32_t n);
@@ -163,6 +271,13 @@ double clothhip_hull_area(const double *xy, int32_t n);
 int clothhip_write_obs_f32_device(clothhip_handle *h, void *d_out);
 /* Same, schedules read from a DEVICE array of ClothSchedule[E] (e.g. after an RCCL broadcast). */
 int clothhip_run_device_sched_async(clothhip_handle *h, const void *d_sched);
+/* Raw device buffers on the handle's device, for the multi-GPU driver's RCCL staging (action tables in, result /
+ * observation tables out; gym_cloth_amd/dist.py). upload/download run on the handle's stream and synchronise it, so
+ * they are ordered with the stepper launches. */
+int clothhip_device_alloc(clothhip_handle *h, uint64_t nbytes, void **d_out);
+int clothhip_device_free(clothhip_handle *h, void *d);
+int clothhip_device_upload(clothhip_handle *h, void *d_dst, const void *src, uint64_t nbytes);
+int clothhip_device_download(clothhip_handle *h, void *dst, const void *d_src, uint64_t nbytes);
 /* the handle's hipStream_t as an opaque pointer (for event timing / stream ordering by the caller) */
 void *clothhip_stream(clothhip_handle *h);
 

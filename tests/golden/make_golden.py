@@ -17,6 +17,8 @@ Fixture inventory:
   g_env_tier1_1337.npz      G3/G4  ClothEnv seed 1337 tier1: reset + oracle-corner episode, per action
   g_env_tier2_*.npz         G5     tier2 reset (2 seeds)
   g_env_tier3_*.npz         G5     tier3 reset (2 seeds)
+  g_traj_friction_25.npz    G1     plane_friction 0.5, damping 1.2, ks 7000: the (1 - friction) != 0 plane response
+  g_decode_modes.npz        G3     ClothEnv.step with clip_act_space / delta_actions off (4 action modes), per action
   g_gripper_25.npz          G6     grab_top index sets on several states + the curZ level table
   g_metrics.npz             G8     positions -> coverage / variance_inv / out_of_bounds
 """
@@ -376,6 +378,82 @@ def traj_tear_25(Cloth, Gripper):
     return tr
 
 
+def traj_friction_25(Cloth, Gripper):
+    """Non-default material and plane constants: plane_friction 0.5 makes (1. - friction) != 0 in
+    _handle_plane_collision (cloth.pyx:345-370), so a particle below the plane is NOT simply restored."""
+    cfg = load_cfg(25)
+    cfg["cloth"]["plane_friction"] = 0.5
+    cfg["cloth"]["damping"] = 1.2
+    cfg["cloth"]["ks"] = 7000.0
+    tr = Trace(Cloth, Gripper, cfg)
+    eps = 0.5 / 24
+    tr.grab_top(eps, eps); tr.checkpoint()
+    tr.adjust_update(0.0, 0.0, 0.0025, 30); tr.checkpoint()
+    d = np.array([1.0, 0.6]) / (np.sqrt(1.36) + 1e-5) * 0.002
+    tr.adjust_update(d[0], d[1], 0.0, 1); tr.checkpoint()
+    tr.adjust_update(d[0], d[1], 0.0, 119); tr.checkpoint()
+    tr.release(); tr.update(1); tr.checkpoint()
+    tr.update(60); tr.checkpoint()                              # falling back onto the plane: z < 0 corrections
+    tr.update(1); tr.checkpoint()
+    tr.update(140); tr.checkpoint()
+    below = int(np.sum(tr.cp[-1][0][:, 2] < 1e-3))
+    print("  friction trajectory: %d particles within 1e-3 of the plane at the end" % below)
+    tr.save("g_traj_friction_25.npz")
+    return tr
+
+
+def decode_modes_fixture():
+    """ClothEnv.step in the action modes the shipped cfgs do not use (cloth_env.py:402-470): clip_act_space off and/or
+    delta_actions off. The reference cannot reset() in non-delta mode (cloth_env.py:862 raises), so the scripted reset
+    pulls are skipped and every action starts from the flat cloth; what is captured per action is the start and end
+    state, the number of update() calls and the (obs, reward, done, info) the reference returned."""
+    import yaml
+    recs = []
+    for clip, delta in ((True, True), (False, True), (True, False), (False, False)):
+        cfg = load_cfg(25)
+        cfg["env"]["clip_act_space"], cfg["env"]["delta_actions"] = clip, delta
+        cfg["seed"] = 7
+        path = os.path.join(SCRATCH, "cfg_modes_%d%d.yaml" % (clip, delta))
+        with open(path, "w") as fh:
+            yaml.safe_dump(cfg, fh)
+        with contextlib.redirect_stdout(io.StringIO()):
+            from gym_cloth.envs import ClothEnv
+        if delta:
+            acts = [(0.52, 0.48, 0.3, -0.2), (-0.4, 0.7, 0.9, 0.8)] if clip else \
+                   [(0.75, 0.25, -0.25, 0.15), (1.2, 0.5, 0.1, -1.4)]          # the 2nd is out of the action bounds
+        else:
+            acts = [(0.1, -0.3, 0.2, 0.35), (0.6, 0.6, -0.5, -0.8)] if clip else \
+                   [(0.3, 0.7, 0.35, 2.2), (0.5, 0.5, 1.3, -4.0)]              # length > 1 and |angle| > pi get truncated
+        for a in acts:
+            env = ClothEnv(path)
+            logging.getLogger().setLevel(logging.WARNING)
+            env.logger.setLevel(logging.WARNING)
+            env.seed(7)
+            env._wd = env._hd = 224
+            env._reset_actions = lambda: None
+            with contextlib.redirect_stdout(io.StringIO()):
+                env.reset()
+            pos0, prev0, pin0 = snap(env.cloth)
+            it0 = env.cloth.iter
+            with contextlib.redirect_stdout(io.StringIO()):
+                obs, rew, done, info = env.step(a)
+            pos1, prev1, pin1 = snap(env.cloth)
+            recs.append(dict(clip=clip, delta=delta, action=[float(x) for x in a], n_updates=env.cloth.iter - it0,
+                             pos0=pos0, pos1=pos1, prev1=prev1, rew=float(rew), done=bool(done),
+                             info={k: (float(v) if isinstance(v, (float, np.floating)) else
+                                       (bool(v) if isinstance(v, (bool, np.bool_)) else int(v))) for k, v in info.items()},
+                             low=[float(x) for x in env.action_space.low], high=[float(x) for x in env.action_space.high]))
+            print("  mode clip=%s delta=%s action %s -> %d updates, rew %.4f" % (clip, delta, a, recs[-1]["n_updates"], rew))
+    out = dict(cfg=physics_cfg_json(load_cfg(25)),
+               meta=json.dumps([{k: r[k] for k in ("clip", "delta", "action", "n_updates", "rew", "done", "info", "low", "high")}
+                                for r in recs]),
+               pos0=np.stack([r["pos0"] for r in recs]), pos1=np.stack([r["pos1"] for r in recs]),
+               prev1=np.stack([r["prev1"] for r in recs]))
+    path = os.path.join(HERE, "g_decode_modes.npz")
+    np.savez_compressed(path, **out)
+    print("wrote g_decode_modes.npz (%.1f KB)" % (os.path.getsize(path) / 1024.0))
+
+
 def gripper_fixture(Cloth, Gripper, traces):
     """grab_top / grab index sets on a few harvested states + the curZ table (G6)."""
     cfg = load_cfg(25)
@@ -568,6 +646,10 @@ def main():
         traj_tear_25(Cloth, Gripper)
     if want("fold50"):
         traj_fold(Cloth, Gripper, 50, 0.0095, "g_traj_fold_50.npz", lift=40, pull=260, rest=60)
+    if want("friction"):
+        traj_friction_25(Cloth, Gripper)
+    if want("decode"):
+        decode_modes_fixture()
     if want("gripper"):
         gripper_fixture(Cloth, Gripper, [(tr_lp, [0, 6, 10]), (tr_fold, [3, 5])])
     if want("metrics"):

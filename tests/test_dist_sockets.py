@@ -1,13 +1,13 @@
-"""world_size-2 test of the multi-GPU data path (gym_cloth_amd/dist.py) on CPU with the gloo backend:
-env blocks sharded over ranks, action table broadcast from rank 0, per-env results all-gathered.
-The physics stand-in on each rank is the CPU oracle (tests may use it); the sharded result must equal the
-single-process result env for env."""
+"""world_size-2 test of the multi-GPU data path (gym_cloth_amd/dist.py) on CPU: env blocks sharded over ranks,
+action table broadcast from rank 0, per-env results and observations all-gathered, through the plain-socket
+transport (the GPU path runs the same StepExchange over RCCL, tests/test_gpu_dist.py). The physics stand-in on each
+rank is the CPU oracle (tests may use it); the sharded result must equal the single-process result env for env."""
+import multiprocessing as mp
 import os
 import socket
 import sys
 
 import numpy as np
-import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -38,30 +38,27 @@ def _step_block(actions, g):
 
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    import torch.distributed as dist
-    from gym_cloth_amd.dist import StepExchange, shard_range
+    from gym_cloth_amd.dist import SocketTransport, StepExchange, shard_range
     from oracle import pyoracle
-    dist.init_process_group("gloo", rank=rank, world_size=world)
     E = 3
-    ex = StepExchange(E, obs_dim=6)
+    ex = StepExchange(E, SocketTransport(rank, world, "127.0.0.1", port))
     assert (ex.g0, ex.g1) == shard_range(rank, world, E) == (rank * E, rank * E + E)
     g = pyoracle.load_golden("g_traj_lift_pull_25.npz")
     acts_all = np.random.RandomState(5).uniform(-1, 1, size=(world * E, 4)) if rank == 0 else None
     mine = ex.broadcast_actions(acts_all)
+    multi = ex.broadcast_actions(np.arange(2 * world * E * 4, dtype=np.float64).reshape(2, world * E, 4)
+                                 if rank == 0 else None, n_actions=2)
     r = _step_block(mine, g)
     res = ex.gather_results(r[:, 0], r[:, 1], r[:, 2], r[:, 3])
-    ex.obs_loc[:] = float(rank)
-    obs = ex.gather_obs().numpy().copy()
+    obs = ex.gather_obs(np.full((E, 6), float(rank), dtype=np.float32))
     tmax = ex.max_over_ranks(1.0 + rank)
     tsum = ex.sum_over_ranks(r[:, 3].sum())
     ex.barrier()
-    q.put((rank, mine, res, obs, tmax, tsum))
-    dist.destroy_process_group()
+    q.put((rank, mine, multi, res, obs, tmax, tsum))
+    ex.t.close()
 
 
 def test_sharded_step_equals_single_process():
-    import torch.multiprocessing as mp
     from oracle import pyoracle
     pyoracle.build()
     world, port = 2, _free_port()
@@ -76,8 +73,29 @@ def test_sharded_step_equals_single_process():
         assert p.exitcode == 0
     acts_all = np.random.RandomState(5).uniform(-1, 1, size=(6, 4))
     ref = _step_block(acts_all, pyoracle.load_golden("g_traj_lift_pull_25.npz"))
-    for rank, mine, res, obs, tmax, tsum in got:
+    table = np.arange(2 * 6 * 4, dtype=np.float64).reshape(2, 6, 4)
+    for rank, mine, multi, res, obs, tmax, tsum in got:
         assert np.array_equal(mine, acts_all[rank * 3:rank * 3 + 3])          # broadcast + slice
+        assert np.array_equal(multi, table[:, rank * 3:rank * 3 + 3])         # multi-action table
         assert np.array_equal(res, ref)                                       # all-gather, env for env
         assert np.array_equal(obs[:3], np.zeros((3, 6))) and np.array_equal(obs[3:], np.ones((3, 6)))
         assert tmax == 2.0 and tsum == ref[:, 3].sum()
+
+
+def test_local_transport_is_identity():
+    sys.path.insert(0, ROOT)
+    from gym_cloth_amd.dist import LocalTransport, StepExchange
+    ex = StepExchange(4, LocalTransport())
+    a = np.random.RandomState(1).uniform(-1, 1, size=(4, 4))
+    assert np.array_equal(ex.broadcast_actions(a), a)
+    assert ex.max_over_ranks(3.5) == 3.5 and ex.sum_over_ranks(2.0) == 2.0
+    assert ex.gather_results(a[:, 0], a[:, 1], a[:, 2], a[:, 3]).shape == (4, 4)
+
+
+def test_package_does_not_import_torch():
+    """north_star: no PyTorch in the stepper or its multi-GPU driver."""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); import gym_cloth_amd, gym_cloth_amd.envs, gym_cloth_amd.dist, "
+            "gym_cloth_amd.rccl, gym_cloth_amd.policies, gym_cloth_amd.physics; "
+            "assert 'torch' not in sys.modules, 'torch was imported'" % ROOT)
+    subprocess.check_call([sys.executable, "-c", code])

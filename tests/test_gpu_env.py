@@ -220,3 +220,65 @@ def test_bench_workload_action_matches_oracle_f64(oracle_lib):
     st = env.batch.debug_stats()
     assert st[:, 1].sum() > 0, "the workload must have exercised the dense strain sweep"
     env.close()
+
+
+def test_all_action_modes_match_reference_f64(oracle_lib):
+    """ClothEnv.step with clip_act_space and/or delta_actions switched off (cloth_env.py:402-470, :579-593): update()
+    count, end state, reward (incl. the out-of-bounds action penalty of the non-clip modes), done and info as the
+    reference returned them (tests/golden/make_golden.py::decode_modes_fixture: flat start, no reset pulls)."""
+    import json
+    from gym_cloth_amd.envs import ClothVecEnv
+    g = oracle_lib.load_golden("g_decode_modes.npz")
+    meta = json.loads(str(g["meta"]))
+    for k, m in enumerate(meta):
+        cfg = base_cfg("tier1", 7)
+        cfg["env"]["clip_act_space"], cfg["env"]["delta_actions"] = m["clip"], m["delta"]
+        v = ClothVecEnv(cfg, n_envs=1, precision="f64")
+        assert np.array_equal(v.action_space.low, m["low"]) and np.array_equal(v.action_space.high, m["high"])
+        v.batch.set_state(g["pos0"][k][None], g["pos0"][k][None], np.zeros((1, 625), dtype=np.uint8))
+        cov, vinv, _, _ = v.batch.metrics()                     # what reset() records before the first action
+        v._prev_reward[:] = cov; v._start_coverage[:] = cov; v._start_variance_inv[:] = vinv
+        obs, rew, done, info = v.step(np.array(m["action"])[None])
+        assert v.last_executed[0] == m["n_updates"], (k, m)
+        assert np.array_equal(obs[0].reshape(-1, 3), g["pos1"][k]), (k, m)
+        assert abs(rew[0] - m["rew"]) <= 1e-12 and bool(done[0]) == m["done"], (k, m, rew[0])
+        assert info["num_sim_steps"][0] == m["info"]["num_sim_steps"]
+        assert abs(info["actual_coverage"][0] - m["info"]["actual_coverage"]) <= 1e-12
+        v.close()
+
+
+@pytest.mark.parametrize("name,tier", [("t1.yaml", "tier1"), ("t2.yaml", "tier2"), ("t3.yaml", "tier3")])
+def test_shipped_yaml_configs_load_and_reset(name, tier):
+    """cfg/t{1,2,3}.yaml (reference schema, obs_type '1d') drive ClothEnv from a file path as the reference's
+    ClothEnv(cfg_file) does (cloth_env.py:87-88)."""
+    from gym_cloth_amd.envs import ClothEnv
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = ClothEnv(os.path.join(root, "cfg", name), precision="f32")
+    assert env.cfg["init"]["type"] == tier and env.cfg["env"]["obs_type"] == "1d"
+    env.seed(1600)
+    obs = env.reset()
+    assert obs.shape == (3 * 625,) and np.isfinite(obs).all()
+    assert 0.2 < env._vec._start_coverage[0] <= 1.0
+    obs2, rew, done, info = env.step(env.get_random_action())
+    assert obs2.shape == obs.shape and np.isfinite(rew) and info["num_steps"] == 1
+    env.close()
+
+
+def test_facade_keeps_tear_flag_and_unpin(oracle_lib):
+    """Writes through the object facade go into a LIVE cloth: the sticky tear flag must survive them (cloth.pyx:272-273)
+    and `pt.pinned = False` must reach the device."""
+    from gym_cloth_amd.physics import Cloth, Gripper
+    cfg = base_cfg("tier1", 3)
+    c = Cloth(params=cfg, random_state=np.random.RandomState(3), precision="f64")
+    gr = Gripper(c, cfg["env"]["grip_radius"], cfg["cloth"]["height"], cfg["cloth"]["thickness"])
+    c.batch.tear = [True]
+    gr.grab_top(0.5, 0.5)
+    gr.adjust(0.0, 0.0, 0.0025)
+    c.update()
+    assert c.have_tear, "a position upload cleared the sticky tear flag"
+    gr.grab_top(0.5, 0.5)                                  # the lifted points are grabbed a second time: listed twice
+    assert len(gr.grabbed_pts) == 10
+    i = gr.grabbed_pts[0]._i
+    c.pts[i].pinned = False
+    c.update()
+    assert not c.batch.get_state()[2][0][i]

@@ -1,0 +1,148 @@
+"""GPU tests of the whole-episode launch (clothhip_run_actions / ClothVecEnv.step_many): action decoding, grab_top,
+the substep loop, metrics, terminal test and episode resets inside ONE kernel launch must give, env for env and bit for
+bit in fp64, what the per-step path gives (which the other GPU tests pin to the reference goldens and the CPU oracle),
+and the in-kernel reset must reproduce the reference's reset goldens directly."""
+import numpy as np
+import pytest
+
+from test_gpu_env import base_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def _bench_env(E, prec, tier="tier1", n_side=25):
+    import bench
+    from gym_cloth_amd.envs import ClothVecEnv
+    cfg = bench.bench_cfg(n_side, 0.02 if n_side <= 25 else 0.0095, tier)
+    env = ClothVecEnv(cfg, n_envs=E, precision=prec, consume_domrand_draws=False)
+    for e in range(E):
+        env.np_randoms[e] = np.random.RandomState(1000 + e)
+    return env
+
+
+def _rng_equal(a, b):
+    sa, sb = a.get_state(), b.get_state()
+    return sa[0] == sb[0] and np.array_equal(sa[1], sb[1]) and sa[2:] == sb[2:]
+
+
+@pytest.mark.parametrize("tier,T,E", [("tier1", 4, 24), ("tier3", 3, 12)])
+def test_step_many_equals_sequential_steps_f64(tier, T, E):
+    """T actions per env with auto-reset: one fused launch == T calls of step(auto_reset=True). Every reward, done flag,
+    info value, counter, the final particle state and the state of every env's RNG must be identical. Uniformly random
+    actions end many episodes early (out of bounds, tears), so the in-kernel reset path is exercised, including
+    episodes that end twice within the launch."""
+    acts = np.stack([np.random.RandomState(2000 + e).uniform(-1, 1, size=(T, 4)) for e in range(E)], axis=1)
+    a = _bench_env(E, "f64", tier); a.reset()
+    b = _bench_env(E, "f64", tier); b.reset()
+    assert np.array_equal(a.batch.get_state()[0], b.batch.get_state()[0])
+    seq = []
+    for t in range(T):
+        obs, rew, done, info = a.step(acts[t], auto_reset=True)
+        seq.append((rew, done, info, a.last_executed.copy(), a.last_grabbed.copy()))
+    out = b.step_many(acts, reset_tail=True)
+    n_idle = 0
+    for t in range(T):
+        rew, done, info, ex, ng = seq[t]
+        ran = out["ran"][t]
+        n_idle += int((~ran).sum())
+        # an env that exhausted its two in-launch resets idles; compare the envs that ran (all of them in practice)
+        assert np.array_equal(rew[ran], out["rew"][t][ran]), (t, rew, out["rew"][t])
+        assert np.array_equal(done[ran], out["done"][t][ran])
+        assert np.array_equal(ex[ran], out["executed"][t][ran]) and np.array_equal(ng[ran], out["n_grabbed"][t][ran])
+        for k in ("num_steps", "num_sim_steps", "actual_coverage", "start_coverage", "variance_inv",
+                  "start_variance_inv", "have_tear", "out_of_bounds"):
+            assert np.array_equal(np.asarray(info[k])[ran], out[k][t][ran]), (t, k)
+    assert n_idle == 0, "an env needed a third reset inside the launch; pick other seeds"
+    assert out["reset_before"].sum() > 0, "the workload must exercise the in-kernel reset"
+    pa, qa, ca = a.batch.get_state()
+    pb, qb, cb = b.batch.get_state()
+    assert np.array_equal(pa, pb) and np.array_equal(qa, qb) and np.array_equal(ca, cb)
+    assert np.array_equal(a.batch.tear, b.batch.tear)
+    assert np.array_equal(a.num_steps, b.num_steps) and np.array_equal(a.num_sim_steps, b.num_sim_steps)
+    assert a.total_substeps == b.total_substeps
+    assert all(_rng_equal(a.np_randoms[e], b.np_randoms[e]) for e in range(E))
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("fixture,tier,seed", [("g_env_tier1_1337.npz", "tier1", 1337),
+                                               ("g_env_tier3_1337.npz", "tier3", 1337),
+                                               ("g_env_tier3_1339.npz", "tier3", 1339)])
+def test_in_kernel_reset_matches_reference_f64(fixture, tier, seed, oracle_lib):
+    """The reset executed INSIDE the kernel (flat grid, scripted pulls with the pick point read from the particle state,
+    _prevent_oob, tier-1's coverage-conditional third pull, tier-3's float iters_up and 800 settling updates) against
+    the reference's reset capture: same clip-space reset actions, same update() counts, same post-reset observation and
+    start coverage; then the first episode action as in the golden."""
+    from gym_cloth_amd.envs import ClothVecEnv
+    g = oracle_lib.load_golden(fixture)
+    v = ClothVecEnv(base_cfg(tier, seed), n_envs=1, precision="f64")
+    v.seed([seed])
+    v._ep_done[:] = True                                   # "episode over": the launch starts with the reset
+    nreset = int(g["n_reset_calls"])
+    first = g["act"][nreset] if len(g["act"]) > nreset else np.array([0.1, 0.1, 0.2, 0.2])
+    rec, rst, obs_t, robs = v.batch.run_actions(v._episode_params(), 1, np.zeros(1, dtype=np.int32),
+                                                np.ones(1, dtype=np.uint8), actions=first[None, None, :],
+                                                scripts=v._prepare_scripts(), want_obs=True)
+    q = rst[0, 0]
+    assert q["consumed"] == 1 and q["pulls_run"] == nreset and rec[0, 0]["reset_before"] == 1
+    for k in range(nreset):
+        assert np.array_equal(q["action"][k], g["act"][k]), (k, q["action"][k], g["act"][k])
+        assert q["executed"][k] == int(g["act_n_updates"][k])
+    assert np.array_equal(robs[0, 0], g["reset_obs"].astype(np.float32))
+    assert abs(q["start_coverage"] - float(g["start_coverage"])) <= 1e-12
+    assert abs(q["start_variance_inv"] - float(g["start_variance_inv"])) <= 1e-9 * float(g["start_variance_inv"])
+    if len(g["act"]) > nreset:                             # tier-1 fixture: the oracle action of the episode follows
+        assert rec[0, 0]["executed"] == int(g["act_n_updates"][nreset])
+        assert np.array_equal(obs_t[0, 0], g["act_pos1"][nreset].reshape(-1).astype(np.float32))
+        assert abs(rec[0, 0]["coverage"] - g["info"][0]["actual_coverage"]) <= 1e-12
+        assert bool(rec[0, 0]["done"]) == bool(g["done"][0])
+    v.close()
+
+
+def test_device_oracle_policy_episode_f64(oracle_lib):
+    """The oracle-corner policy evaluated in the kernel picks the action the reference's examples/analytic.py picked
+    (seed 1337, tier 1) and the episode ends with the reference's reward."""
+    from gym_cloth_amd.envs import ClothVecEnv
+    g = oracle_lib.load_golden("g_env_tier1_1337.npz")
+    v = ClothVecEnv(base_cfg("tier1", 1337), n_envs=2, precision="f64")
+    v.seed([1337, 1337])
+    v.reset()
+    out = v.step_many(policy="oracle_corner", n_actions=2, auto_reset=False)
+    k = int(g["n_reset_calls"])
+    for e in range(2):
+        assert np.array_equal(out["actions"][0, e], g["act"][k])
+        assert abs(out["rew"][0, e] - g["rew"][0]) <= 1e-12 and out["done"][0, e]
+        assert not out["ran"][1, e]                        # episode over, no reset requested: the second slot idles
+    v.close()
+
+
+def test_step_many_f32_outcomes_and_obs():
+    """fp32 instantiation of the fused launch: identical to the fp32 per-step path (same kernel arithmetic), and the
+    per-slot observations equal the state after each step."""
+    E, T = 8, 2
+    acts = np.stack([np.random.RandomState(2000 + e).uniform(-1, 1, size=(T, 4)) for e in range(E)], axis=1)
+    a = _bench_env(E, "f32"); a.reset()
+    b = _bench_env(E, "f32"); b.reset()
+    obs_seq = []
+    for t in range(T):
+        obs, rew, done, info = a.step(acts[t], auto_reset=False)
+        obs_seq.append((obs.copy(), rew, done))
+    out = b.step_many(acts, auto_reset=False, want_obs=True)
+    for t in range(T):
+        ran = out["ran"][t]
+        assert np.array_equal(obs_seq[t][1][ran], out["rew"][t][ran]) and np.array_equal(obs_seq[t][2][ran], out["done"][t][ran])
+        if t == 0:
+            assert ran.all() and np.array_equal(out["obs_t"][0], obs_seq[0][0].astype(np.float32))
+    a.close(); b.close()
+
+
+def test_fused_refuses_what_it_cannot_run():
+    from gym_cloth_amd import _lib
+    from gym_cloth_amd.envs import ClothVecEnv
+    v = ClothVecEnv(base_cfg("tier2", 3), n_envs=2, precision="f32")
+    v.seed(3); v.reset()                                   # tier 2: per-env rest tables
+    out = v.step_many(np.zeros((1, 2, 4)), auto_reset=True)    # allowed: resets simply stay on the host
+    assert out["ran"].all()
+    with pytest.raises(Exception):
+        v.batch.run_actions(v._episode_params(), 1, np.zeros(2, dtype=np.int32), np.zeros(2, dtype=np.uint8),
+                            actions=np.zeros((1, 2, 4)), scripts=np.zeros((2, 3), dtype=_lib.RESET_SCRIPT_DTYPE))
+    v.close()

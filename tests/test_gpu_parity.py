@@ -7,7 +7,9 @@ from helpers import BatchReplay, max_abs
 
 pytestmark = pytest.mark.gpu
 
-TRAJ = ["g_traj_lift_pull_25.npz", "g_traj_fold_25.npz", "g_traj_tear_25.npz", "g_traj_fold_50.npz"]
+TRAJ = ["g_traj_lift_pull_25.npz", "g_traj_fold_25.npz", "g_traj_tear_25.npz", "g_traj_fold_50.npz",
+        "g_traj_friction_25.npz"]       # the last: plane_friction 0.5, damping 1.2, ks 7000 (cloth.pyx:345-370 with 1-friction != 0)
+F32_WINDOWS = TRAJ[:3] + ["g_traj_fold_50.npz", "g_traj_friction_25.npz"]   # fold_50 runs the 512-thread x 5-particle variant
 
 
 def cfg_from_golden(g):
@@ -59,7 +61,7 @@ def test_f64_bit_exact_vs_reference_golden(name, oracle_lib):
     assert not bad, bad[:5]
 
 
-@pytest.mark.parametrize("name", TRAJ[:3])
+@pytest.mark.parametrize("name", F32_WINDOWS)
 def test_f32_teacher_forced_windows(name, oracle_lib):
     """fp32 instantiation, teacher-forced: restart from every reference checkpoint, run to the next one
     (<= ~200 substeps) and compare. Tolerance (stated): 2e-4 absolute on positions for

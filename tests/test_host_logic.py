@@ -41,7 +41,7 @@ def test_abi_exports_every_declared_symbol(lib):
     assert declared == bound, (declared ^ bound)
     for name in declared:
         assert getattr(L, name) is not None
-    assert L.clothhip_abi_version() == 1
+    assert L.clothhip_abi_version() == lib.ABI_VERSION == 2
     assert C.sizeof(lib.ClothSchedule) == 64 and C.sizeof(lib.ClothParams) == 104
 
 
@@ -166,3 +166,65 @@ def test_schedule_helpers():
     assert schedule_bounds(237.4, 80, 10, 300, 1000) == (238, 318, 328, 628, 1628)   # tier 3: i < 237.4 <=> i < 238
     s = make_schedules(3, n_total=7, active=1)
     assert s.shape == (3,) and s.dtype.itemsize == 64 and (s["n_total"] == 7).all()
+
+
+def test_gym_registration_shim(monkeypatch):
+    """gym_cloth/__init__.py:1-5 registers 'cloth-v0'; the same happens here whenever gym is importable (it is not a
+    dependency of the stepper, so the registry is stubbed)."""
+    import sys
+    import types
+    calls = []
+    reg = types.ModuleType("gym.envs.registration")
+    reg.register = lambda id, entry_point: calls.append((id, entry_point))
+    gym = types.ModuleType("gym"); envs = types.ModuleType("gym.envs")
+    gym.envs = envs; envs.registration = reg
+    for k, v in (("gym", gym), ("gym.envs", envs), ("gym.envs.registration", reg)):
+        monkeypatch.setitem(sys.modules, k, v)
+    import gym_cloth_amd
+    assert gym_cloth_amd.register_gym_env() is True
+    assert calls == [("cloth-v0", "gym_cloth_amd.envs:ClothEnv")]
+    from gym_cloth_amd import envs as our_envs
+    assert hasattr(our_envs, "ClothEnv")
+
+
+def test_shipped_yaml_schema_matches_reference_keys():
+    """cfg/t{1,2,3}.yaml: same sections and keys as the reference's cfg/t1_rgbd.yaml (listed here: the reference tree is
+    not available where the tests run), values of the physics keys as shipped there."""
+    import yaml
+    want = {"cloth": {"damping", "density", "ks", "enable_structural", "enable_shearing", "enable_bending", "orientation",
+                      "width", "height", "num_width_points", "num_height_points", "thickness", "pin_cond", "color_pts",
+                      "plane_friction", "tear_thresh"},
+            "env": {"max_actions", "max_z_threshold", "iters_up", "iters_up_rest", "iters_pull_max", "iters_grip_rest",
+                    "iters_rest", "updates_per_move", "reduce_factor", "grip_radius", "reward_type", "force_grab",
+                    "clip_act_space", "delta_actions", "obs_type", "oracle_reveal", "use_depth", "use_dom_rand", "use_rgbd"},
+            "init": {"type", "debug_matplotlib", "render_opengl"}, "log": {"level", "file"}}
+    for n in (1, 2, 3):
+        cfg = yaml.safe_load(open(os.path.join(ROOT, "cfg", "t%d.yaml" % n)))
+        assert set(cfg) == set(want) | {"frames_per_sec", "simulation_steps", "seed"}
+        for sec, keys in want.items():
+            assert set(cfg[sec]) == keys, (n, sec)
+        assert cfg["init"]["type"] == "tier%d" % n and cfg["env"]["obs_type"] == "1d"
+        c = cfg["cloth"]
+        assert (c["ks"], c["damping"], c["density"], c["thickness"], c["plane_friction"], c["tear_thresh"]) == \
+               (10000.0, 2.0, 200.0, 0.02, 1.0, 2.0)
+
+
+def test_step_many_script_drawing_is_rng_neutral():
+    """The reset scripts step_many pre-draws leave every env RNG where it was, and the draws of slot 0 are exactly the ones
+    the host reset makes (cloth.pyx:75; cloth_env.py:851-877)."""
+    from gym_cloth_amd.envs import ClothVecEnv
+    v = ClothVecEnv.__new__(ClothVecEnv)                     # host-only pieces: no device needed
+    v.E, v.P, v._init_type, v._consume_domrand, v.iters_up = 3, 625, "tier1", False, 50
+    v.np_randoms = [np.random.RandomState(40 + e) for e in range(3)]
+    v._pending = [None] * 3
+    before = [r.get_state()[1].copy() for r in v.np_randoms]
+    sc = v._prepare_scripts()
+    assert all(np.array_equal(b, r.get_state()[1]) for b, r in zip(before, v.np_randoms))
+    ref = np.random.RandomState(40)
+    ref.rand()                                               # init_side
+    for k in range(3):
+        assert sc[0, 0]["pull"][k]["point"] == ref.randint(625)
+        assert sc[0, 0]["pull"][k]["dx"] == ClothVecEnv._randval_minabs(ref, -0.2, 0.2, 0.08)
+        assert sc[0, 0]["pull"][k]["dy"] == ClothVecEnv._randval_minabs(ref, -0.2, 0.2, 0.08)
+    assert sc[0, 0]["n_pulls"] == 3 and sc[0, 0]["pull"][2]["need_coverage"] == 1 and sc[0, 1]["valid"] and sc[0, 2]["valid"]
+    assert sc[0, 1]["pull"][0]["point"] != sc[0, 2]["pull"][0]["point"] or sc[0, 1]["pull"][0]["dx"] != sc[0, 2]["pull"][0]["dx"]

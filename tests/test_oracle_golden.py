@@ -4,7 +4,8 @@ The reference itself ships no tests or golden vectors for this path (SURVEY.md s
 import numpy as np
 import pytest
 
-TRAJ = ["g_traj_lift_pull_25.npz", "g_traj_fold_25.npz", "g_traj_tear_25.npz", "g_traj_fold_50.npz"]
+TRAJ = ["g_traj_lift_pull_25.npz", "g_traj_fold_25.npz", "g_traj_tear_25.npz", "g_traj_fold_50.npz",
+        "g_traj_friction_25.npz"]
 ENVS = ["g_env_tier1_1337.npz", "g_env_tier2_1337.npz", "g_env_tier2_1338.npz", "g_env_tier3_1337.npz",
         "g_env_tier3_1339.npz"]
 
@@ -95,6 +96,29 @@ def test_env_actions_bit_exact(name, oracle_lib):
         assert np.array_equal(pos, g["act_pos1"][k]) and np.array_equal(prev, g["act_prev1"][k]), (name, k)
         assert np.array_equal(pin.astype(bool), g["act_pin1"][k].astype(bool))
         assert c.have_tear == bool(g["act_tear"][k])
+
+
+def test_action_modes_bit_exact(oracle_lib):
+    """ClothEnv.step in all four action modes (clip_act_space x delta_actions, cloth_env.py:402-470): the host-side
+    decoding of gym_cloth_amd.envs + the oracle reproduce the reference's update() count and end state bit for bit,
+    including actions outside the bounds (truncated) and the non-delta length/angle form."""
+    import json
+    from gym_cloth_amd.envs import decode_actions
+    g = oracle_lib.load_golden("g_decode_modes.npz")
+    meta = json.loads(str(g["meta"]))
+    e = g["cfg"]["env"]
+    assert len(meta) == 8 and {(m["clip"], m["delta"]) for m in meta} == {(True, True), (False, True), (True, False), (False, False)}
+    for k, m in enumerate(meta):
+        c = oracle_lib.OracleCloth(g["cfg"])
+        c.set_state(g["pos0"][k], g["pos0"][k], np.zeros(c.P, dtype=np.uint8))
+        d = decode_actions(np.array(m["action"])[None], m["low"], m["high"], m["clip"], m["delta"], e["reduce_factor"],
+                           e["iters_up"], e["iters_up_rest"], e["iters_pull_max"], e["iters_grip_rest"], e["iters_rest"])
+        n = c.grab_top(float(d["x"][0]), float(d["y"][0]))
+        done = c.run_schedule(d["bounds"][0] if n > 0 else np.zeros(5, dtype=np.int64), 0.0025,
+                              float(d["x_dir_r"][0]), float(d["y_dir_r"][0]), True)
+        assert done == m["n_updates"], (k, m, done)
+        pos, prev, pin = c.get_state()
+        assert np.array_equal(pos, g["pos1"][k]) and np.array_equal(prev, g["prev1"][k]), (k, m)
 
 
 @pytest.mark.parametrize("name", ENVS)
