@@ -11,9 +11,12 @@ A "step" = ClothEnv.step for every env of the batch = decode + Gripper.grab_top 
 (~1430 + iters_pull Cloth.update() per env, cloth_env.py:472-515) + metrics + terminal test.
 
 Two execution modes (both reported; `value` is the fused one unless --mode step):
-  fused  ClothVecEnv.step_many: T steps per kernel launch (clothhip_run_actions), episode resets INSIDE the launch
-         (their Cloth.update() calls are executed by the same kernel, inside the timed region, and are counted),
-         envs never wait for each other.
+  fused  ClothVecEnv.step_many: one kernel launch (clothhip_run_actions) is a TIME SLICE in which every env executes its
+         own sequence of actions and episode resets back to back (the resets' Cloth.update() calls are executed by the same
+         kernel, inside the timed region, and are counted). Envs never wait for each other: the launch ends when the
+         slice is used up, not when the env with the most work has finished a fixed number of actions, so after K
+         "steps" the envs have executed K actions on average, not each exactly K (config.env_steps_executed says how
+         many). The result of an action does not depend on which launch executes it.
   step   ClothVecEnv.step: one launch sequence per step (grab, schedule kernel, metrics), the clock is STOPPED around the
          host-driven episode resets between steps (SURVEY 8d excludes reset from the timed region).
 value = executed Cloth.update()-equivalents of all envs and ranks / timed wall time. State is resident in HBM; the timed
@@ -28,7 +31,6 @@ Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
-import math
 import os
 import subprocess
 import sys
@@ -104,14 +106,6 @@ def cpu_baseline(cfg, acts0, states, budget_s=15.0):
             "single_core_value": float(ex1 / dt1) if dt1 > 0 and ex1 > 0 else None}
 
 
-def pick_fuse(steps, warmup, fuse_max):
-    """steps per launch in fused mode: the largest T <= fuse_max that divides both the timed and the warm-up step count."""
-    for t in range(max(1, fuse_max), 0, -1):
-        if steps % t == 0 and warmup % t == 0:
-            return t
-    return 1
-
-
 def load_traffic(mode, E, n_side, precision, fuse):
     """HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/r02_traffic.json, produced by
     tools/collect_profiles.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950
@@ -127,7 +121,7 @@ def load_traffic(mode, E, n_side, precision, fuse):
 
 
 def run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, rank, world, local_rank, thickness=None,
-                 want_cpu=False):
+                 want_cpu=False, step_ms=170.0, slots=0, max_resets=0):
     """One bench configuration on this rank's GPU; returns the result record (rank 0) or None."""
     from gym_cloth_amd.dist import LocalTransport, RcclTransport, StepExchange
     from gym_cloth_amd.envs import ClothVecEnv
@@ -142,11 +136,14 @@ def run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, rank
     P = env.P
     fuse = 1
     if mode == "fused":
-        fuse = pick_fuse(steps, warmup, fuse_max)
+        fuse = max(1, min(fuse_max, steps))              # nominal steps per launch: the timed region is steps // fuse launches
         if not env.batch.fused_supported:                    # grid too large for the in-kernel metrics: report the step mode
             if rank == 0:
                 print("bench: fused mode unavailable for %dx%d; using step mode" % (n_side, n_side), file=sys.stderr)
             mode, fuse = "step", 1
+    slice_ms = fuse * step_ms
+    slots = slots if slots > 0 else 4 * fuse
+    max_resets = max_resets if max_resets > 0 else 2 * fuse
     total = warmup + steps
     acts_all = None
     if rank == 0:                                            # actions for ALL envs of the job, RandomState(2000+e)
@@ -158,7 +155,8 @@ def run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, rank
         xch.barrier()                                        # RCCL all-reduce on the handle's stream + stream sync
         env.batch.sync(False)
 
-    stat = {"sub": 0, "act_sub": 0, "kms": 0.0, "launches": 0, "ran": 0, "slots": 0, "resets": 0}
+    stat = {"sub": 0, "act_sub": 0, "kms": 0.0, "launches": 0, "ran": 0, "grabbed": 0, "slots": 0, "resets": 0, "out_of_slots": 0}
+    cpu_acts = None
     cpu_states = None
     t_timed = 0.0
     if mode == "step":
@@ -177,48 +175,67 @@ def run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, rank
                 t_timed += dt
                 s = int(env.last_executed.sum())
                 stat["sub"] += s; stat["act_sub"] += s; stat["kms"] += env.batch.last_kernel_ms; stat["launches"] += 1
-                stat["ran"] += int((env.last_executed > 0).sum()); stat["slots"] += E
+                stat["ran"] += E; stat["grabbed"] += int((info["n_grabbed"] > 0).sum()); stat["slots"] += E
             if auto_reset_host and done.any():               # the reference's episode loop; clock stopped
                 stat["resets"] += int(done.sum()) if t >= warmup else 0
                 env.reset(mask=done)
     else:
-        n_warm, n_timed = warmup // fuse, steps // fuse
+        # every env consumes ITS OWN action stream (RandomState(2000+e)) at its own pace: per launch rank 0 builds the table
+        # of each env's next `slots` actions from the per-env counters, broadcasts it, and gets the consumed counts back
+        n_warm, n_timed = (warmup + fuse - 1) // fuse, max(1, steps // fuse)
+        n_stream = total + slots * (n_warm + n_timed + 1)
+        if rank == 0:
+            streams = np.stack([np.random.RandomState(2000 + e).uniform(-1, 1, size=(n_stream, 4)) for e in range(world * E)])
+            cnt = np.zeros(world * E, dtype=np.int64)
         for w in range(n_warm + n_timed):
-            tbl = xch.broadcast_actions(acts_all[w * fuse:(w + 1) * fuse] if rank == 0 else None, n_actions=fuse)
+            tbl = None
+            if rank == 0:
+                idx = (cnt[None, :] + np.arange(slots)[:, None]) % n_stream
+                tbl = streams[np.arange(world * E)[None, :], idx]                     # [slots, world*E, 4]
+            tbl = xch.broadcast_actions(tbl, n_actions=slots)
             if w == n_warm:
                 if want_cpu and rank == 0:
                     cpu_states = env.batch.get_state(0, min(E, 512))
+                    cpu_acts = tbl[0][:min(E, 512)].copy()
                 fence()
                 t0 = time.perf_counter()
-            out = env.step_many(tbl, auto_reset=True)
-            xch.gather_results(out["rew"][-1], out["done"][-1], out["actual_coverage"][-1], out["executed"].sum(axis=0))
+            out = env.step_many(tbl, auto_reset=True, time_budget_ms=slice_ms, max_resets=max_resets)
+            n_ran = out["ran"].sum(axis=0)
+            res = xch.gather_results(n_ran, out["done"][-1], out["actual_coverage"][-1], out["executed"].sum(axis=0))
+            if rank == 0:
+                cnt += res[:, 0].astype(np.int64)
             if w >= n_warm:
                 a_sub, r_sub = int(out["executed"].sum()), int(out["reset_substeps"].sum())
                 stat["sub"] += a_sub + r_sub; stat["act_sub"] += a_sub
                 stat["kms"] += env.batch.last_kernel_ms; stat["launches"] += 1
-                stat["ran"] += int((out["executed"] > 0).sum()); stat["slots"] += fuse * E
+                stat["ran"] += int(n_ran.sum()); stat["grabbed"] += int((out["n_grabbed"] > 0).sum()); stat["slots"] += slots * E
                 stat["resets"] += int((out["reset_before"] > 0).sum())
+                stat["out_of_slots"] += int((n_ran == slots).sum())
         fence()
         t_timed = time.perf_counter() - t0
     dt = xch.max_over_ranks(t_timed)
     n_sub_all = xch.sum_over_ranks(stat["sub"])
     n_act_all = xch.sum_over_ranks(stat["act_sub"])
+    n_env_steps = xch.sum_over_ranks(stat["ran"])
     rec = None
     if rank == 0:
         b_alg = 49 * P                                        # algorithmic bytes per cloth-substep (fp32)
         ach = (stat["sub"] * b_alg / 1e9) / (stat["kms"] / 1e3) if stat["kms"] > 0 else 0.0
         rec = {
-            "value": n_sub_all / dt, "ms_per_step": dt / steps * 1e3, "dtype": precision,
+            "value": n_sub_all / dt, "ms_per_step": dt / max(n_env_steps / (world * E), 1e-9) * 1e3, "dtype": precision,
             "config": {"workload": "%d batched %dx%d cloths per GPU, %s start, random pick-and-place actions, episodes "
                                    "reset as in the reference's loop (BASELINE configs[2]; configs[3] = 8 x this)"
                                    % (E, n_side, n_side, init.replace("tier", "tier-")),
-                       "mode": "fused: %d steps per launch, episode resets inside the launch (counted)" % fuse
+                       "mode": ("fused: %d launches, each a %.0f ms time slice of back-to-back actions and episode resets per env "
+                                "(reset substeps counted)" % (stat["launches"], slice_ms))
                                if mode == "fused" else "step: one launch sequence per step, clock stopped around host-driven resets",
-                       "envs_per_gpu": E, "n_side": n_side, "init": init, "exact_order": True, "steps_per_launch": fuse,
-                       "env_steps_per_s": world * E * steps / dt,
-                       "substeps_per_env_step": n_sub_all / (world * E * steps),
+                       "envs_per_gpu": E, "n_side": n_side, "init": init, "exact_order": True,
+                       "env_steps_executed": n_env_steps, "steps_equivalent": n_env_steps / (world * E),
+                       "env_steps_per_s": n_env_steps / dt,
+                       "substeps_per_env_step": n_sub_all / max(n_env_steps, 1),
                        "action_substeps_per_s": n_act_all / dt,
-                       "active_env_frac": stat["ran"] / max(stat["slots"], 1),
+                       "grabbed_env_frac": stat["grabbed"] / max(stat["ran"], 1),       # env-steps whose pick point hit the cloth (else 0 substeps)
+                       "envs_out_of_slots": stat["out_of_slots"],                       # fused: envs that used all their action slots of a launch
                        "episode_resets_in_timed_region": stat["resets"]},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": load_traffic(mode, E, n_side, precision, fuse),
@@ -227,7 +244,8 @@ def run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, rank
                          "substeps_per_launch": stat["sub"] / max(stat["launches"], 1)},
         }
         if want_cpu and cpu_states is not None:
-            rec["cpu_baseline"] = cpu_baseline(cfg, acts_all[warmup][:len(cpu_states[0])], cpu_states)
+            rec["cpu_baseline"] = cpu_baseline(cfg, (cpu_acts if cpu_acts is not None else acts_all[warmup])[:len(cpu_states[0])],
+                                               cpu_states)
     xch.barrier()
     xch.t.close()
     env.close()
@@ -266,7 +284,11 @@ def main():
     ap.add_argument("--init", default="tier1", choices=["tier1", "tier2", "tier3"],
                     help="start state of every env (reset draws come from RandomState(1000+e))")
     ap.add_argument("--mode", default="fused", choices=["fused", "step"])
-    ap.add_argument("--fuse", type=int, default=5, help="fused mode: at most this many steps per launch")
+    ap.add_argument("--fuse", type=int, default=10, help="fused mode: nominal steps per launch; the timed region is steps // fuse launches")
+    ap.add_argument("--step-ms", type=float, default=170.0,
+                    help="fused mode: nominal duration of one step; a launch is a time slice of fuse * step_ms (scaled with the "
+                         "work per cloth-substep for other grids / precisions)")
+    ap.add_argument("--slots", type=int, default=0, help="fused mode: action slots per env and launch (0: 4 * fuse)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the companion records (f64, step mode, tier-2, 50x50, 2048 cloths)")
     args = ap.parse_args()
@@ -280,7 +302,7 @@ def main():
 
     head = run_workload(args.n_side, args.envs, args.precision, args.init, args.mode, args.steps, args.warmup, args.fuse,
                         rank, world, local_rank, thickness=args.thickness,
-                        want_cpu=(world == 1 and not args.no_cpu_baseline))
+                        want_cpu=(world == 1 and not args.no_cpu_baseline), step_ms=args.step_ms, slots=args.slots)
     extra = []
     if world == 1 and not args.no_extra:
         def companion(label, **kw):
@@ -291,22 +313,25 @@ def main():
                 r = {"error": "%s: %s" % (type(exc).__name__, exc)}
             r["label"], r["wall_s"] = label, time.perf_counter() - t0
             extra.append(r)
-        k5 = dict(rank=0, world=1, local_rank=local_rank, fuse_max=args.fuse)
+        k5 = dict(rank=0, world=1, local_rank=local_rank, slots=args.slots)
         other = "f64" if args.precision == "f32" else "f32"
         companion("same workload, %s instantiation%s" % (other, " (bit-exact vs the reference)" if other == "f64" else ""),
-                  n_side=args.n_side, E=args.envs, precision=other, init=args.init, mode=args.mode, steps=5, warmup=5, **k5)
+                  n_side=args.n_side, E=args.envs, precision=other, init=args.init, mode=args.mode, steps=10, warmup=5,
+                  fuse_max=10, step_ms=args.step_ms * (1.5 if other == "f64" else 0.7), **k5)
         companion("same workload, the other execution mode", n_side=args.n_side, E=args.envs, precision=args.precision,
-                  init=args.init, mode="step" if args.mode == "fused" else "fused", steps=10, warmup=5, **k5)
+                  init=args.init, mode="step" if args.mode == "fused" else "fused", steps=10, warmup=5, fuse_max=10,
+                  step_ms=args.step_ms, **k5)
         if args.init != "tier2":
             companion("BASELINE configs[3] shape: tier-2 start, 512 cloths per GPU (per-env rest tables; resets on the host)",
-                      n_side=25, E=512, precision=args.precision, init="tier2", mode="step", steps=5, warmup=1, **k5)
+                      n_side=25, E=512, precision=args.precision, init="tier2", mode="step", steps=5, warmup=1, fuse_max=1, **k5)
         if args.envs < 2048 and args.n_side == 25:
             companion("2048 cloths per GPU (4 resident generations of workgroups per launch)", n_side=25, E=2048,
-                      precision=args.precision, init="tier1", mode="fused", steps=5, warmup=5, **k5)
+                      precision=args.precision, init="tier1", mode="fused", steps=5, warmup=0, fuse_max=5,
+                      step_ms=4 * args.step_ms, **k5)
         if args.n_side == 25:
             companion("BASELINE configs[4]: 50x50 x 1024 cloths, thickness 0.0095", n_side=50, E=1024,
-                      precision=args.precision, init="tier1", mode="fused", steps=2, warmup=0, want_cpu=not args.no_cpu_baseline,
-                      **k5)
+                      precision=args.precision, init="tier1", mode="fused", steps=5, warmup=0, fuse_max=5, step_ms=2400.0,
+                      want_cpu=not args.no_cpu_baseline, **k5)
     if rank == 0:
         out = {
             "metric": "cloth substeps/sec (25x25 grid, batched envs)" if args.n_side == 25 else
@@ -323,7 +348,8 @@ def main():
             f64 = next((r for r in extra if r.get("dtype") == "f64" and "value" in r), None)
             if f64:
                 out["f64"] = {"value": f64["value"], "ms_per_step": f64["ms_per_step"], "frac": f64["roofline"]["frac"],
-                              "note": "the bit-exact instantiation on the same workload (%d timed steps)" % 5}
+                              "note": "the bit-exact instantiation on the same workload (%.1f steps timed)"
+                                      % f64["config"]["steps_equivalent"]}
         print(json.dumps(out))
 
 

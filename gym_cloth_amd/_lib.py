@@ -100,8 +100,11 @@ SYMBOLS = [
     ("clothhip_run_async", C.c_int, [_vp, _vp]),
     ("clothhip_sync", C.c_int, [_vp, _i32p]),
     ("clothhip_fused_supported", C.c_int, [_vp]),
+    ("clothhip_run_actions_begin", C.c_int, [_vp, C.POINTER(ClothEpisodeParams), C.c_int32, C.c_int32, _vp, C.c_int32, _i32p,
+                                             _vp, C.c_int32, _i32p, _u8p, C.c_int32, C.c_int32, C.c_int32, C.c_double]),
+    ("clothhip_run_actions_end", C.c_int, [_vp, _i32p, _u8p, _vp, _vp, _vp, _vp]),
     ("clothhip_run_actions", C.c_int, [_vp, C.POINTER(ClothEpisodeParams), C.c_int32, C.c_int32, _vp, C.c_int32, _i32p, _vp,
-                                       _i32p, _u8p, _vp, _vp, _vp, _vp]),
+                                       C.c_int32, _i32p, _u8p, _vp, _vp, _vp, _vp, C.c_double]),
     ("clothhip_update", C.c_int, [_vp, C.c_int32, _dp]),
     ("clothhip_metrics", C.c_int, [_vp, _dp, _dp, _u8p, _u8p]),
     ("clothhip_metrics_ex", C.c_int, [_vp, _dp, _dp, _u8p, _u8p, _i32p]),

@@ -197,12 +197,10 @@ class ClothBatch(object):
     def fused_supported(self):
         return bool(check(self._L.clothhip_fused_supported(self._h)))
 
-    def run_actions(self, ep, n_actions, num_steps, done, actions=None, policy=None, policy_arg=None, scripts=None,
-                    want_resets=True, want_obs=False, actions_device_ptr=None):
-        """clothhip_run_actions: `n_actions` whole ClothEnv.step calls per env in one launch (see include/clothhip.h).
-        ep: _lib.ClothEpisodeParams; num_steps int32[E] and done uint8[E] are updated in place.
-        Returns (records[T, E], resets[E, 2] or None, obs float32[T, E, 3P] or None, reset_obs float32[E, 2, 3P] or
-        None: the first observation of every episode started inside the launch)."""
+    def run_actions_begin(self, ep, n_actions, num_steps, done, actions=None, policy=None, policy_arg=None, scripts=None,
+                          want_resets=True, want_obs=False, actions_device_ptr=None, time_budget_ms=0.0):
+        """First half of clothhip_run_actions (see include/clothhip.h): upload + launch, returns while the kernel runs.
+        ep: _lib.ClothEpisodeParams; scripts: RESET_SCRIPT_DTYPE[E, R], each env's next R resets in order."""
         T = int(n_actions)
         pol = _lib.POLICY_TABLE if policy is None else int(policy)
         on_dev = 0
@@ -220,16 +218,36 @@ class ClothBatch(object):
         parg = None if policy_arg is None else np.ascontiguousarray(policy_arg, dtype=np.int32)
         if scripts is not None:
             scripts = np.ascontiguousarray(scripts, dtype=_lib.RESET_SCRIPT_DTYPE)
-            if scripts.shape != (self.E, 3):
-                raise ValueError("scripts must have shape (%d, 3)" % self.E)
-        rec = np.zeros((T, self.E), dtype=_lib.STEP_RECORD_DTYPE)
-        rst = np.zeros((self.E, 2), dtype=_lib.RESET_RECORD_DTYPE) if (want_resets and scripts is not None) else None
-        obs = np.empty((T, self.E, 3 * self.P), dtype=np.float32) if want_obs else None
-        robs = np.empty((self.E, 2, 3 * self.P), dtype=np.float32) if (want_obs and scripts is not None) else None
+            if scripts.ndim != 2 or scripts.shape[0] != self.E:
+                raise ValueError("scripts must have shape (%d, R)" % self.E)
+        R = 0 if scripts is None else scripts.shape[1]
+        have_rst = bool(want_resets and scripts is not None)
+        have_robs = bool(want_obs and scripts is not None)
         vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
-        check(self._L.clothhip_run_actions(self._h, C.byref(ep), T, pol, ap, on_dev, _lib.i32p(parg), vp(scripts),
-                                           _lib.i32p(num_steps), _lib.u8p(done), vp(rec), vp(rst), vp(obs), vp(robs)))
+        check(self._L.clothhip_run_actions_begin(self._h, C.byref(ep), T, pol, ap, on_dev, _lib.i32p(parg), vp(scripts), R,
+                                                 _lib.i32p(num_steps), _lib.u8p(done), int(have_rst), int(bool(want_obs)),
+                                                 int(have_robs), float(time_budget_ms)))
+        self._fused = (T, R, num_steps, done, have_rst, bool(want_obs), have_robs)
+
+    def run_actions_end(self):
+        """Second half: wait for the launch and fetch its outputs. num_steps / done given to _begin are updated in place.
+        Returns (records[T, E], resets[E, R] or None, obs float32[T, E, 3P] or None, reset_obs float32[E, R, 3P] or None:
+        the first observation of every episode started inside the launch)."""
+        T, R, num_steps, done, have_rst, have_obs, have_robs = self._fused
+        self._fused = None
+        rec = np.zeros((T, self.E), dtype=_lib.STEP_RECORD_DTYPE)
+        rst = np.zeros((self.E, R), dtype=_lib.RESET_RECORD_DTYPE) if have_rst else None
+        obs = np.empty((T, self.E, 3 * self.P), dtype=np.float32) if have_obs else None
+        robs = np.empty((self.E, R, 3 * self.P), dtype=np.float32) if have_robs else None
+        vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        check(self._L.clothhip_run_actions_end(self._h, _lib.i32p(num_steps), _lib.u8p(done), vp(rec), vp(rst), vp(obs),
+                                               vp(robs)))
         return rec, rst, obs, robs
+
+    def run_actions(self, *a, **k):
+        """clothhip_run_actions: `n_actions` whole ClothEnv.step calls per env in one launch (begin + end)."""
+        self.run_actions_begin(*a, **k)
+        return self.run_actions_end()
 
     def update(self, n=1, delta=None):
         """n x Cloth.update() (cloth.pyx:169), each preceded by Gripper.adjust(*delta) if delta is given."""

@@ -48,16 +48,18 @@ template <typename T> struct FusedArgs {
     int32_t nT, policy, NS, NH;       // action slots per launch, CLOTHHIP_POLICY_*, metrics sort / hull buffer sizes
     const double *actions;            // [nT][E][4]
     const int32_t *policy_arg;        // [E] or nullptr
-    const ClothResetScript *scripts;  // [E][3] or nullptr
+    const ClothResetScript *scripts;  // [E][n_scripts] or nullptr: the env's next resets, in order (see clothhip.h)
     int32_t *num_steps;               // [E]
     uint8_t *done;                    // [E]
     ClothStepRecord *records;         // [nT][E]
-    ClothResetRecord *resets;         // [E][2] or nullptr
+    ClothResetRecord *resets;         // [E][n_scripts] or nullptr
     float *obs;                       // [nT][E][3P] or nullptr
-    float *reset_obs;                 // [E][2][3P] or nullptr
+    float *reset_obs;                 // [E][n_scripts][3P] or nullptr
     const T *flat;                    // [3][Ppad] flat grid
     const double *levels;             // Gripper.grab_top curZ table
     int32_t n_glevels, E;
+    int32_t n_scripts, _pad;
+    uint64_t budget_ticks;            // 0 = none; else no new action / reset starts once the launch has run this many 100 MHz ticks
     double two_thickness, half_thickness;
     ClothEpisodeParams ep;
 };
@@ -68,12 +70,13 @@ struct EpState {
     int32_t t_slot;        // next action slot of this launch
     int32_t rp;            // reset stage: -1 none; 2p = coverage condition of pull p, 2p+1 = pull p, 6 = settle, 7 = end
     int32_t n_resets;      // resets done in this launch
-    int32_t first_pulls;   // pulls the first one ran (selects the RNG fork of the second script, see clothhip.h)
+    int32_t chain_ok;      // 1 while every reset of this launch ran its unconditional pulls only: the next script is valid
     int32_t rs_pulls;      // pulls run by the reset in progress
     int32_t reset_mark;    // the next executed action record gets reset_before = this
     int32_t ep_steps, ep_done;
     int32_t op, n_grab, iters_pull, decode_err;
-    int32_t done_total, _pad;
+    int32_t done_total;
+    int32_t stop;          // the launch's time slice is used up: no new action or reset starts
     double act[4];
 };
 
@@ -439,10 +442,11 @@ __device__ __forceinline__ void collide_cell_serial(Pt<T> *cur, uint16_t *m, int
 // kernel (256 threads) and the in-kernel call of the episode stepper give the same bits.
 // Results: out[0] coverage, out[1] variance_inv, out[2] out-of-bounds (0/1), out[3] #(z < half_thick); valid for ALL
 // threads on return (the function ends with a barrier).
-template <int NT, typename Src>
+template <int NT, typename K, typename Src>
 __device__ __forceinline__ void metrics_block(const Src &src, int P, int NS, int NH, unsigned char *scr, int tid, double half_thick,
                                               double out[4]) {
-    double *sx = reinterpret_cast<double *>(scr), *sy = sx + NS, *hx = sy + NS, *hy = hx + NH;
+    K *sx = reinterpret_cast<K *>(scr), *sy = sx + NS;
+    double *hx = reinterpret_cast<double *>(sy + NS), *hy = hx + NH;
     double *red = hy + NH;                                    // [64] reduction scratch
     const int lane = tid & 63, wave = tid >> 6;
     const double INF = __longlong_as_double(0x7ff0000000000000LL);
@@ -459,7 +463,7 @@ __device__ __forceinline__ void metrics_block(const Src &src, int P, int NS, int
                 mnz = fmin(mnz, z); mxz = fmax(mxz, z); sum += z;
                 x = fmin(fmax(x, 0.0), 1.0); y = fmin(fmax(y, 0.0), 1.0);                         // cloth_env.py:629
             }
-            sx[i] = x; sy[i] = y;
+            sx[i] = (K)x; sy[i] = (K)y;
         }
     }
     // block reductions (min/max exact; the z-sum order differs from numpy's pairwise sum only in the last bits)
@@ -496,7 +500,7 @@ __device__ __forceinline__ void metrics_block(const Src &src, int P, int NS, int
             __syncthreads();
             for (int t = tid; t < (NS >> 1); t += NT) {
                 const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
-                const double ax = sx[i], ay = sy[i], bx = sx[l], by = sy[l];
+                const K ax = sx[i], ay = sy[i], bx = sx[l], by = sy[l];
                 const bool gt = ax > bx || (ax == bx && ay > by);
                 if (gt == ((i & kk) == 0)) { sx[i] = bx; sy[i] = by; sx[l] = ax; sy[l] = ay; }
             }
@@ -521,12 +525,12 @@ __device__ __forceinline__ void metrics_block(const Src &src, int P, int NS, int
             };
             int k = 0;
             for (int i = 0; i < m; i++) {
-                while (k >= 2 && cross(hx[k - 2], hy[k - 2], hx[k - 1], hy[k - 1], sx[i], sy[i]) <= 0) k--;
-                hx[k] = sx[i]; hy[k] = sy[i]; k++;
+                while (k >= 2 && cross(hx[k - 2], hy[k - 2], hx[k - 1], hy[k - 1], (double)sx[i], (double)sy[i]) <= 0) k--;
+                hx[k] = (double)sx[i]; hy[k] = (double)sy[i]; k++;
             }
             for (int i = m - 2, t = k + 1; i >= 0; i--) {
-                while (k >= t && cross(hx[k - 2], hy[k - 2], hx[k - 1], hy[k - 1], sx[i], sy[i]) <= 0) k--;
-                hx[k] = sx[i]; hy[k] = sy[i]; k++;
+                while (k >= t && cross(hx[k - 2], hy[k - 2], hx[k - 1], hy[k - 1], (double)sx[i], (double)sy[i]) <= 0) k--;
+                hx[k] = (double)sx[i]; hy[k] = (double)sy[i]; k++;
             }
             k--;
             if (k >= 3) {
@@ -673,11 +677,12 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
     EpState *const eps = reinterpret_cast<EpState *>(smem + lay.eps);
     if (fused) {
         if (tid == 0) {
-            eps->t_slot = 0; eps->rp = -1; eps->n_resets = 0; eps->first_pulls = 0; eps->rs_pulls = 0; eps->reset_mark = 0;
-            eps->ep_steps = Fp->num_steps[e]; eps->ep_done = Fp->done[e] ? 1 : 0; eps->done_total = 0;
+            eps->t_slot = 0; eps->rp = -1; eps->n_resets = 0; eps->chain_ok = 1; eps->rs_pulls = 0; eps->reset_mark = 0;
+            eps->ep_steps = Fp->num_steps[e]; eps->ep_done = Fp->done[e] ? 1 : 0; eps->done_total = 0; eps->stop = 0;
         }
         __syncthreads();
     }
+    const uint64_t t_launch = FUSED ? __builtin_amdgcn_s_memrealtime() : 0;   // 100 MHz, constant rate (thread 0's copy is used)
     int done_nf = 0;                   // executed substeps of the external schedule (not fused)
     for (;;) {
         bool do_run = true;
@@ -685,9 +690,10 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
             // ---- plan the next operation. Every thread evaluates the same transitions on the same LDS-resident state.
             const FusedArgs<T> &F = *Fp;
             int t_slot = eps->t_slot, rp = eps->rp;
-            const int n_resets = eps->n_resets, first_pulls = eps->first_pulls;
-            const int slot = n_resets == 0 ? 0 : (n_resets == 1 ? (first_pulls >= 3 ? 2 : 1) : -1);
-            const ClothResetScript *scr = (F.scripts != nullptr && slot >= 0) ? F.scripts + ((size_t)e * 3 + slot) : nullptr;
+            const int n_resets = eps->n_resets;
+            // rp >= 0: the script of the reset in progress; else the env's next one, valid only while the chain is intact
+            const bool have_scr = F.scripts != nullptr && n_resets < F.n_scripts && (rp >= 0 || eps->chain_ok);
+            const ClothResetScript *scr = have_scr ? F.scripts + ((size_t)e * F.n_scripts + n_resets) : nullptr;
             int op = OP_ACTION;
             bool do_decode = false;
             double act[4] = {0.0, 0.0, 0.0, 0.0};
@@ -695,6 +701,10 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
             do_run = false;
             if (rp < 0) {
                 if (t_slot >= F.nT) break;
+                // time slice: envs advance at their own pace, so a launch ends when its time budget is used up rather than when
+                // the slowest env has finished a fixed number of actions. Decided by thread 0 between actions (a reset is always
+                // followed by its first action in the same launch). Which launch executes an action never changes its result.
+                if (eps->stop && eps->reset_mark == 0) break;
                 if (eps->ep_done) {
                     __syncthreads();                     // everyone has read the state
                     if (scr != nullptr && scr->valid) {
@@ -710,7 +720,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                             misc[0] = 0;
                             eps->rp = 0; eps->rs_pulls = 0; eps->ep_steps = 0; eps->ep_done = 0;
                             if (F.resets) {
-                                ClothResetRecord *rr_ = F.resets + ((size_t)e * 2 + n_resets);
+                                ClothResetRecord *rr_ = F.resets + ((size_t)e * F.n_scripts + n_resets);
                                 rr_->consumed = 1; rr_->pulls_run = 0; rr_->executed[0] = rr_->executed[1] = rr_->executed[2] = 0;
                                 rr_->settle_executed = 0; rr_->tear = 0;
                             }
@@ -1509,7 +1519,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
             if (op == OP_ACTION || op == OP_RESET_COND || op == OP_RESET_END) {
                 // cloth_env.py:1020-1098 on the LDS-resident state; the sort buffers borrow the LDS behind the particle records
                 auto src = [&](int i, double &x, double &y, double &z) { const Pt<T> c = cur[i]; x = (double)c.x; y = (double)c.y; z = (double)c.z; };
-                metrics_block<NT>(src, P, F.NS, F.NH, smem + lay.ent, tid, F.half_thickness, mo);
+                metrics_block<NT, T>(src, P, F.NS, F.NH, smem + lay.ent, tid, F.half_thickness, mo);
                 init_lds(tear_now);
                 __syncthreads();
             }
@@ -1518,10 +1528,11 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                 for (int i = tid; i < P; i += NT) { const Pt<T> c = cur[i]; o_[3 * i] = (float)c.x; o_[3 * i + 1] = (float)c.y; o_[3 * i + 2] = (float)c.z; }
             }
             if (op == OP_RESET_END && F.reset_obs) {                                              // what env.reset() returns
-                float *o_ = F.reset_obs + ((size_t)e * 2 + n_resets) * 3 * P;
+                float *o_ = F.reset_obs + ((size_t)e * F.n_scripts + n_resets) * 3 * P;
                 for (int i = tid; i < P; i += NT) { const Pt<T> c = cur[i]; o_[3 * i] = (float)c.x; o_[3 * i + 1] = (float)c.y; o_[3 * i + 2] = (float)c.z; }
             }
             if (tid == 0) {
+                if (F.budget_ticks != 0 && __builtin_amdgcn_s_memrealtime() - t_launch >= F.budget_ticks) eps->stop = 1;
                 eps->done_total += done;
                 if (op == OP_ACTION) {
                     const int ep_steps = eps->ep_steps + 1;
@@ -1537,9 +1548,8 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                     r_->reset_before = (uint8_t)eps->reset_mark;
                     eps->reset_mark = 0; eps->ep_steps = ep_steps; eps->ep_done = dn ? 1 : 0; eps->t_slot = t_slot + 1;
                 } else {
-                    const int slot = n_resets == 0 ? 0 : (eps->first_pulls >= 3 ? 2 : 1);
-                    const ClothResetScript *scr = F.scripts + ((size_t)e * 3 + slot);
-                    ClothResetRecord *rr_ = F.resets ? F.resets + ((size_t)e * 2 + n_resets) : nullptr;
+                    const ClothResetScript *scr = F.scripts + ((size_t)e * F.n_scripts + n_resets);
+                    ClothResetRecord *rr_ = F.resets ? F.resets + ((size_t)e * F.n_scripts + n_resets) : nullptr;
                     if (op == OP_RESET_COND) {
                         eps->rp = mo[0] >= scr->pull[rp >> 1].coverage_min ? rp + 1 : 6;        // cloth_env.py:866
                     } else if (op == OP_RESET_PULL) {
@@ -1555,7 +1565,12 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                         eps->rp = 7;
                     } else {                                                                      // OP_RESET_END
                         if (rr_) { rr_->start_coverage = mo[0]; rr_->start_variance_inv = mo[1]; rr_->tear = tear_now; }
-                        if (n_resets == 0) eps->first_pulls = eps->rs_pulls;
+                        // a conditional pull that ran consumed RNG draws the later scripts were drawn without (clothhip.h)
+                        {
+                            int n_uncond = 0;
+                            for (int p_ = 0; p_ < scr->n_pulls; p_++) n_uncond += scr->pull[p_].need_coverage ? 0 : 1;
+                            if (eps->rs_pulls > n_uncond) eps->chain_ok = 0;
+                        }
                         eps->n_resets = n_resets + 1; eps->reset_mark = n_resets + 1; eps->rp = -1;
                     }
                 }
@@ -1675,7 +1690,7 @@ __global__ __launch_bounds__(256) void k_metrics(const T *pos, int P, int Ppad, 
     const T *px = pos + (size_t)e * 3 * Ppad, *py = px + Ppad, *pz = py + Ppad;
     auto src = [&](int i, double &x, double &y, double &z) { x = (double)px[i]; y = (double)py[i]; z = (double)pz[i]; };
     double out[4];
-    metrics_block<256>(src, P, NS, NH, smem, (int)threadIdx.x, half_thick, out);
+    metrics_block<256, T>(src, P, NS, NH, smem, (int)threadIdx.x, half_thick, out);
     if (threadIdx.x == 0) {
         cov[e] = out[0]; vinv[e] = out[1]; oob[e] = out[2] != 0.0 ? 1 : 0;
         if (hcnt) hcnt[e] = (int32_t)out[3];

@@ -66,7 +66,8 @@ struct clothhip_handle {
     void *d_fz = nullptr, *d_fact = nullptr, *d_fscr = nullptr, *d_frec = nullptr, *d_frst = nullptr, *d_fobs = nullptr, *d_frobs = nullptr;
     int32_t *d_fsteps = nullptr, *d_fparg = nullptr;
     uint8_t *d_fdone = nullptr;
-    size_t cap_fact = 0, cap_frec = 0, cap_fobs = 0;
+    int f_T = 0; size_t f_nscr = 0; bool f_pending = false, f_resets = false, f_obs = false, f_robs = false;
+    size_t cap_fact = 0, cap_frec = 0, cap_fobs = 0, cap_fscr = 0, cap_frst = 0, cap_frobs = 0;
     Topology topo;
     LevelSchedule lv;
     std::vector<unsigned char> stage;   // host staging for layout conversion
@@ -632,7 +633,7 @@ extern "C" int clothhip_run(clothhip_handle *h, const ClothSchedule *sched, int3
 // ---- whole episodes on the device ---------------------------------------------------------------------------------
 template <typename T> static void fill_fused(clothhip_handle *h, FusedArgs<T> &f, const ClothEpisodeParams *ep, int T_, int policy,
                                              const double *d_actions, bool have_parg, bool have_scripts, bool have_resets, bool have_obs,
-                                             bool have_robs, int NS, int NH) {
+                                             bool have_robs, int n_scripts, uint64_t budget_ticks, int NS, int NH) {
     memset(&f, 0, sizeof(f));
     f.nT = T_; f.policy = policy; f.NS = NS; f.NH = NH;
     f.actions = d_actions;
@@ -644,7 +645,7 @@ template <typename T> static void fill_fused(clothhip_handle *h, FusedArgs<T> &f
     f.obs = have_obs ? (float *)h->d_fobs : nullptr;
     f.reset_obs = have_robs ? (float *)h->d_frobs : nullptr;
     f.flat = (const T *)h->d_flat;
-    f.levels = h->d_levels; f.n_glevels = h->n_grab_levels; f.E = h->E;
+    f.levels = h->d_levels; f.n_glevels = h->n_grab_levels; f.E = h->E; f.n_scripts = n_scripts; f.budget_ticks = budget_ticks;
     f.two_thickness = 2 * h->prm.thickness; f.half_thickness = h->prm.thickness / 2.0;
     f.ep = *ep;
 }
@@ -661,7 +662,7 @@ static int grow(void **p, size_t *cap, size_t need) {
 static int fused_scratch(const clothhip_handle *h, int *need_out) {
     int NS = 1; while (NS < h->P) NS <<= 1;
     const int NH = h->Ppad + 8;
-    *need_out = (2 * NS + 2 * NH + 64) * 8;
+    *need_out = 2 * NS * (int)h->tsz + (2 * NH + 64) * 8;
     const LdsLayout lay((int)h->tsz, h->Ppad, h->Spad, h->lv.n_levels, h->n_levels8, h->HT, h->tab, h->cell_copy);
     return lay.total - lay.ent;
 }
@@ -672,16 +673,21 @@ extern "C" int clothhip_fused_supported(const clothhip_handle *h) {
     return fused_scratch(h, &need) >= need ? 1 : 0;
 }
 
-extern "C" int clothhip_run_actions(clothhip_handle *h, const ClothEpisodeParams *ep, int32_t T_, int32_t policy,
-                                    const double *actions, int32_t actions_on_device, const int32_t *policy_arg,
-                                    const ClothResetScript *scripts, int32_t *num_steps, uint8_t *done,
-                                    ClothStepRecord *records, ClothResetRecord *resets, float *obs, float *reset_obs) {
-    if (!h || !ep || !num_steps || !done || !records) return fail(CLOTHHIP_EINVAL, "NULL argument");
+extern "C" int clothhip_run_actions_begin(clothhip_handle *h, const ClothEpisodeParams *ep, int32_t T_, int32_t policy,
+                                          const double *actions, int32_t actions_on_device, const int32_t *policy_arg,
+                                          const ClothResetScript *scripts, int32_t n_scripts, const int32_t *num_steps,
+                                          const uint8_t *done, int32_t want_resets, int32_t want_obs, int32_t want_reset_obs,
+                                          double time_budget_ms) {
+    if (!h || !ep || !num_steps || !done) return fail(CLOTHHIP_EINVAL, "NULL argument");
+    if (h->f_pending) return fail(CLOTHHIP_ESTATE, "a clothhip_run_actions_begin is already in flight");
+    const bool resets = want_resets != 0, obs = want_obs != 0, reset_obs = want_reset_obs != 0;
     if (T_ < 1 || T_ > 4096) return fail(CLOTHHIP_EINVAL, "T must be in [1, 4096]");
     if (policy != CLOTHHIP_POLICY_TABLE && policy != CLOTHHIP_POLICY_ORACLE_CORNER) return fail(CLOTHHIP_EINVAL, "unknown policy %d", policy);
     if (policy == CLOTHHIP_POLICY_TABLE && !actions) return fail(CLOTHHIP_EINVAL, "the table policy needs actions[T][E][4]");
     if (policy == CLOTHHIP_POLICY_ORACLE_CORNER && h->N != 25)
         return fail(CLOTHHIP_ESTATE, "the oracle-corner policy is defined for 25x25 cloths only (analytic.py:106)");
+    if (scripts && (n_scripts < 1 || n_scripts > 64)) return fail(CLOTHHIP_EINVAL, "n_scripts must be in [1, 64]");
+    if (!scripts) n_scripts = 0;
     if (scripts && h->rest_stride != 0)
         return fail(CLOTHHIP_ESTATE, "in-kernel resets need the shared flat rest table (tiers 1 and 3); this handle has per-env rest lengths");
     if (!(ep->reduce_factor > 0) || ep->max_actions < 1) return fail(CLOTHHIP_EINVAL, "bad episode parameters");
@@ -696,13 +702,14 @@ extern "C" int clothhip_run_actions(clothhip_handle *h, const ClothEpisodeParams
     const size_t E = h->E, nrec = (size_t)T_ * E;
     if (!h->d_fz) {
         HIPCHECK(hipMalloc(&h->d_fz, 1024));
-        HIPCHECK(hipMalloc(&h->d_fscr, E * 3 * sizeof(ClothResetScript)));
-        HIPCHECK(hipMalloc(&h->d_frst, E * 2 * sizeof(ClothResetRecord)));
         HIPCHECK(hipMalloc(&h->d_fsteps, E * 4));
         HIPCHECK(hipMalloc(&h->d_fparg, E * 4));
         HIPCHECK(hipMalloc(&h->d_fdone, E));
     }
     if (int rc = grow(&h->d_frec, &h->cap_frec, nrec * sizeof(ClothStepRecord))) return rc;
+    const size_t nscr = E * (size_t)(n_scripts > 0 ? n_scripts : 1);
+    if (int rc = grow(&h->d_fscr, &h->cap_fscr, nscr * sizeof(ClothResetScript))) return rc;
+    if (int rc = grow(&h->d_frst, &h->cap_frst, nscr * sizeof(ClothResetRecord))) return rc;
     const double *d_actions = nullptr;
     if (policy == CLOTHHIP_POLICY_TABLE) {
         if (actions_on_device) d_actions = actions;
@@ -713,20 +720,24 @@ extern "C" int clothhip_run_actions(clothhip_handle *h, const ClothEpisodeParams
         }
     }
     if (obs) if (int rc = grow(&h->d_fobs, &h->cap_fobs, nrec * 3 * h->P * 4)) return rc;
-    if (reset_obs && !h->d_frobs) HIPCHECK(hipMalloc(&h->d_frobs, E * 2 * 3 * h->P * 4));
-    if (reset_obs) HIPCHECK(hipMemsetAsync(h->d_frobs, 0, E * 2 * 3 * h->P * 4, h->stream));
+    if (reset_obs && !scripts) return fail(CLOTHHIP_EINVAL, "reset_obs without scripts");
+    if (reset_obs) {
+        if (int rc = grow(&h->d_frobs, &h->cap_frobs, nscr * 3 * h->P * 4)) return rc;
+        HIPCHECK(hipMemsetAsync(h->d_frobs, 0, nscr * 3 * h->P * 4, h->stream));
+    }
     if (policy_arg) HIPCHECK(hipMemcpyAsync(h->d_fparg, policy_arg, E * 4, hipMemcpyHostToDevice, h->stream));
-    if (scripts) HIPCHECK(hipMemcpyAsync(h->d_fscr, scripts, E * 3 * sizeof(ClothResetScript), hipMemcpyHostToDevice, h->stream));
+    if (scripts) HIPCHECK(hipMemcpyAsync(h->d_fscr, scripts, nscr * sizeof(ClothResetScript), hipMemcpyHostToDevice, h->stream));
     HIPCHECK(hipMemcpyAsync(h->d_fsteps, num_steps, E * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHECK(hipMemcpyAsync(h->d_fdone, done, E, hipMemcpyHostToDevice, h->stream));
     HIPCHECK(hipMemsetAsync(h->d_frec, 0, nrec * sizeof(ClothStepRecord), h->stream));
-    if (resets) HIPCHECK(hipMemsetAsync(h->d_frst, 0, E * 2 * sizeof(ClothResetRecord), h->stream));
+    if (resets) HIPCHECK(hipMemsetAsync(h->d_frst, 0, nscr * sizeof(ClothResetRecord), h->stream));
+    const uint64_t budget_ticks = time_budget_ms > 0 ? (uint64_t)(time_budget_ms * 1e5) : 0;      // s_memrealtime: 100 MHz
     static_assert(sizeof(FusedArgs<double>) <= 1024 && sizeof(FusedArgs<float>) <= 1024, "fused argument block");
     unsigned char fzbuf[1024];
     if (h->precision == CLOTHHIP_F64)
-        fill_fused<double>(h, *reinterpret_cast<FusedArgs<double> *>(fzbuf), ep, T_, policy, d_actions, policy_arg != nullptr, scripts != nullptr, resets != nullptr, obs != nullptr, reset_obs != nullptr, NS, NH);
+        fill_fused<double>(h, *reinterpret_cast<FusedArgs<double> *>(fzbuf), ep, T_, policy, d_actions, policy_arg != nullptr, scripts != nullptr, resets, obs, reset_obs, n_scripts, budget_ticks, NS, NH);
     else
-        fill_fused<float>(h, *reinterpret_cast<FusedArgs<float> *>(fzbuf), ep, T_, policy, d_actions, policy_arg != nullptr, scripts != nullptr, resets != nullptr, obs != nullptr, reset_obs != nullptr, NS, NH);
+        fill_fused<float>(h, *reinterpret_cast<FusedArgs<float> *>(fzbuf), ep, T_, policy, d_actions, policy_arg != nullptr, scripts != nullptr, resets, obs, reset_obs, n_scripts, budget_ticks, NS, NH);
     HIPCHECK(hipMemcpyAsync(h->d_fz, fzbuf, 1024, hipMemcpyHostToDevice, h->stream));
     HIPCHECK(hipStreamSynchronize(h->stream));          // fzbuf is on this stack frame
     HIPCHECK(hipEventRecord(h->ev0, h->stream));
@@ -736,14 +747,40 @@ extern "C" int clothhip_run_actions(clothhip_handle *h, const ClothEpisodeParams
     HIPCHECK(hipEventRecord(h->ev1, h->stream));
     h->have_timing = true;
     h->pending_exec = true;
+    h->f_T = T_; h->f_nscr = nscr; h->f_resets = resets; h->f_obs = obs; h->f_robs = reset_obs;
+    h->f_pending = true;
+    return 0;
+}
+
+extern "C" int clothhip_run_actions_end(clothhip_handle *h, int32_t *num_steps, uint8_t *done, ClothStepRecord *records,
+                                        ClothResetRecord *resets, float *obs, float *reset_obs) {
+    if (!h || !num_steps || !done || !records) return fail(CLOTHHIP_EINVAL, "NULL argument");
+    if (!h->f_pending) return fail(CLOTHHIP_ESTATE, "no clothhip_run_actions_begin in flight");
+    if ((resets != nullptr) != h->f_resets || (obs != nullptr) != h->f_obs || (reset_obs != nullptr) != h->f_robs)
+        return fail(CLOTHHIP_EINVAL, "the output buffers must match the ones announced to clothhip_run_actions_begin");
+    HIPCHECK(hipSetDevice(h->device));
+    const size_t E = h->E, nrec = (size_t)h->f_T * E, nscr = h->f_nscr;
     HIPCHECK(hipMemcpyAsync(records, h->d_frec, nrec * sizeof(ClothStepRecord), hipMemcpyDeviceToHost, h->stream));
-    if (resets) HIPCHECK(hipMemcpyAsync(resets, h->d_frst, E * 2 * sizeof(ClothResetRecord), hipMemcpyDeviceToHost, h->stream));
+    if (resets) HIPCHECK(hipMemcpyAsync(resets, h->d_frst, nscr * sizeof(ClothResetRecord), hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(hipMemcpyAsync(num_steps, h->d_fsteps, E * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(hipMemcpyAsync(done, h->d_fdone, E, hipMemcpyDeviceToHost, h->stream));
     if (obs) HIPCHECK(hipMemcpyAsync(obs, h->d_fobs, nrec * 3 * h->P * 4, hipMemcpyDeviceToHost, h->stream));
-    if (reset_obs) HIPCHECK(hipMemcpyAsync(reset_obs, h->d_frobs, E * 2 * 3 * h->P * 4, hipMemcpyDeviceToHost, h->stream));
+    if (reset_obs) HIPCHECK(hipMemcpyAsync(reset_obs, h->d_frobs, nscr * 3 * h->P * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(hipStreamSynchronize(h->stream));
+    h->f_pending = false;
     return 0;
+}
+
+extern "C" int clothhip_run_actions(clothhip_handle *h, const ClothEpisodeParams *ep, int32_t T_, int32_t policy,
+                                    const double *actions, int32_t actions_on_device, const int32_t *policy_arg,
+                                    const ClothResetScript *scripts, int32_t n_scripts, int32_t *num_steps, uint8_t *done,
+                                    ClothStepRecord *records, ClothResetRecord *resets, float *obs, float *reset_obs,
+                                    double time_budget_ms) {
+    if (!records) return fail(CLOTHHIP_EINVAL, "NULL argument");
+    if (int rc = clothhip_run_actions_begin(h, ep, T_, policy, actions, actions_on_device, policy_arg, scripts, n_scripts,
+                                            num_steps, done, resets != nullptr, obs != nullptr, reset_obs != nullptr, time_budget_ms))
+        return rc;
+    return clothhip_run_actions_end(h, num_steps, done, records, resets, obs, reset_obs);
 }
 
 extern "C" int clothhip_update(clothhip_handle *h, int32_t n_sub, const double *delta) {
@@ -792,7 +829,7 @@ extern "C" double clothhip_hull_area(const double *xy, int32_t n) {
 static int launch_metrics(clothhip_handle *h) {
     int NS = 1; while (NS < h->P) NS <<= 1;
     const int NH = h->Ppad + 8;                 // the monotone chain holds at most m + 1 <= P + 1 points
-    const int lds = (2 * NS + 2 * NH + 64) * 8;
+    const int lds = 2 * NS * (int)h->tsz + (2 * NH + 64) * 8;
     const double half_thick = h->prm.thickness / 2.0;                                   // cloth_env.py:604
     if (h->precision == CLOTHHIP_F64) {
         HIPCHECK(hipFuncSetAttribute((const void *)k_metrics<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

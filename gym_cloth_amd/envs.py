@@ -258,6 +258,7 @@ class ClothVecEnv(object):
             'actual_coverage': self._current_coverage.copy(), 'start_coverage': self._start_coverage.copy(),
             'variance_inv': vinv, 'start_variance_inv': self._start_variance_inv.copy(),
             'have_tear': self.have_tear.copy(), 'out_of_bounds': oob,
+            'executed': executed.copy(), 'n_grabbed': n_grab.copy(),      # (not in the reference's info) this action's update() calls
         }
         obs = self.state
         if auto_reset and term.any():
@@ -321,41 +322,53 @@ class ClothVecEnv(object):
         return init_side, st, st
 
     def _drop_pending(self, e):
-        pend = self._pending[e]
-        if pend is not None:
-            self.np_randoms[e].set_state(pend['s0'])
-            self._pending[e] = None
+        """Give back the draws of the env's pre-drawn reset scripts (the RNG is parked at the first one's start)."""
+        self._pending[e] = None
 
-    def _prepare_scripts(self):
-        """Reset scripts of every env for the next launch, [E, 3]: slot 0 = the env's next reset, slots 1 / 2 = the one
-        after it when slot 0 ran 2 / 3 pulls (the RNG stream forks at tier 1's conditional third pull). The env RNGs are
-        left where they were; the draws are committed after the launch according to what the device consumed."""
+    def _extend_chain(self, e, n):
+        """Make env e's chain of pre-drawn resets at least n long (see _prepare_scripts); the RandomState stays parked."""
         from ._lib import RESET_SCRIPT_DTYPE
+        chain = self._pending[e]
+        if chain is None:
+            chain = self._pending[e] = []
+        if len(chain) >= n:
+            return chain
         tier = {'tier1': 1, 'tier3': 3}[self._init_type]
-        scripts = np.zeros((self.E, 3), dtype=RESET_SCRIPT_DTYPE)
+        rng = self.np_randoms[e]
+        s_start = rng.get_state()
+        if chain:
+            rng.set_state(chain[-1]['after'][0])
+            if self._consume_domrand:
+                self._domrand_draws(rng)
+        while len(chain) < n:
+            node = {'before': rng.get_state(), 'rec': np.zeros((), dtype=RESET_SCRIPT_DTYPE)}
+            side, s2, s3 = self._draw_script(rng, tier, node['rec'])
+            node['side'], node['after'] = side, (s2, s3)
+            chain.append(node)
+            rng.set_state(s2)                                     # the chain continues as if only the unconditional pulls ran
+            if self._consume_domrand:
+                self._domrand_draws(rng)
+        rng.set_state(s_start)
+        return chain
+
+    def _prepare_scripts(self, n_scripts):
+        """The next `n_scripts` resets of every env, [E, R]. Script k+1 is drawn from the RNG state script k leaves when
+        only its unconditional pulls run (tier 1: two pulls; the third, coverage-conditional one draws further numbers and
+        forks the stream, cloth_env.py:866-877). Scripts that were not consumed stay cached for the next launch; each env's
+        RandomState stays parked where its first pending script starts, so a host-side reset() simply re-draws."""
+        from ._lib import RESET_SCRIPT_DTYPE
+        R = int(n_scripts)
+        scripts = np.zeros((self.E, R), dtype=RESET_SCRIPT_DTYPE)
+        self._script_sides = np.zeros((self.E, R), dtype=bool)        # Cloth.init_side of each scripted reset (cloth.pyx:75)
         for e in range(self.E):
-            pend = self._pending[e]
-            if pend is None:
-                rng = self.np_randoms[e]
-                pend = {'s0': rng.get_state(), 'rec': np.zeros(3, dtype=RESET_SCRIPT_DTYPE), 'side': [False] * 3,
-                        'after': [None] * 3}
-                side, s2, s3 = self._draw_script(rng, tier, pend['rec'][0])
-                pend['side'][0], pend['after'][0] = side, (s2, s3)
-                for slot, st in ((1, s2), (2, s3)):
-                    if slot == 2 and tier != 1:
-                        break                                     # no fork: slot 1 is the only successor
-                    rng.set_state(st)
-                    if self._consume_domrand:
-                        self._domrand_draws(rng)
-                    side, a2, a3 = self._draw_script(rng, tier, pend['rec'][slot])
-                    pend['side'][slot], pend['after'][slot] = side, (a2, a3)
-                rng.set_state(pend['s0'])
-                self._pending[e] = pend
-            scripts[e] = pend['rec']
+            chain = self._extend_chain(e, R)
+            for k in range(R):
+                scripts[e, k] = chain[k]['rec']
+                self._script_sides[e, k] = chain[k]['side']
         return scripts
 
     def step_many(self, actions=None, n_actions=None, policy=None, auto_reset=True, want_obs=False, reset_tail=False,
-                  actions_device_ptr=None):
+                  actions_device_ptr=None, max_resets=None, time_budget_ms=0.0):
         """T consecutive `step(a_t, auto_reset=auto_reset)` calls for every env in ONE device launch
         (clothhip_run_actions): decoding, grab, the substep loop, metrics, the terminal test and the episode resets all
         run in the kernel, envs never wait for each other, and the host only does the reward / info bookkeeping below.
@@ -363,8 +376,15 @@ class ClothVecEnv(object):
         actions: float64[T, E, 4], or policy='oracle_corner' (examples/analytic.py's oracle, evaluated on the device)
         with n_actions=T. Resets inside the launch need init type tier1 or tier3 (tier 2 rebuilds per-env rest lengths
         on the host): with tier2, or auto_reset=False, an env whose episode ends idles for the rest of the launch
-        (`ran` False). An env can be reset at most twice per launch. An episode that ends in the last slot is reset by the
-        NEXT launch, or here on the host with reset_tail=True (then the returned obs is what T sequential steps return).
+        (`ran` False). Up to `max_resets` (default T) resets per env and launch; when tier 1's coverage-conditional third
+        reset pull runs, that env's later pre-drawn resets are void (the RNG stream forked) and it idles after its next
+        episode until the launch ends. An episode that ends in the last slot is reset by the NEXT launch, or here on the
+        host with reset_tail=True (then the returned obs is what T sequential steps return).
+
+        time_budget_ms > 0 turns the launch into a time slice: an env starts no further action once the launch has run that
+        long, so envs advance at their own pace instead of waiting for the one with the most work (episode resets make
+        the work per env very uneven). out['ran'][:, e] is then True for the first n_e slots only, and the caller passes
+        actions[n_e:, e] again in the next call. Results do not depend on how an env's actions are split into launches.
 
         Returns a dict of arrays [T, E] (rew, done, ran, executed, n_grabbed, reset_before, and the info keys of step())
         plus 'obs' [E, 3P] (state after the launch), 'actions' [T, E, 4] and, with want_obs, 'obs_t' [T, E, 3P]."""
@@ -385,15 +405,20 @@ class ClothVecEnv(object):
         if not self._delta_actions:
             raise NotImplementedError("non-delta actions are decoded on the host only (cos/sin, cloth_env.py:452-453)")
         dev_reset = auto_reset and self._init_type in ('tier1', 'tier3')
-        scripts = self._prepare_scripts() if dev_reset else None
+        scripts = self._prepare_scripts(T if max_resets is None else max_resets) if dev_reset else None
         parg = None
         if pol == _lib.POLICY_ORACLE_CORNER and self._init_type == 'tier2':
             parg = (~self.init_side).astype(np.int32)                                    # analytic.py:108-114
         nsteps = np.ascontiguousarray(self.num_steps, dtype=np.int32)
         done_io = np.ascontiguousarray(self._ep_done, dtype=np.uint8)
-        rec, rst, obs_t, robs = self.batch.run_actions(self._episode_params(), T, nsteps, done_io, actions=actions, policy=pol,
-                                                 policy_arg=parg, scripts=scripts, want_obs=want_obs,
-                                                 actions_device_ptr=actions_device_ptr)
+        self.batch.run_actions_begin(self._episode_params(), T, nsteps, done_io, actions=actions, policy=pol,
+                                     policy_arg=parg, scripts=scripts, want_obs=want_obs,
+                                     actions_device_ptr=actions_device_ptr, time_budget_ms=time_budget_ms)
+        if dev_reset:                                                 # while the kernel runs: draw ahead for the NEXT launch
+            R = scripts.shape[1]
+            for e in range(E):
+                self._extend_chain(e, 2 * R)
+        rec, rst, obs_t, robs = self.batch.run_actions_end()
         if (rec['ran'] == 2).any():
             raise FloatingPointError("iters_pull does not terminate (non-finite action?)")
         out = {k: np.zeros((T, E)) for k in ('rew', 'actual_coverage', 'start_coverage', 'variance_inv', 'start_variance_inv')}
@@ -406,23 +431,22 @@ class ClothVecEnv(object):
         for t in range(T):
             r = rec[t]
             rb = r['reset_before'].astype(np.int64)
-            for e in np.nonzero(rb)[0]:                               # ClothEnv.reset bookkeeping (cloth_env.py:717-790)
-                k = int(rb[e]) - 1
-                q = rst[e, k]
-                pend = self._pending[e]
-                slot = 0 if k == 0 else (2 if int(rst[e, 0]['pulls_run']) >= 3 else 1)
-                self.init_side[e] = pend['side'][slot]
-                n_consumed[e] = k + 1
-                sub = int(q['executed'].sum()) + int(q['settle_executed'])
-                out['reset_substeps'][t, e] = sub
-                self.total_substeps += sub
-                self.num_steps[e] = 0; self.num_sim_steps[e] = 0
-                self.have_tear[e] = bool(q['tear'])
-                self._prev_reward[e] = q['start_coverage']
-                self._start_coverage[e] = q['start_coverage']
-                self._start_variance_inv[e] = q['start_variance_inv']
-                self._current_coverage[e] = 0.0
-                self._ep_done[e] = False
+            ie = np.nonzero(rb)[0]                                    # ClothEnv.reset bookkeeping (cloth_env.py:717-790)
+            if len(ie):
+                k = rb[ie] - 1
+                q = rst[ie, k]
+                self.init_side[ie] = self._script_sides[ie, k]
+                n_consumed[ie] = k + 1
+                sub = q['executed'].sum(axis=1).astype(np.int64) + q['settle_executed']
+                out['reset_substeps'][t, ie] = sub
+                self.total_substeps += int(sub.sum())
+                self.num_steps[ie] = 0; self.num_sim_steps[ie] = 0
+                self.have_tear[ie] = q['tear'] != 0
+                self._prev_reward[ie] = q['start_coverage']
+                self._start_coverage[ie] = q['start_coverage']
+                self._start_variance_inv[ie] = q['start_variance_inv']
+                self._current_coverage[ie] = 0.0
+                self._ep_done[ie] = False
             ran = r['ran'] == 1
             executed = np.where(ran, r['executed'], 0).astype(np.int64)
             self.total_substeps += int(executed.sum())
@@ -448,18 +472,24 @@ class ClothVecEnv(object):
         assert np.array_equal(self.num_steps.astype(np.int32), nsteps) and np.array_equal(self._ep_done, done_io != 0)
         if dev_reset:                                                 # commit the RNG draws the device consumed
             for e in np.nonzero(n_consumed)[0]:
-                pend = self._pending[e]
-                slot = 0
-                for k in range(int(n_consumed[e])):
-                    pulls3 = int(rst[e, k]['pulls_run']) >= 3
-                    st = pend['after'][slot][1 if pulls3 else 0]
-                    if k == 0:
-                        slot = 2 if (pulls3 and self._init_type == 'tier1') else 1
+                chain, c = self._pending[e], int(n_consumed[e])
+                last = chain[c - 1]
+                n_uncond = int((last['rec']['pull']['need_coverage'][:int(last['rec']['n_pulls'])] == 0).sum())
+                forked = int(rst[e, c - 1]['pulls_run']) > n_uncond
                 rng = self.np_randoms[e]
-                rng.set_state(st)
-                if self._consume_domrand:
-                    self._domrand_draws(rng)
-                self._pending[e] = None
+                if forked:                                            # the conditional pull ran: later scripts are void
+                    rng.set_state(last['after'][1])
+                    if self._consume_domrand:
+                        self._domrand_draws(rng)
+                    self._pending[e] = None
+                elif c < len(chain):
+                    rng.set_state(chain[c]['before'])
+                    self._pending[e] = chain[c:]
+                else:
+                    rng.set_state(last['after'][0])
+                    if self._consume_domrand:
+                        self._domrand_draws(rng)
+                    self._pending[e] = None
         obs = self.state
         if reset_tail and auto_reset and self._ep_done.any():
             obs = self.reset(mask=self._ep_done.copy())
@@ -561,7 +591,7 @@ class ClothVecEnv(object):
             raise ValueError(self._init_type)                         # cloth.pyx:131-132
         if not self._delta_actions:
             raise NotImplementedError()                               # cloth_env.py:862, :917, :968
-        for e in idx:                                                 # scripts pre-drawn for step_many: give the draws back
+        for e in idx:                                                 # scripts pre-drawn for step_many: re-drawn below
             self._drop_pending(e)
         # ---- Cloth(...) construction: RNG draws in the reference's order (cloth.pyx:75, :101) --------------
         if tier == 2:

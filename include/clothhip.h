@@ -213,7 +213,7 @@ typedef struct ClothStepRecord {
     int32_t n_below_half_thickness;  /* compute_height numerator (cloth_env.py:603-609) */
     uint8_t ran;                     /* 0: slot not executed (episode over and no reset script left) */
     uint8_t oob, tear, done;
-    uint8_t reset_before;            /* 1: the env was reset right before this action; 2: the 2nd reset of this launch */
+    uint8_t reset_before;            /* k > 0: the env was reset right before this action, by its k-th script of this launch */
     uint8_t _pad[3];
 } ClothStepRecord;
 
@@ -231,19 +231,38 @@ typedef struct ClothResetRecord {
 
 /* T action slots for every env. policy: CLOTHHIP_POLICY_*. actions: [T][E][4] (TABLE), a HOST pointer unless
  * actions_on_device != 0 (a device table, e.g. after an RCCL broadcast). policy_arg[E] or NULL (ORACLE_CORNER: != 0 =
- * tier-2 cloth with init_side False, corner indices swapped, analytic.py:108-114). scripts: [E][3] or NULL -- slot 0 is
- * the env's next reset, slot 1 / slot 2 the one after it if slot 0 ran 2 / 3 pulls (the reference's RNG stream forks
- * there). num_steps[E], done[E]: in/out episode state (ClothEnv.num_steps; episode over). records: [T][E].
- * resets: [E][2] or NULL. obs: [T][E][3P] float32 '1d' observation after each executed slot, or NULL. reset_obs:
- * [E][2][3P] float32 first observation of each episode started inside the launch (what env.reset() returns), or NULL.
+ * tier-2 cloth with init_side False, corner indices swapped, analytic.py:108-114). scripts: [E][n_scripts] or NULL -- the
+ * env's next resets in order. Script k+1 is drawn (by the host) from the RNG state script k leaves when only its
+ * unconditional pulls run; if a conditional pull (tier 1's third, cloth_env.py:866) does run, it consumes further draws,
+ * the later scripts of that env are void, and the env idles once its next episode ends (the host re-draws them for the
+ * next launch). num_steps[E], done[E]: in/out episode state (ClothEnv.num_steps; episode over). records: [T][E].
+ * resets: [E][n_scripts] or NULL. obs: [T][E][3P] float32 '1d' observation after each executed slot, or NULL. reset_obs:
+ * [E][n_scripts][3P] float32 first observation of each episode started inside the launch (what env.reset() returns), or
+ * NULL.
+ * time_budget_ms > 0 makes the launch a TIME SLICE: an env starts no further action once the launch has run that long
+ * (constant-rate 100 MHz clock), so envs advance at their own pace and the launch does not wait for the env with the most
+ * work; the unused slots of an env stay `ran == 0` at the END of its column and the caller passes those actions again in
+ * the next launch. Which launch executes an action never changes its result (envs are independent); only the partition
+ * of an env's action sequence into launches depends on timing. 0 = every env executes all T slots.
  * Returns CLOTHHIP_ESTATE when the handle's variant cannot run fused (per-env rest tables with reset scripts,
  * non-25x25 oracle policy, grid too large for the in-kernel metrics). Synchronous. */
+/* The same in two halves, so that the caller can work (e.g. draw the next reset scripts) while the launch runs:
+ * _begin uploads the inputs and launches (the host input arrays are not retained), _end waits and downloads. The want_*
+ * flags of _begin announce which of the optional output buffers _end will be given. One launch in flight per handle. */
+int clothhip_run_actions_begin(clothhip_handle *h, const ClothEpisodeParams *ep, int32_t T, int32_t policy,
+                               const double *actions, int32_t actions_on_device, const int32_t *policy_arg,
+                               const ClothResetScript *scripts, int32_t n_scripts, const int32_t *num_steps,
+                               const uint8_t *done, int32_t want_resets, int32_t want_obs, int32_t want_reset_obs,
+                               double time_budget_ms);
+int clothhip_run_actions_end(clothhip_handle *h, int32_t *num_steps, uint8_t *done, ClothStepRecord *records,
+                             ClothResetRecord *resets, float *obs, float *reset_obs);
 /* 1 if this handle's kernel variant has the LDS room for the in-kernel metrics of clothhip_run_actions, else 0 */
 int clothhip_fused_supported(const clothhip_handle *h);
 int clothhip_run_actions(clothhip_handle *h, const ClothEpisodeParams *ep, int32_t T, int32_t policy,
                          const double *actions, int32_t actions_on_device, const int32_t *policy_arg,
-                         const ClothResetScript *scripts, int32_t *num_steps, uint8_t *done,
-                         ClothStepRecord *records, ClothResetRecord *resets, float *obs, float *reset_obs);
+                         const ClothResetScript *scripts, int32_t n_scripts, int32_t *num_steps, uint8_t *done,
+                         ClothStepRecord *records, ClothResetRecord *resets, float *obs, float *reset_obs,
+                         double time_budget_ms);
 
 /* Convenience: n x Cloth.update() on every env (cloth_env.py:902-903, :948-949, :980-981), optionally
  * preceded each time by Gripper.adjust(delta) when delta != NULL ([3] doubles, same for all envs). */

@@ -210,21 +210,30 @@ def test_shipped_yaml_schema_matches_reference_keys():
 
 
 def test_step_many_script_drawing_is_rng_neutral():
-    """The reset scripts step_many pre-draws leave every env RNG where it was, and the draws of slot 0 are exactly the ones
-    the host reset makes (cloth.pyx:75; cloth_env.py:851-877)."""
+    """The reset scripts step_many pre-draws leave every env RNG where it was; script 0 holds exactly the draws the host
+    reset makes (cloth.pyx:75; cloth_env.py:851-877), script 1 continues from the state after TWO pulls, and cached scripts
+    are reused by the next call."""
     from gym_cloth_amd.envs import ClothVecEnv
     v = ClothVecEnv.__new__(ClothVecEnv)                     # host-only pieces: no device needed
     v.E, v.P, v._init_type, v._consume_domrand, v.iters_up = 3, 625, "tier1", False, 50
     v.np_randoms = [np.random.RandomState(40 + e) for e in range(3)]
     v._pending = [None] * 3
     before = [r.get_state()[1].copy() for r in v.np_randoms]
-    sc = v._prepare_scripts()
+    sc = v._prepare_scripts(3)
+    assert sc.shape == (3, 3) and sc["valid"].all()
     assert all(np.array_equal(b, r.get_state()[1]) for b, r in zip(before, v.np_randoms))
     ref = np.random.RandomState(40)
-    ref.rand()                                               # init_side
-    for k in range(3):
-        assert sc[0, 0]["pull"][k]["point"] == ref.randint(625)
-        assert sc[0, 0]["pull"][k]["dx"] == ClothVecEnv._randval_minabs(ref, -0.2, 0.2, 0.08)
-        assert sc[0, 0]["pull"][k]["dy"] == ClothVecEnv._randval_minabs(ref, -0.2, 0.2, 0.08)
-    assert sc[0, 0]["n_pulls"] == 3 and sc[0, 0]["pull"][2]["need_coverage"] == 1 and sc[0, 1]["valid"] and sc[0, 2]["valid"]
-    assert sc[0, 1]["pull"][0]["point"] != sc[0, 2]["pull"][0]["point"] or sc[0, 1]["pull"][0]["dx"] != sc[0, 2]["pull"][0]["dx"]
+    for s in range(2):
+        ref.rand()                                           # init_side
+        st2 = None
+        for k in range(3):
+            if k == 2:
+                st2 = ref.get_state()
+            assert sc[0, s]["pull"][k]["point"] == ref.randint(625)
+            assert sc[0, s]["pull"][k]["dx"] == ClothVecEnv._randval_minabs(ref, -0.2, 0.2, 0.08)
+            assert sc[0, s]["pull"][k]["dy"] == ClothVecEnv._randval_minabs(ref, -0.2, 0.2, 0.08)
+        assert sc[0, s]["n_pulls"] == 3 and sc[0, s]["pull"][2]["need_coverage"] == 1
+        ref.set_state(st2)                                   # the next script assumes the third pull did not happen
+    sc2 = v._prepare_scripts(4)                              # longer chain: the first three are the cached ones
+    assert np.array_equal(sc2[:, :3], sc) and sc2["valid"].all()
+    assert all(np.array_equal(b, r.get_state()[1]) for b, r in zip(before, v.np_randoms))
