@@ -205,11 +205,12 @@ def run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, rank
             if rank == 0:
                 cnt += res[:, 0].astype(np.int64)
             if w >= n_warm:
-                a_sub, r_sub = int(out["executed"].sum()), int(out["reset_substeps"].sum())
+                a_sub = int(out["executed"].sum())
+                r_sub = int(out["reset_substeps"].sum()) + int(out.get("tail_reset_substeps", np.zeros(1)).sum())
                 stat["sub"] += a_sub + r_sub; stat["act_sub"] += a_sub
                 stat["kms"] += env.batch.last_kernel_ms; stat["launches"] += 1
                 stat["ran"] += int(n_ran.sum()); stat["grabbed"] += int((out["n_grabbed"] > 0).sum()); stat["slots"] += slots * E
-                stat["resets"] += int((out["reset_before"] > 0).sum())
+                stat["resets"] += int((out["reset_before"] > 0).sum()) + int((out.get("tail_reset_substeps", np.zeros(1)) > 0).sum())
                 stat["out_of_slots"] += int((n_ran == slots).sum())
         fence()
         t_timed = time.perf_counter() - t0
@@ -246,6 +247,8 @@ def run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, rank
         if want_cpu and cpu_states is not None:
             rec["cpu_baseline"] = cpu_baseline(cfg, (cpu_acts if cpu_acts is not None else acts_all[warmup])[:len(cpu_states[0])],
                                                cpu_states)
+    if rank == 0 and os.environ.get("CLOTH_BENCH_HOST_PROFILE") and getattr(env, "host_prof", None):
+        print("bench: host time in step_many [s]: %s" % {k: round(v, 3) for k, v in env.host_prof.items()}, file=sys.stderr)
     xch.barrier()
     xch.t.close()
     env.close()

@@ -55,6 +55,7 @@ class ClothEpisodeParams(C.Structure):
 
 
 POLICY_TABLE, POLICY_ORACLE_CORNER = 0, 1
+MT_WORDS = 626                      # per-env RandomState image: key[624], pos, pad (csrc/cloth_rng.hpp)
 
 RESET_PULL_DTYPE = np.dtype([("point", "<i4"), ("need_coverage", "<i4"), ("x", "<f8"), ("y", "<f8"), ("dx", "<f8"),
                              ("dy", "<f8"), ("iters_up", "<f8"), ("coverage_min", "<f8")])
@@ -65,7 +66,7 @@ STEP_RECORD_DTYPE = np.dtype([("action", "<f8", (4,)), ("coverage", "<f8"), ("va
                               ("n_below_half_thickness", "<i4"), ("ran", "u1"), ("oob", "u1"), ("tear", "u1"),
                               ("done", "u1"), ("reset_before", "u1"), ("_pad", "u1", (3,))])
 RESET_RECORD_DTYPE = np.dtype([("consumed", "<i4"), ("pulls_run", "<i4"), ("executed", "<i4", (3,)),
-                               ("settle_executed", "<i4"), ("tear", "<i4"), ("_pad", "<i4"),
+                               ("settle_executed", "<i4"), ("tear", "<i4"), ("init_side", "<i4"),
                                ("start_coverage", "<f8"), ("start_variance_inv", "<f8"), ("action", "<f8", (3, 4))])
 assert RESET_PULL_DTYPE.itemsize == 56 and RESET_SCRIPT_DTYPE.itemsize == 184
 assert STEP_RECORD_DTYPE.itemsize == 72 and RESET_RECORD_DTYPE.itemsize == 144
@@ -101,8 +102,9 @@ SYMBOLS = [
     ("clothhip_sync", C.c_int, [_vp, _i32p]),
     ("clothhip_fused_supported", C.c_int, [_vp]),
     ("clothhip_run_actions_begin", C.c_int, [_vp, C.POINTER(ClothEpisodeParams), C.c_int32, C.c_int32, _vp, C.c_int32, _i32p,
-                                             _vp, C.c_int32, _i32p, _u8p, C.c_int32, C.c_int32, C.c_int32, C.c_double]),
-    ("clothhip_run_actions_end", C.c_int, [_vp, _i32p, _u8p, _vp, _vp, _vp, _vp]),
+                                             _vp, C.c_int32, _i32p, _u8p, _vp, C.c_int32, C.c_uint64, C.c_int32, C.c_int32,
+                                             C.c_int32, C.c_double]),
+    ("clothhip_run_actions_end", C.c_int, [_vp, _i32p, _u8p, _vp, _vp, _vp, _vp, _vp]),
     ("clothhip_run_actions", C.c_int, [_vp, C.POINTER(ClothEpisodeParams), C.c_int32, C.c_int32, _vp, C.c_int32, _i32p, _vp,
                                        C.c_int32, _i32p, _u8p, _vp, _vp, _vp, _vp, C.c_double]),
     ("clothhip_update", C.c_int, [_vp, C.c_int32, _dp]),
@@ -118,6 +120,7 @@ SYMBOLS = [
     ("clothhip_stream", _vp, [_vp]),
     ("clothhip_last_kernel_ms", C.c_double, [_vp]),
     ("clothhip_debug_stats", C.c_int, [_vp, _i32p]),
+    ("clothhip_selftest_rng", C.c_int, [_vp, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, _dp]),
     ("clothhip_selftest_arith", C.c_int, [C.c_int32, C.c_int32, _dp, _dp, _dp, C.c_int64]),
 ]
 

@@ -198,7 +198,8 @@ class ClothBatch(object):
         return bool(check(self._L.clothhip_fused_supported(self._h)))
 
     def run_actions_begin(self, ep, n_actions, num_steps, done, actions=None, policy=None, policy_arg=None, scripts=None,
-                          want_resets=True, want_obs=False, actions_device_ptr=None, time_budget_ms=0.0):
+                          want_resets=True, want_obs=False, actions_device_ptr=None, time_budget_ms=0.0,
+                          rng_states=None, rng_tier=0, domrand_words=0, reset_capacity=0):
         """First half of clothhip_run_actions (see include/clothhip.h): upload + launch, returns while the kernel runs.
         ep: _lib.ClothEpisodeParams; scripts: RESET_SCRIPT_DTYPE[E, R], each env's next R resets in order."""
         T = int(n_actions)
@@ -220,20 +221,26 @@ class ClothBatch(object):
             scripts = np.ascontiguousarray(scripts, dtype=_lib.RESET_SCRIPT_DTYPE)
             if scripts.ndim != 2 or scripts.shape[0] != self.E:
                 raise ValueError("scripts must have shape (%d, R)" % self.E)
-        R = 0 if scripts is None else scripts.shape[1]
-        have_rst = bool(want_resets and scripts is not None)
-        have_robs = bool(want_obs and scripts is not None)
+        if rng_states is not None:                       # resets drawn on the device from the envs' numpy streams
+            assert scripts is None and rng_states.dtype == np.uint32 and rng_states.shape == (self.E, _lib.MT_WORDS)
+            assert rng_states.flags['C_CONTIGUOUS']
+        have_src = scripts is not None or rng_states is not None
+        R = scripts.shape[1] if scripts is not None else (int(reset_capacity) if rng_states is not None else 0)
+        have_rst = bool(want_resets and have_src)
+        have_robs = bool(want_obs and have_src)
         vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
         check(self._L.clothhip_run_actions_begin(self._h, C.byref(ep), T, pol, ap, on_dev, _lib.i32p(parg), vp(scripts), R,
-                                                 _lib.i32p(num_steps), _lib.u8p(done), int(have_rst), int(bool(want_obs)),
-                                                 int(have_robs), float(time_budget_ms)))
-        self._fused = (T, R, num_steps, done, have_rst, bool(want_obs), have_robs)
+                                                 _lib.i32p(num_steps), _lib.u8p(done), vp(rng_states), int(rng_tier),
+                                                 int(domrand_words), int(have_rst), int(bool(want_obs)), int(have_robs),
+                                                 float(time_budget_ms)))
+        self._fused = (T, R, num_steps, done, have_rst, bool(want_obs), have_robs, rng_states)
 
     def run_actions_end(self):
         """Second half: wait for the launch and fetch its outputs. num_steps / done given to _begin are updated in place.
+        rng_states given to _begin (uint32[E, 626]) now hold the advanced streams.
         Returns (records[T, E], resets[E, R] or None, obs float32[T, E, 3P] or None, reset_obs float32[E, R, 3P] or None:
         the first observation of every episode started inside the launch)."""
-        T, R, num_steps, done, have_rst, have_obs, have_robs = self._fused
+        T, R, num_steps, done, have_rst, have_obs, have_robs, rng_states = self._fused
         self._fused = None
         rec = np.zeros((T, self.E), dtype=_lib.STEP_RECORD_DTYPE)
         rst = np.zeros((self.E, R), dtype=_lib.RESET_RECORD_DTYPE) if have_rst else None
@@ -241,7 +248,7 @@ class ClothBatch(object):
         robs = np.empty((self.E, R, 3 * self.P), dtype=np.float32) if have_robs else None
         vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
         check(self._L.clothhip_run_actions_end(self._h, _lib.i32p(num_steps), _lib.u8p(done), vp(rec), vp(rst), vp(obs),
-                                               vp(robs)))
+                                               vp(robs), vp(rng_states)))
         return rec, rst, obs, robs
 
     def run_actions(self, *a, **k):

@@ -25,6 +25,7 @@
 #include <stdint.h>
 
 #include "../../include/clothhip.h"
+#include "cloth_rng.hpp"
 #include "cloth_tables.hpp"
 
 namespace clothhip {
@@ -59,6 +60,9 @@ template <typename T> struct FusedArgs {
     const double *levels;             // Gripper.grab_top curZ table
     int32_t n_glevels, E;
     int32_t n_scripts, _pad;
+    uint32_t *mt;                     // [E][MT_WORDS] numpy RandomState of every env, or nullptr (resets come from `scripts`)
+    uint64_t domrand_words;           // 32-bit words the domain-randomisation draws after a reset consume (cloth_env.py:786-789), or 0
+    int32_t rng_tier, _pad2;          // with mt: 1 or 3, the reset procedure to draw (cloth_env.py:843-891, :951-982)
     uint64_t budget_ticks;            // 0 = none; else no new action / reset starts once the launch has run this many 100 MHz ticks
     double two_thickness, half_thickness;
     ClothEpisodeParams ep;
@@ -77,7 +81,9 @@ struct EpState {
     int32_t op, n_grab, iters_pull, decode_err;
     int32_t done_total;
     int32_t stop;          // the launch's time slice is used up: no new action or reset starts
+    int32_t side, _pad;    // device-RNG resets: Cloth.init_side of the reset in progress (cloth.pyx:75)
     double act[4];
+    ClothResetPull pull;   // device-RNG resets: the draws of the pull being executed
 };
 
 template <typename T> struct StepArgs {
@@ -200,7 +206,7 @@ struct LdsLayout {
         int o = 0;
         auto take = [&](int bytes) { int r = o; o += (bytes + 15) / 16 * 16; return r; };
         cur = take(4 * Ppad * tsz);
-        eps = take(96);              // EpState (fused episodes)
+        eps = take(160);             // EpState (fused episodes)
         ent = take(tab >= 1 ? Spad * 4 : 0);
         rest = take(tab >= 1 ? Spad * tsz : 0);
         off = take(tab >= 1 ? (nL + 40) * 2 : 0);       // padded: levels past the end are empty
@@ -432,6 +438,38 @@ __device__ __forceinline__ void collide_cell_serial(Pt<T> *cur, uint16_t *m, int
                            I.z + dev_div<T>(dev_div<T>(tz, nf), k.sim_steps), I.w};
         }
     }
+}
+
+// Advance env's MT19937 stream (global memory, numpy layout) by n words with the whole workgroup: the twist of the 624-word
+// state is done in its three dependency phases, one word per thread (mt19937_gen's sequential in-place semantics: phase A
+// reads old words only, phases B / C read the new words of the previous phase). All threads must call it.
+template <int NT>
+__device__ __forceinline__ void mt_skip_block(uint32_t *mt, uint64_t n, int tid) {
+    static_assert(NT >= 256, "one word per thread and phase");
+    __syncthreads();
+    uint32_t pos = mt[MT_N];
+    while (n > 0) {
+        if (pos >= (uint32_t)MT_N) {
+            const int lo[3] = {0, MT_N - MT_M, 2 * (MT_N - MT_M)}, hi[3] = {MT_N - MT_M, 2 * (MT_N - MT_M), MT_N - 1};
+            for (int ph = 0; ph < 3; ph++) {
+                const int i = lo[ph] + tid;
+                uint32_t v = 0;
+                const bool on = i < hi[ph];
+                if (on) v = mt_twist_word(mt[i], mt[i + 1], ph == 0 ? mt[i + MT_M] : mt[i + (MT_M - MT_N)]);
+                __syncthreads();
+                if (on) mt[i] = v;
+                __syncthreads();
+            }
+            if (tid == 0) mt[MT_N - 1] = mt_twist_word(mt[MT_N - 1], mt[0], mt[MT_M - 1]);
+            __syncthreads();
+            pos = 0;
+        }
+        const uint64_t take = n < (uint64_t)(MT_N - pos) ? n : (uint64_t)(MT_N - pos);
+        pos += (uint32_t)take;
+        n -= take;
+    }
+    if (tid == 0) mt[MT_N] = pos;
+    __syncthreads();
 }
 
 // ---- per-env metrics (cloth_env.py:1020-1098): coverage = area of the convex hull of the clipped (x,y) (same
@@ -694,6 +732,14 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
             // rp >= 0: the script of the reset in progress; else the env's next one, valid only while the chain is intact
             const bool have_scr = F.scripts != nullptr && n_resets < F.n_scripts && (rp >= 0 || eps->chain_ok);
             const ClothResetScript *scr = have_scr ? F.scripts + ((size_t)e * F.n_scripts + n_resets) : nullptr;
+            // device-RNG resets (F.mt): the script is not read from a table but drawn from the env's numpy stream as the reset
+            // proceeds, in the reference's order; its shape depends on the tier only
+            uint32_t *const mt = F.mt ? F.mt + (size_t)e * MT_WORDS : nullptr;
+            const bool rngm = mt != nullptr;
+            const int tier = F.rng_tier;
+            auto s_n_pulls = [&]() { return rngm ? (tier == 1 ? 3 : 1) : scr->n_pulls; };
+            auto s_settle = [&]() { return rngm ? (tier == 3 ? 800 : 0) : scr->settle_after; };
+            auto s_need_cov = [&](int p_) { return rngm ? (tier == 1 && p_ == 2) : (scr->pull[p_].need_coverage != 0); };
             int op = OP_ACTION;
             bool do_decode = false;
             double act[4] = {0.0, 0.0, 0.0, 0.0};
@@ -702,12 +748,13 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
             if (rp < 0) {
                 if (t_slot >= F.nT) break;
                 // time slice: envs advance at their own pace, so a launch ends when its time budget is used up rather than when
-                // the slowest env has finished a fixed number of actions. Decided by thread 0 between actions (a reset is always
-                // followed by its first action in the same launch). Which launch executes an action never changes its result.
-                if (eps->stop && eps->reset_mark == 0) break;
+                // the slowest env has finished a fixed number of actions. Decided by thread 0 between operations (also between a
+                // reset and the first action of the new episode: the reset record tells the host). Which launch executes an
+                // action never changes its result.
+                if (eps->stop) break;
                 if (eps->ep_done) {
                     __syncthreads();                     // everyone has read the state
-                    if (scr != nullptr && scr->valid) {
+                    if (rngm ? (n_resets < F.n_scripts) : (scr != nullptr && scr->valid)) {
                         // the Cloth(...) rebuild of ClothEnv.reset (cloth_env.py:737-746): flat grid, nothing pinned, no tear
                         for (int i = tid; i < Ppad; i += NT)
                             cur[i] = Pt<T>{F.flat[i], F.flat[Ppad + i], F.flat[2 * Ppad + i], w_make<T>(0u)};
@@ -719,8 +766,12 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                         if (tid == 0) {
                             misc[0] = 0;
                             eps->rp = 0; eps->rs_pulls = 0; eps->ep_steps = 0; eps->ep_done = 0;
+                            int side_ = 0;
+                            if (rngm) side_ = mt_double(mt) > 0.5 ? 1 : 0;                       // cloth.pyx:75
+                            eps->side = side_;
                             if (F.resets) {
                                 ClothResetRecord *rr_ = F.resets + ((size_t)e * F.n_scripts + n_resets);
+                                rr_->init_side = side_;
                                 rr_->consumed = 1; rr_->pulls_run = 0; rr_->executed[0] = rr_->executed[1] = rr_->executed[2] = 0;
                                 rr_->settle_executed = 0; rr_->tear = 0;
                             }
@@ -763,16 +814,38 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                 for (;;) {                               // skip the stages this script does not have
                     if (rp < 6) {
                         const int p_ = rp >> 1;
-                        if (p_ >= scr->n_pulls) { rp = 6; continue; }
-                        if (!(rp & 1) && !scr->pull[p_].need_coverage) { rp++; continue; }
+                        if (p_ >= s_n_pulls()) { rp = 6; continue; }
+                        if (!(rp & 1) && !s_need_cov(p_)) { rp++; continue; }
                     }
-                    if (rp == 6 && scr->settle_after <= 0) { rp = 7; continue; }
+                    if (rp == 6 && s_settle() <= 0) { rp = 7; continue; }
                     break;
                 }
                 if (rp < 6 && !(rp & 1)) op = OP_RESET_COND;
                 else if (rp < 6) {
                     op = OP_RESET_PULL; do_decode = true;
-                    const ClothResetPull *pl = &scr->pull[rp >> 1];
+                    if (rngm) {                          // draw this pull now (cloth_env.py:851-877 tier 1, :959-972 tier 3)
+                        if (tid == 0) {
+                            ClothResetPull d_;
+                            d_.need_coverage = 0; d_.coverage_min = 0.0;
+                            if (tier == 1) {
+                                d_.point = (int32_t)mt_randint(mt, (uint32_t)P);
+                                d_.x = d_.y = 0.0;
+                                d_.dx = mt_randval_minabs(mt, -0.20, 0.20, 0.08);
+                                d_.dy = mt_randval_minabs(mt, -0.20, 0.20, 0.08);
+                                d_.iters_up = F.ep.iters_up;
+                            } else {
+                                d_.iters_up = mt_uniform(mt, 200.0, 280.0);
+                                d_.point = -1;
+                                d_.x = mt_randval_minabs(mt, 0.30, 0.70, 0.0);
+                                d_.y = mt_randval_minabs(mt, 0.30, 0.70, 0.0);
+                                d_.dx = mt_randval_minabs(mt, -0.25, 0.25, 0.10);
+                                d_.dy = mt_randval_minabs(mt, -0.25, 0.25, 0.10);
+                            }
+                            eps->pull = d_;
+                        }
+                        __syncthreads();
+                    }
+                    const ClothResetPull *pl = rngm ? &eps->pull : &scr->pull[rp >> 1];
                     double px_ = pl->x, py_ = pl->y;
                     const int pt_ = pl->point;
                     if (pt_ >= 0) { const Pt<T> pp = cur[pt_ < P ? pt_ : 0]; px_ = (double)pp.x; py_ = (double)pp.y; }
@@ -788,7 +861,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                 } else if (rp == 6) {
                     op = OP_RESET_SETTLE; do_run = true;
                     sc.n_up_end = sc.n_uprest_end = sc.n_pull_end = 0;
-                    sc.n_griprest_end = sc.n_total = scr->settle_after;
+                    sc.n_griprest_end = sc.n_total = s_settle();
                     sc.break_on_tear = 0;
                 } else {
                     op = OP_RESET_END;
@@ -1502,6 +1575,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                 for (int i = lane; i < (A.Spad / 64 + 2) * 2; i += 64) reinterpret_cast<uint32_t *>(smem + lay.abits)[i] = 0u;
             }
             __syncthreads();
+            TSTAMP(9)
         }
         if (timing) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory"); }
         done++;
@@ -1548,10 +1622,12 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                     r_->reset_before = (uint8_t)eps->reset_mark;
                     eps->reset_mark = 0; eps->ep_steps = ep_steps; eps->ep_done = dn ? 1 : 0; eps->t_slot = t_slot + 1;
                 } else {
-                    const ClothResetScript *scr = F.scripts + ((size_t)e * F.n_scripts + n_resets);
+                    const bool rngm = F.mt != nullptr;
+                    const ClothResetScript *scr = rngm ? nullptr : F.scripts + ((size_t)e * F.n_scripts + n_resets);
                     ClothResetRecord *rr_ = F.resets ? F.resets + ((size_t)e * F.n_scripts + n_resets) : nullptr;
                     if (op == OP_RESET_COND) {
-                        eps->rp = mo[0] >= scr->pull[rp >> 1].coverage_min ? rp + 1 : 6;        // cloth_env.py:866
+                        const double cmin = rngm ? 0.90 : scr->pull[rp >> 1].coverage_min;
+                        eps->rp = mo[0] >= cmin ? rp + 1 : 6;                                     // cloth_env.py:866
                     } else if (op == OP_RESET_PULL) {
                         const int p_ = rp >> 1;
                         if (rr_) {
@@ -1566,7 +1642,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                     } else {                                                                      // OP_RESET_END
                         if (rr_) { rr_->start_coverage = mo[0]; rr_->start_variance_inv = mo[1]; rr_->tear = tear_now; }
                         // a conditional pull that ran consumed RNG draws the later scripts were drawn without (clothhip.h)
-                        {
+                        if (!rngm) {
                             int n_uncond = 0;
                             for (int p_ = 0; p_ < scr->n_pulls; p_++) n_uncond += scr->pull[p_].need_coverage ? 0 : 1;
                             if (eps->rs_pulls > n_uncond) eps->chain_ok = 0;
@@ -1576,6 +1652,8 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                 }
             }
             __syncthreads();
+            if (op == OP_RESET_END && F.mt != nullptr && F.domrand_words != 0)                    // cloth_env.py:786-789
+                mt_skip_block<NT>(F.mt + (size_t)e * MT_WORDS, F.domrand_words, tid);
         }
     }
     const int done = fused ? eps->done_total : done_nf;

@@ -65,8 +65,9 @@ struct clothhip_handle {
     // clothhip_run_actions staging (device), grown on demand
     void *d_fz = nullptr, *d_fact = nullptr, *d_fscr = nullptr, *d_frec = nullptr, *d_frst = nullptr, *d_fobs = nullptr, *d_frobs = nullptr;
     int32_t *d_fsteps = nullptr, *d_fparg = nullptr;
+    uint32_t *d_fmt = nullptr;      // [E][MT_WORDS] numpy RandomState of every env (device-drawn resets)
     uint8_t *d_fdone = nullptr;
-    int f_T = 0; size_t f_nscr = 0; bool f_pending = false, f_resets = false, f_obs = false, f_robs = false;
+    int f_T = 0; size_t f_nscr = 0; bool f_pending = false, f_resets = false, f_obs = false, f_robs = false, f_mt = false;
     size_t cap_fact = 0, cap_frec = 0, cap_fobs = 0, cap_fscr = 0, cap_frst = 0, cap_frobs = 0;
     Topology topo;
     LevelSchedule lv;
@@ -162,7 +163,7 @@ static void free_handle(clothhip_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_pos, h->d_prev, h->d_rest, h->d_cnt, h->d_active, h->d_tear, h->d_exec, h->d_ngrab, h->d_stats,
-                    h->d_sched, h->d_flat, h->d_flat_rest, h->d_hcnt, h->d_fz, h->d_fact, h->d_fscr, h->d_frec, h->d_frst, h->d_fobs, h->d_frobs, h->d_fsteps, h->d_fparg, h->d_fdone, h->d_gather, h->d_lv_ent, h->d_lv_off, h->d_lv_off8, h->d_pt_lev, h->d_levels, h->d_xy, h->d_radius, h->d_cov, h->d_vinv, h->d_oob};
+                    h->d_sched, h->d_flat, h->d_flat_rest, h->d_hcnt, h->d_fz, h->d_fact, h->d_fscr, h->d_frec, h->d_frst, h->d_fobs, h->d_frobs, h->d_fsteps, h->d_fparg, h->d_fdone, h->d_fmt, h->d_gather, h->d_lv_ent, h->d_lv_off, h->d_lv_off8, h->d_pt_lev, h->d_levels, h->d_xy, h->d_radius, h->d_cov, h->d_vinv, h->d_oob};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->h_sched) (void)hipHostFree(h->h_sched);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -633,7 +634,8 @@ extern "C" int clothhip_run(clothhip_handle *h, const ClothSchedule *sched, int3
 // ---- whole episodes on the device ---------------------------------------------------------------------------------
 template <typename T> static void fill_fused(clothhip_handle *h, FusedArgs<T> &f, const ClothEpisodeParams *ep, int T_, int policy,
                                              const double *d_actions, bool have_parg, bool have_scripts, bool have_resets, bool have_obs,
-                                             bool have_robs, int n_scripts, uint64_t budget_ticks, int NS, int NH) {
+                                             bool have_robs, int n_scripts, uint64_t budget_ticks, bool have_mt, int rng_tier,
+                                             uint64_t domrand_words, int NS, int NH) {
     memset(&f, 0, sizeof(f));
     f.nT = T_; f.policy = policy; f.NS = NS; f.NH = NH;
     f.actions = d_actions;
@@ -646,6 +648,7 @@ template <typename T> static void fill_fused(clothhip_handle *h, FusedArgs<T> &f
     f.reset_obs = have_robs ? (float *)h->d_frobs : nullptr;
     f.flat = (const T *)h->d_flat;
     f.levels = h->d_levels; f.n_glevels = h->n_grab_levels; f.E = h->E; f.n_scripts = n_scripts; f.budget_ticks = budget_ticks;
+    f.mt = have_mt ? h->d_fmt : nullptr; f.rng_tier = rng_tier; f.domrand_words = domrand_words;
     f.two_thickness = 2 * h->prm.thickness; f.half_thickness = h->prm.thickness / 2.0;
     f.ep = *ep;
 }
@@ -676,7 +679,8 @@ extern "C" int clothhip_fused_supported(const clothhip_handle *h) {
 extern "C" int clothhip_run_actions_begin(clothhip_handle *h, const ClothEpisodeParams *ep, int32_t T_, int32_t policy,
                                           const double *actions, int32_t actions_on_device, const int32_t *policy_arg,
                                           const ClothResetScript *scripts, int32_t n_scripts, const int32_t *num_steps,
-                                          const uint8_t *done, int32_t want_resets, int32_t want_obs, int32_t want_reset_obs,
+                                          const uint8_t *done, const uint32_t *rng_states, int32_t rng_tier, uint64_t domrand_words,
+                                          int32_t want_resets, int32_t want_obs, int32_t want_reset_obs,
                                           double time_budget_ms) {
     if (!h || !ep || !num_steps || !done) return fail(CLOTHHIP_EINVAL, "NULL argument");
     if (h->f_pending) return fail(CLOTHHIP_ESTATE, "a clothhip_run_actions_begin is already in flight");
@@ -686,9 +690,11 @@ extern "C" int clothhip_run_actions_begin(clothhip_handle *h, const ClothEpisode
     if (policy == CLOTHHIP_POLICY_TABLE && !actions) return fail(CLOTHHIP_EINVAL, "the table policy needs actions[T][E][4]");
     if (policy == CLOTHHIP_POLICY_ORACLE_CORNER && h->N != 25)
         return fail(CLOTHHIP_ESTATE, "the oracle-corner policy is defined for 25x25 cloths only (analytic.py:106)");
-    if (scripts && (n_scripts < 1 || n_scripts > 64)) return fail(CLOTHHIP_EINVAL, "n_scripts must be in [1, 64]");
-    if (!scripts) n_scripts = 0;
-    if (scripts && h->rest_stride != 0)
+    if ((scripts || rng_states) && (n_scripts < 1 || n_scripts > 255)) return fail(CLOTHHIP_EINVAL, "n_scripts must be in [1, 255]");
+    if (scripts && rng_states) return fail(CLOTHHIP_EINVAL, "resets come either from scripts or from the device-side RNG streams, not both");
+    if (rng_states && rng_tier != 1 && rng_tier != 3) return fail(CLOTHHIP_EINVAL, "device-drawn resets exist for tiers 1 and 3");
+    if (!scripts && !rng_states) n_scripts = 0;
+    if ((scripts || rng_states) && h->rest_stride != 0)
         return fail(CLOTHHIP_ESTATE, "in-kernel resets need the shared flat rest table (tiers 1 and 3); this handle has per-env rest lengths");
     if (!(ep->reduce_factor > 0) || ep->max_actions < 1) return fail(CLOTHHIP_EINVAL, "bad episode parameters");
     int NS = 1; while (NS < h->P) NS <<= 1;
@@ -720,10 +726,14 @@ extern "C" int clothhip_run_actions_begin(clothhip_handle *h, const ClothEpisode
         }
     }
     if (obs) if (int rc = grow(&h->d_fobs, &h->cap_fobs, nrec * 3 * h->P * 4)) return rc;
-    if (reset_obs && !scripts) return fail(CLOTHHIP_EINVAL, "reset_obs without scripts");
+    if ((reset_obs || resets) && !scripts && !rng_states) return fail(CLOTHHIP_EINVAL, "reset outputs without a reset source");
     if (reset_obs) {
         if (int rc = grow(&h->d_frobs, &h->cap_frobs, nscr * 3 * h->P * 4)) return rc;
         HIPCHECK(hipMemsetAsync(h->d_frobs, 0, nscr * 3 * h->P * 4, h->stream));
+    }
+    if (rng_states) {
+        if (!h->d_fmt) HIPCHECK(hipMalloc(&h->d_fmt, E * MT_WORDS * 4));
+        HIPCHECK(hipMemcpyAsync(h->d_fmt, rng_states, E * MT_WORDS * 4, hipMemcpyHostToDevice, h->stream));
     }
     if (policy_arg) HIPCHECK(hipMemcpyAsync(h->d_fparg, policy_arg, E * 4, hipMemcpyHostToDevice, h->stream));
     if (scripts) HIPCHECK(hipMemcpyAsync(h->d_fscr, scripts, nscr * sizeof(ClothResetScript), hipMemcpyHostToDevice, h->stream));
@@ -735,9 +745,11 @@ extern "C" int clothhip_run_actions_begin(clothhip_handle *h, const ClothEpisode
     static_assert(sizeof(FusedArgs<double>) <= 1024 && sizeof(FusedArgs<float>) <= 1024, "fused argument block");
     unsigned char fzbuf[1024];
     if (h->precision == CLOTHHIP_F64)
-        fill_fused<double>(h, *reinterpret_cast<FusedArgs<double> *>(fzbuf), ep, T_, policy, d_actions, policy_arg != nullptr, scripts != nullptr, resets, obs, reset_obs, n_scripts, budget_ticks, NS, NH);
+        fill_fused<double>(h, *reinterpret_cast<FusedArgs<double> *>(fzbuf), ep, T_, policy, d_actions, policy_arg != nullptr, scripts != nullptr, resets, obs, reset_obs, n_scripts, budget_ticks,
+                           rng_states != nullptr, rng_tier, domrand_words, NS, NH);
     else
-        fill_fused<float>(h, *reinterpret_cast<FusedArgs<float> *>(fzbuf), ep, T_, policy, d_actions, policy_arg != nullptr, scripts != nullptr, resets, obs, reset_obs, n_scripts, budget_ticks, NS, NH);
+        fill_fused<float>(h, *reinterpret_cast<FusedArgs<float> *>(fzbuf), ep, T_, policy, d_actions, policy_arg != nullptr, scripts != nullptr, resets, obs, reset_obs, n_scripts, budget_ticks,
+                           rng_states != nullptr, rng_tier, domrand_words, NS, NH);
     HIPCHECK(hipMemcpyAsync(h->d_fz, fzbuf, 1024, hipMemcpyHostToDevice, h->stream));
     HIPCHECK(hipStreamSynchronize(h->stream));          // fzbuf is on this stack frame
     HIPCHECK(hipEventRecord(h->ev0, h->stream));
@@ -747,17 +759,18 @@ extern "C" int clothhip_run_actions_begin(clothhip_handle *h, const ClothEpisode
     HIPCHECK(hipEventRecord(h->ev1, h->stream));
     h->have_timing = true;
     h->pending_exec = true;
-    h->f_T = T_; h->f_nscr = nscr; h->f_resets = resets; h->f_obs = obs; h->f_robs = reset_obs;
+    h->f_T = T_; h->f_nscr = nscr; h->f_resets = resets; h->f_obs = obs; h->f_robs = reset_obs; h->f_mt = rng_states != nullptr;
     h->f_pending = true;
     return 0;
 }
 
 extern "C" int clothhip_run_actions_end(clothhip_handle *h, int32_t *num_steps, uint8_t *done, ClothStepRecord *records,
-                                        ClothResetRecord *resets, float *obs, float *reset_obs) {
+                                        ClothResetRecord *resets, float *obs, float *reset_obs, uint32_t *rng_states) {
     if (!h || !num_steps || !done || !records) return fail(CLOTHHIP_EINVAL, "NULL argument");
     if (!h->f_pending) return fail(CLOTHHIP_ESTATE, "no clothhip_run_actions_begin in flight");
     if ((resets != nullptr) != h->f_resets || (obs != nullptr) != h->f_obs || (reset_obs != nullptr) != h->f_robs)
         return fail(CLOTHHIP_EINVAL, "the output buffers must match the ones announced to clothhip_run_actions_begin");
+    if ((rng_states != nullptr) != h->f_mt) return fail(CLOTHHIP_EINVAL, "rng_states must be given to both halves or to neither");
     HIPCHECK(hipSetDevice(h->device));
     const size_t E = h->E, nrec = (size_t)h->f_T * E, nscr = h->f_nscr;
     HIPCHECK(hipMemcpyAsync(records, h->d_frec, nrec * sizeof(ClothStepRecord), hipMemcpyDeviceToHost, h->stream));
@@ -766,6 +779,7 @@ extern "C" int clothhip_run_actions_end(clothhip_handle *h, int32_t *num_steps, 
     HIPCHECK(hipMemcpyAsync(done, h->d_fdone, E, hipMemcpyDeviceToHost, h->stream));
     if (obs) HIPCHECK(hipMemcpyAsync(obs, h->d_fobs, nrec * 3 * h->P * 4, hipMemcpyDeviceToHost, h->stream));
     if (reset_obs) HIPCHECK(hipMemcpyAsync(reset_obs, h->d_frobs, nscr * 3 * h->P * 4, hipMemcpyDeviceToHost, h->stream));
+    if (rng_states) HIPCHECK(hipMemcpyAsync(rng_states, h->d_fmt, E * MT_WORDS * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(hipStreamSynchronize(h->stream));
     h->f_pending = false;
     return 0;
@@ -778,9 +792,10 @@ extern "C" int clothhip_run_actions(clothhip_handle *h, const ClothEpisodeParams
                                     double time_budget_ms) {
     if (!records) return fail(CLOTHHIP_EINVAL, "NULL argument");
     if (int rc = clothhip_run_actions_begin(h, ep, T_, policy, actions, actions_on_device, policy_arg, scripts, n_scripts,
-                                            num_steps, done, resets != nullptr, obs != nullptr, reset_obs != nullptr, time_budget_ms))
+                                            num_steps, done, nullptr, 0, 0, resets != nullptr, obs != nullptr,
+                                            reset_obs != nullptr, time_budget_ms))
         return rc;
-    return clothhip_run_actions_end(h, num_steps, done, records, resets, obs, reset_obs);
+    return clothhip_run_actions_end(h, num_steps, done, records, resets, obs, reset_obs, nullptr);
 }
 
 extern "C" int clothhip_update(clothhip_handle *h, int32_t n_sub, const double *delta) {
@@ -918,6 +933,22 @@ extern "C" double clothhip_last_kernel_ms(clothhip_handle *h) {
     float ms = -1.f;
     if (hipEventElapsedTime(&ms, h->ev0, h->ev1) != hipSuccess) return -1.0;
     return (double)ms;
+}
+
+extern "C" int clothhip_selftest_rng(uint32_t *state, int32_t kind, int32_t n, double a, double b, double c, double *out) {
+    if (!state || n < 0 || (n > 0 && !out && kind != 5)) return fail(CLOTHHIP_EINVAL, "bad argument");
+    for (int i = 0; i < n; i++) {
+        switch (kind) {
+        case 0: out[i] = (double)mt_next32(state); break;
+        case 1: out[i] = mt_double(state); break;
+        case 2: out[i] = mt_uniform(state, a, b); break;
+        case 3: out[i] = (double)mt_randint(state, (uint32_t)a); break;
+        case 4: out[i] = mt_randval_minabs(state, a, b, c); break;
+        default: break;
+        }
+    }
+    if (kind == 5) mt_skip_serial(state, (uint64_t)a);
+    return 0;
 }
 
 extern "C" int clothhip_selftest_arith(int32_t device, int32_t op, const double *a, const double *b, double *out, int64_t n) {

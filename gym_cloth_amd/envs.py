@@ -326,28 +326,35 @@ class ClothVecEnv(object):
         self._pending[e] = None
 
     def _extend_chain(self, e, n):
-        """Make env e's chain of pre-drawn resets at least n long (see _prepare_scripts); the RandomState stays parked."""
+        """Make env e's chain of pre-drawn resets at least n long (see _prepare_scripts); the RandomState stays parked.
+        A chain is {'nodes': [{before, after: (state after the unconditional pulls, state after all pulls)}], 'recs':
+        RESET_SCRIPT_DTYPE[n], 'sides': bool[n]}."""
         from ._lib import RESET_SCRIPT_DTYPE
         chain = self._pending[e]
         if chain is None:
-            chain = self._pending[e] = []
-        if len(chain) >= n:
+            chain = self._pending[e] = {'nodes': [], 'recs': np.zeros(0, dtype=RESET_SCRIPT_DTYPE), 'sides': np.zeros(0, dtype=bool)}
+        nodes = chain['nodes']
+        if len(nodes) >= n:
             return chain
         tier = {'tier1': 1, 'tier3': 3}[self._init_type]
         rng = self.np_randoms[e]
         s_start = rng.get_state()
-        if chain:
-            rng.set_state(chain[-1]['after'][0])
+        if nodes:
+            rng.set_state(nodes[-1]['after'][0])
             if self._consume_domrand:
                 self._domrand_draws(rng)
-        while len(chain) < n:
-            node = {'before': rng.get_state(), 'rec': np.zeros((), dtype=RESET_SCRIPT_DTYPE)}
-            side, s2, s3 = self._draw_script(rng, tier, node['rec'])
-            node['side'], node['after'] = side, (s2, s3)
-            chain.append(node)
+        k0 = len(nodes)
+        recs = np.zeros(n, dtype=RESET_SCRIPT_DTYPE)
+        sides = np.zeros(n, dtype=bool)
+        recs[:k0], sides[:k0] = chain['recs'], chain['sides']
+        for k in range(k0, n):
+            before = rng.get_state()
+            sides[k], s2, s3 = self._draw_script(rng, tier, recs[k])
+            nodes.append({'before': before, 'after': (s2, s3)})
             rng.set_state(s2)                                     # the chain continues as if only the unconditional pulls ran
             if self._consume_domrand:
                 self._domrand_draws(rng)
+        chain['recs'], chain['sides'] = recs, sides
         rng.set_state(s_start)
         return chain
 
@@ -362,13 +369,31 @@ class ClothVecEnv(object):
         self._script_sides = np.zeros((self.E, R), dtype=bool)        # Cloth.init_side of each scripted reset (cloth.pyx:75)
         for e in range(self.E):
             chain = self._extend_chain(e, R)
-            for k in range(R):
-                scripts[e, k] = chain[k]['rec']
-                self._script_sides[e, k] = chain[k]['side']
+            scripts[e] = chain['recs'][:R]
+            self._script_sides[e] = chain['sides'][:R]
         return scripts
 
+    def _apply_reset_records(self, ie, rb, rst, n_consumed, substeps_out, device_rng):
+        """ClothEnv.reset bookkeeping (cloth_env.py:717-790) for the envs `ie` whose rb[e]-th reset of this launch ran."""
+        if not len(ie):
+            return
+        k = rb[ie] - 1
+        q = rst[ie, k]
+        self.init_side[ie] = (q['init_side'] != 0) if device_rng else self._script_sides[ie, k]
+        n_consumed[ie] = k + 1
+        sub = q['executed'].sum(axis=1).astype(np.int64) + q['settle_executed']
+        substeps_out[ie] = sub
+        self.total_substeps += int(sub.sum())
+        self.num_steps[ie] = 0; self.num_sim_steps[ie] = 0
+        self.have_tear[ie] = q['tear'] != 0
+        self._prev_reward[ie] = q['start_coverage']
+        self._start_coverage[ie] = q['start_coverage']
+        self._start_variance_inv[ie] = q['start_variance_inv']
+        self._current_coverage[ie] = 0.0
+        self._ep_done[ie] = False
+
     def step_many(self, actions=None, n_actions=None, policy=None, auto_reset=True, want_obs=False, reset_tail=False,
-                  actions_device_ptr=None, max_resets=None, time_budget_ms=0.0):
+                  actions_device_ptr=None, max_resets=None, time_budget_ms=0.0, device_rng=True):
         """T consecutive `step(a_t, auto_reset=auto_reset)` calls for every env in ONE device launch
         (clothhip_run_actions): decoding, grab, the substep loop, metrics, the terminal test and the episode resets all
         run in the kernel, envs never wait for each other, and the host only does the reward / info bookkeeping below.
@@ -376,10 +401,13 @@ class ClothVecEnv(object):
         actions: float64[T, E, 4], or policy='oracle_corner' (examples/analytic.py's oracle, evaluated on the device)
         with n_actions=T. Resets inside the launch need init type tier1 or tier3 (tier 2 rebuilds per-env rest lengths
         on the host): with tier2, or auto_reset=False, an env whose episode ends idles for the rest of the launch
-        (`ran` False). Up to `max_resets` (default T) resets per env and launch; when tier 1's coverage-conditional third
-        reset pull runs, that env's later pre-drawn resets are void (the RNG stream forked) and it idles after its next
-        episode until the launch ends. An episode that ends in the last slot is reset by the NEXT launch, or here on the
-        host with reset_tail=True (then the returned obs is what T sequential steps return).
+        (`ran` False). Up to `max_resets` (default T) resets per env and launch. The resets are drawn on the device from
+        each env's numpy RandomState stream (device_rng=True: the states are uploaded before and read back after the
+        launch; csrc/cloth_rng.hpp reproduces numpy's MT19937 draws bit for bit), or, with device_rng=False, pre-drawn
+        on the host as a chain of scripts -- then, when tier 1's coverage-conditional third reset pull runs, that env's
+        later scripts are void (the RNG stream forked) and it idles after its next episode until the launch ends.
+        An episode that ends in the last slot is reset by the NEXT launch, or here on the host with reset_tail=True (then
+        the returned obs is what T sequential steps return).
 
         time_budget_ms > 0 turns the launch into a time slice: an env starts no further action once the launch has run that
         long, so envs advance at their own pace instead of waiting for the one with the most work (episode resets make
@@ -389,6 +417,14 @@ class ClothVecEnv(object):
         Returns a dict of arrays [T, E] (rew, done, ran, executed, n_grabbed, reset_before, and the info keys of step())
         plus 'obs' [E, 3P] (state after the launch), 'actions' [T, E, 4] and, with want_obs, 'obs_t' [T, E, 3P]."""
         from . import _lib
+        import time as _time
+        _tp = [_time.perf_counter()]
+        prof = self.__dict__.setdefault('host_prof', {})
+
+        def _lap(name):
+            now = _time.perf_counter()
+            prof[name] = prof.get(name, 0.0) + now - _tp[0]
+            _tp[0] = now
         E = self.E
         if policy in (None, 'table'):
             pol = _lib.POLICY_TABLE
@@ -405,20 +441,37 @@ class ClothVecEnv(object):
         if not self._delta_actions:
             raise NotImplementedError("non-delta actions are decoded on the host only (cos/sin, cloth_env.py:452-453)")
         dev_reset = auto_reset and self._init_type in ('tier1', 'tier3')
-        scripts = self._prepare_scripts(T if max_resets is None else max_resets) if dev_reset else None
+        R = T if max_resets is None else int(max_resets)
+        use_rng = dev_reset and device_rng
+        scripts = self._prepare_scripts(R) if (dev_reset and not use_rng) else None
+        mt = gauss = None
+        if use_rng:                                                   # every env's numpy stream, as RandomState.get_state() has it
+            for e in range(E):
+                self._drop_pending(e)
+            mt = np.zeros((E, _lib.MT_WORDS), dtype=np.uint32)
+            gauss = [None] * E
+            for e in range(E):
+                st = self.np_randoms[e].get_state()
+                mt[e, :624], mt[e, 624], gauss[e] = st[1], st[2], st[3:]
         parg = None
         if pol == _lib.POLICY_ORACLE_CORNER and self._init_type == 'tier2':
             parg = (~self.init_side).astype(np.int32)                                    # analytic.py:108-114
         nsteps = np.ascontiguousarray(self.num_steps, dtype=np.int32)
         done_io = np.ascontiguousarray(self._ep_done, dtype=np.uint8)
+        _lap('prepare_resets')
         self.batch.run_actions_begin(self._episode_params(), T, nsteps, done_io, actions=actions, policy=pol,
                                      policy_arg=parg, scripts=scripts, want_obs=want_obs,
-                                     actions_device_ptr=actions_device_ptr, time_budget_ms=time_budget_ms)
-        if dev_reset:                                                 # while the kernel runs: draw ahead for the NEXT launch
-            R = scripts.shape[1]
+                                     actions_device_ptr=actions_device_ptr, time_budget_ms=time_budget_ms,
+                                     rng_states=mt, rng_tier={'tier1': 1, 'tier3': 3}.get(self._init_type, 0),
+                                     domrand_words=2 * (3 + self._wd * self._hd * 3) if self._consume_domrand else 0,
+                                     reset_capacity=R)
+        _lap('launch')
+        if dev_reset and not use_rng:                                 # while the kernel runs: draw ahead for the NEXT launch
             for e in range(E):
                 self._extend_chain(e, 2 * R)
+        _lap('draw_ahead(overlapped)')
         rec, rst, obs_t, robs = self.batch.run_actions_end()
+        _lap('wait+download')
         if (rec['ran'] == 2).any():
             raise FloatingPointError("iters_pull does not terminate (non-finite action?)")
         out = {k: np.zeros((T, E)) for k in ('rew', 'actual_coverage', 'start_coverage', 'variance_inv', 'start_variance_inv')}
@@ -431,22 +484,7 @@ class ClothVecEnv(object):
         for t in range(T):
             r = rec[t]
             rb = r['reset_before'].astype(np.int64)
-            ie = np.nonzero(rb)[0]                                    # ClothEnv.reset bookkeeping (cloth_env.py:717-790)
-            if len(ie):
-                k = rb[ie] - 1
-                q = rst[ie, k]
-                self.init_side[ie] = self._script_sides[ie, k]
-                n_consumed[ie] = k + 1
-                sub = q['executed'].sum(axis=1).astype(np.int64) + q['settle_executed']
-                out['reset_substeps'][t, ie] = sub
-                self.total_substeps += int(sub.sum())
-                self.num_steps[ie] = 0; self.num_sim_steps[ie] = 0
-                self.have_tear[ie] = q['tear'] != 0
-                self._prev_reward[ie] = q['start_coverage']
-                self._start_coverage[ie] = q['start_coverage']
-                self._start_variance_inv[ie] = q['start_variance_inv']
-                self._current_coverage[ie] = 0.0
-                self._ep_done[ie] = False
+            self._apply_reset_records(np.nonzero(rb)[0], rb, rst, n_consumed, out['reset_substeps'][t], use_rng)
             ran = r['ran'] == 1
             executed = np.where(ran, r['executed'], 0).astype(np.int64)
             self.total_substeps += int(executed.sum())
@@ -469,28 +507,36 @@ class ClothVecEnv(object):
             out['actual_coverage'][t], out['start_coverage'][t] = self._current_coverage, self._start_coverage
             out['variance_inv'][t], out['start_variance_inv'][t] = r['variance_inv'], self._start_variance_inv
             out['have_tear'][t], out['out_of_bounds'][t] = self.have_tear, oob
+        if dev_reset:                                                 # a time slice may end right after a reset
+            tail = np.nonzero(rst['consumed'].sum(axis=1) > n_consumed)[0]
+            if len(tail):
+                rb = np.zeros(E, dtype=np.int64)
+                rb[tail] = n_consumed[tail] + 1
+                out['tail_reset_substeps'] = np.zeros(E, dtype=np.int64)
+                self._apply_reset_records(tail, rb, rst, n_consumed, out['tail_reset_substeps'], use_rng)
         assert np.array_equal(self.num_steps.astype(np.int32), nsteps) and np.array_equal(self._ep_done, done_io != 0)
-        if dev_reset:                                                 # commit the RNG draws the device consumed
+        _lap('bookkeeping')
+        if use_rng:                                                   # the streams as the device left them
+            for e in np.nonzero(n_consumed)[0]:
+                self.np_randoms[e].set_state(('MT19937', mt[e, :624], int(mt[e, 624])) + tuple(gauss[e]))
+        elif dev_reset:                                               # commit the RNG draws the device consumed
             for e in np.nonzero(n_consumed)[0]:
                 chain, c = self._pending[e], int(n_consumed[e])
-                last = chain[c - 1]
-                n_uncond = int((last['rec']['pull']['need_coverage'][:int(last['rec']['n_pulls'])] == 0).sum())
+                nodes, last_rec = chain['nodes'], chain['recs'][c - 1]
+                n_uncond = int((last_rec['pull']['need_coverage'][:int(last_rec['n_pulls'])] == 0).sum())
                 forked = int(rst[e, c - 1]['pulls_run']) > n_uncond
                 rng = self.np_randoms[e]
-                if forked:                                            # the conditional pull ran: later scripts are void
-                    rng.set_state(last['after'][1])
+                if forked or c >= len(nodes):                         # forked: the conditional pull ran, later scripts are void
+                    rng.set_state(nodes[c - 1]['after'][1 if forked else 0])
                     if self._consume_domrand:
                         self._domrand_draws(rng)
                     self._pending[e] = None
-                elif c < len(chain):
-                    rng.set_state(chain[c]['before'])
-                    self._pending[e] = chain[c:]
                 else:
-                    rng.set_state(last['after'][0])
-                    if self._consume_domrand:
-                        self._domrand_draws(rng)
-                    self._pending[e] = None
+                    rng.set_state(nodes[c]['before'])
+                    self._pending[e] = {'nodes': nodes[c:], 'recs': chain['recs'][c:], 'sides': chain['sides'][c:]}
+        _lap('rng_commit')
         obs = self.state
+        _lap('obs_download')
         if reset_tail and auto_reset and self._ep_done.any():
             obs = self.reset(mask=self._ep_done.copy())
         out['obs'] = obs

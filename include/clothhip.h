@@ -224,7 +224,7 @@ typedef struct ClothResetRecord {
     int32_t executed[3];             /* update() calls of each pull */
     int32_t settle_executed;
     int32_t tear;                    /* Cloth.have_tear after the reset */
-    int32_t _pad;
+    int32_t init_side;               /* device-drawn resets: Cloth.init_side (cloth.pyx:75: np_random.rand() > 0.5) */
     double start_coverage, start_variance_inv;   /* cloth_env.py:780-782 */
     double action[3][4];             /* the reset actions in clip space, as the reference passes them to step(initialize=True) */
 } ClothResetRecord;
@@ -242,20 +242,28 @@ typedef struct ClothResetRecord {
  * time_budget_ms > 0 makes the launch a TIME SLICE: an env starts no further action once the launch has run that long
  * (constant-rate 100 MHz clock), so envs advance at their own pace and the launch does not wait for the env with the most
  * work; the unused slots of an env stay `ran == 0` at the END of its column and the caller passes those actions again in
- * the next launch. Which launch executes an action never changes its result (envs are independent); only the partition
+ * the next launch; a slice may also end right after a reset (ClothResetRecord.consumed set, no record with that
+ * reset_before). Which launch executes an action never changes its result (envs are independent); only the partition
  * of an env's action sequence into launches depends on timing. 0 = every env executes all T slots.
  * Returns CLOTHHIP_ESTATE when the handle's variant cannot run fused (per-env rest tables with reset scripts,
  * non-25x25 oracle policy, grid too large for the in-kernel metrics). Synchronous. */
-/* The same in two halves, so that the caller can work (e.g. draw the next reset scripts) while the launch runs:
+/* Resets drawn ON THE DEVICE (the _begin/_end form only): instead of `scripts`, pass rng_states[E][626] = every env's
+ * numpy RandomState (get_state(): key[624], pos, one pad word). The kernel then draws each reset exactly as ClothEnv.reset
+ * does from np_random (cloth.pyx:75; cloth_env.py:851-877 tier 1 incl. the coverage-conditional third pull, :959-972
+ * tier 3; rng_tier = 1 or 3), bit for bit numpy's MT19937 / rand / uniform / randint stream (csrc/cloth_rng.hpp), skips
+ * domrand_words 32-bit words after each reset (the domain-randomisation draws of cloth_env.py:786-789; 0 = none), and
+ * _end returns the advanced states. n_scripts is then the capacity of resets[E][n_scripts] / reset_obs per env; any number
+ * of resets per env and launch up to that capacity, no void scripts.
+ * The same in two halves, so that the caller can work (e.g. draw the next reset scripts) while the launch runs:
  * _begin uploads the inputs and launches (the host input arrays are not retained), _end waits and downloads. The want_*
  * flags of _begin announce which of the optional output buffers _end will be given. One launch in flight per handle. */
 int clothhip_run_actions_begin(clothhip_handle *h, const ClothEpisodeParams *ep, int32_t T, int32_t policy,
                                const double *actions, int32_t actions_on_device, const int32_t *policy_arg,
                                const ClothResetScript *scripts, int32_t n_scripts, const int32_t *num_steps,
-                               const uint8_t *done, int32_t want_resets, int32_t want_obs, int32_t want_reset_obs,
-                               double time_budget_ms);
+                               const uint8_t *done, const uint32_t *rng_states, int32_t rng_tier, uint64_t domrand_words,
+                               int32_t want_resets, int32_t want_obs, int32_t want_reset_obs, double time_budget_ms);
 int clothhip_run_actions_end(clothhip_handle *h, int32_t *num_steps, uint8_t *done, ClothStepRecord *records,
-                             ClothResetRecord *resets, float *obs, float *reset_obs);
+                             ClothResetRecord *resets, float *obs, float *reset_obs, uint32_t *rng_states);
 /* 1 if this handle's kernel variant has the LDS room for the in-kernel metrics of clothhip_run_actions, else 0 */
 int clothhip_fused_supported(const clothhip_handle *h);
 int clothhip_run_actions(clothhip_handle *h, const ClothEpisodeParams *ep, int32_t T, int32_t policy,
@@ -313,6 +321,10 @@ int clothhip_debug_stats(clothhip_handle *h, int32_t *stats);
 /* Arithmetic self-test used by the parity tests: evaluates out[i] = op(a[i], b[i]) in double ON THE
  * DEVICE with the same compiler flags as the stepper (op 0: a/b, 1: sqrt(a), 2: a*b+c unfused = (a*b)+b,
  * 3: floor(a/b)).  Lets tests assert IEEE-correct rounding of the device's sqrt/div bit-for-bit. */
+/* Host-side self-test of csrc/cloth_rng.hpp (the same functions the kernel runs): n draws of kind 0 next32, 1 rand(),
+ * 2 uniform(a, b), 3 randint((uint32)a), 4 _randval_minabs(a, b, minabs = c) into out[n]; kind 5 skips (uint64)a words.
+ * state[625] = key[624], pos: numpy RandomState.get_state()[1:3], advanced in place. No device needed. */
+int clothhip_selftest_rng(uint32_t *state, int32_t kind, int32_t n, double a, double b, double c, double *out);
 int clothhip_selftest_arith(int32_t device, int32_t op, const double *a, const double *b, double *out,
                             int64_t n);
 

@@ -237,3 +237,53 @@ def test_step_many_script_drawing_is_rng_neutral():
     sc2 = v._prepare_scripts(4)                              # longer chain: the first three are the cached ones
     assert np.array_equal(sc2[:, :3], sc) and sc2["valid"].all()
     assert all(np.array_equal(b, r.get_state()[1]) for b, r in zip(before, v.np_randoms))
+
+
+def _mt_image(rng):
+    st = rng.get_state()
+    img = np.zeros(625, dtype=np.uint32)
+    img[:624], img[624] = st[1], st[2]
+    return img
+
+
+def test_device_rng_functions_match_numpy(lib):
+    """csrc/cloth_rng.hpp (the code the kernel runs to draw episode resets) against numpy's legacy RandomState, on the
+    host: raw MT19937 words across several twists, rand(), uniform(), randint(625) (masked rejection), the rejection loop
+    of ClothEnv._randval_minabs, a skip of the 301 062 words the domain-randomisation draws consume, and the exact draw
+    sequence of a tier-1 and a tier-3 reset (cloth.pyx:75; cloth_env.py:851-877, :959-972)."""
+    from gym_cloth_amd.envs import ClothVecEnv
+    L = lib.load()
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+
+    def draw(img, kind, n, a=0.0, b=0.0, c=0.0):
+        out = np.zeros(max(n, 1))
+        lib.check(L.clothhip_selftest_rng(vp(img), kind, n, a, b, c, lib.dp(out)))
+        return out[:n]
+    for seed in (0, 1337, 2 ** 31 - 5):
+        ref = np.random.RandomState(seed)
+        ref.rand(100)                                          # start from a mid-buffer position
+        img = _mt_image(ref)
+        want = ref.randint(0, 2 ** 32, size=2000, dtype=np.uint64).astype(np.float64)      # one 32-bit word each
+        assert np.array_equal(draw(img, 0, 2000), want)
+        assert np.array_equal(draw(img, 1, 700), ref.rand(700))
+        assert np.array_equal(draw(img, 2, 300, -0.2, 0.2), np.array([ref.uniform(-0.2, 0.2) for _ in range(300)]))
+        assert np.array_equal(draw(img, 3, 500, 625), np.array([ref.randint(625) for _ in range(500)], dtype=np.float64))
+        assert np.array_equal(draw(img, 3, 50, 1024), np.array([ref.randint(1024) for _ in range(50)], dtype=np.float64))
+        assert np.array_equal(draw(img, 4, 200, -0.2, 0.2, 0.08),
+                              np.array([ClothVecEnv._randval_minabs(ref, -0.2, 0.2, 0.08) for _ in range(200)]))
+        ref.uniform(40, 50); ref.uniform(0.7, 1.3)
+        lim = ref.uniform(-15.0, 15.0)
+        ref.uniform(-lim, lim, size=(224, 224, 3))
+        draw(img, 5, 0, float(2 * (3 + 224 * 224 * 3)))
+        assert np.array_equal(img, _mt_image(ref)), "state after the domain-randomisation skip"
+        # a tier-1 reset with its third pull, then a tier-3 reset, drawn word for word like the host path draws them
+        side = ref.rand() > 0.5
+        assert (draw(img, 1, 1)[0] > 0.5) == side
+        for _ in range(3):
+            assert draw(img, 3, 1, 625)[0] == ref.randint(625)
+            assert draw(img, 4, 1, -0.2, 0.2, 0.08)[0] == ClothVecEnv._randval_minabs(ref, -0.2, 0.2, 0.08)
+            assert draw(img, 4, 1, -0.2, 0.2, 0.08)[0] == ClothVecEnv._randval_minabs(ref, -0.2, 0.2, 0.08)
+        assert draw(img, 2, 1, 200.0, 280.0)[0] == ref.uniform(low=200, high=280)
+        for lo, hi, m in ((0.30, 0.70, 0.0), (0.30, 0.70, 0.0), (-0.25, 0.25, 0.10), (-0.25, 0.25, 0.10)):
+            assert draw(img, 4, 1, lo, hi, m)[0] == ClothVecEnv._randval_minabs(ref, lo, hi, m if m > 0 else None)
+        assert np.array_equal(img, _mt_image(ref))
