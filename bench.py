@@ -113,7 +113,7 @@ def load_traffic(mode, E, n_side, precision, fuse):
     try:
         with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as fh:
             for r in json.load(fh)["records"]:
-                if (r["mode"], r["envs"], r["n_side"], r["precision"], r.get("fuse", 1)) == (mode, E, n_side, precision, fuse):
+                if (r["mode"], r["envs"], r["n_side"], r["precision"]) == (mode, E, n_side, precision):
                     return r["hbm_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
@@ -142,8 +142,8 @@ def run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, rank
                 print("bench: fused mode unavailable for %dx%d; using step mode" % (n_side, n_side), file=sys.stderr)
             mode, fuse = "step", 1
     slice_ms = fuse * step_ms
-    slots = slots if slots > 0 else 4 * fuse
-    max_resets = max_resets if max_resets > 0 else 2 * fuse
+    slots = slots if slots > 0 else max(4 * fuse, int(slice_ms / 40.0))   # a missed grab costs no time: be generous
+    max_resets = max_resets if max_resets > 0 else min(slots, 250)
     total = warmup + steps
     acts_all = None
     if rank == 0:                                            # actions for ALL envs of the job, RandomState(2000+e)

@@ -60,6 +60,9 @@ template <typename T> struct FusedArgs {
     const double *levels;             // Gripper.grab_top curZ table
     int32_t n_glevels, E;
     int32_t n_scripts, _pad;
+    // copies of StepArgs' static-table pointers: the LDS re-initialisation after the in-kernel metrics loads them from
+    // here (plain global loads at the point of use) instead of keeping the kernel arguments alive across the substep loop
+    const uint32_t *lv_ent; const uint16_t *lv_off, *lv_off8, *pt_lev; const T *rest; int32_t rest_stride, _pad3;
     uint32_t *mt;                     // [E][MT_WORDS] numpy RandomState of every env, or nullptr (resets come from `scripts`)
     uint64_t domrand_words;           // 32-bit words the domain-randomisation draws after a reset consume (cloth_env.py:786-789), or 0
     int32_t rng_tier, _pad2;          // with mt: 1 or 3, the reset procedure to draw (cloth_env.py:843-891, :951-982)
@@ -661,26 +664,27 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
     }
     // everything in LDS behind the particle records: static tables, hash table, sweep flags (also re-run after the in-kernel
     // metrics, which borrow that region as scratch)
-    auto init_lds = [&](int tear_flag) {
+    auto init_lds = [&](int tear_flag, const uint32_t *s_ent, const T *s_rest, const uint16_t *s_off, const uint16_t *s_off8,
+                        const uint16_t *s_plev) {
         if (TAB >= 1) {
             uint32_t *d0 = reinterpret_cast<uint32_t *>(smem + lay.ent);
             T *d1 = reinterpret_cast<T *>(smem + lay.rest);
-            for (int i = tid; i < A.Spad; i += NT) { d0[i] = A.lv_ent[i]; d1[i] = g_rest[i]; }
+            for (int i = tid; i < A.Spad; i += NT) { d0[i] = s_ent[i]; d1[i] = s_rest[i]; }
             uint16_t *d2 = reinterpret_cast<uint16_t *>(smem + lay.off);
-            for (int i = tid; i < nL + 40; i += NT) d2[i] = A.lv_off[i];
+            for (int i = tid; i < nL + 40; i += NT) d2[i] = s_off[i];
             uint16_t *d3 = reinterpret_cast<uint16_t *>(smem + lay.off8);
-            for (int i = tid; i < (A.n_levels8 > 0 ? A.n_levels8 + 40 : 0); i += NT) d3[i] = A.lv_off8[i];
+            for (int i = tid; i < (A.n_levels8 > 0 ? A.n_levels8 + 40 : 0); i += NT) d3[i] = s_off8[i];
         }
         if (TAB >= 2) {
             uint16_t *d4 = reinterpret_cast<uint16_t *>(smem + lay.plev);
-            for (int i = tid; i < HK_SLOTS * Ppad; i += NT) d4[i] = A.pt_lev[i];
+            for (int i = tid; i < HK_SLOTS * Ppad; i += NT) d4[i] = s_plev[i];
         }
         for (int h = tid; h < HT; h += NT) { hkey[h] = KEY_EMPTY; hco[h] = 0; }
         for (int i = tid; i < nL + 64; i += NT) lvflag[i] = 0;
         for (int i = tid; i < (A.Spad / 64 + 2) * 2; i += NT) reinterpret_cast<uint32_t *>(smem + lay.abits)[i] = 0u;
         if (tid == 0) { misc[0] = tear_flag; misc[1] = 0; misc[2] = 0; misc[3] = 0; misc[4] = 0; misc[5] = 0; misc[6] = 0; }
     };
-    init_lds(A.tear[e]);
+    init_lds(A.tear[e], A.lv_ent, g_rest, A.lv_off, A.lv_off8, A.pt_lev);
     __syncthreads();
 
     int st_sweeps = 0, st_dense = 0, st_levels = 0, st_trig = 0;      // wave 0 only (uniform)
@@ -1594,7 +1598,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                 // cloth_env.py:1020-1098 on the LDS-resident state; the sort buffers borrow the LDS behind the particle records
                 auto src = [&](int i, double &x, double &y, double &z) { const Pt<T> c = cur[i]; x = (double)c.x; y = (double)c.y; z = (double)c.z; };
                 metrics_block<NT, T>(src, P, F.NS, F.NH, smem + lay.ent, tid, F.half_thickness, mo);
-                init_lds(tear_now);
+                init_lds(tear_now, F.lv_ent, F.rest + (size_t)e * F.rest_stride, F.lv_off, F.lv_off8, F.pt_lev);
                 __syncthreads();
             }
             if (op == OP_ACTION && F.obs) {                                                       // '1d' observation, cloth_env.py:196-200

@@ -34,8 +34,9 @@ CLOTH_HD inline uint32_t mt_twist_word(uint32_t cur, uint32_t nxt, uint32_t far)
     return far ^ (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
 }
 
-// mt19937_gen: regenerate the 624 words in place, sequentially (one thread)
-CLOTH_HD inline void mt_twist_serial(uint32_t *key) {
+// mt19937_gen: regenerate the 624 words in place, sequentially (one thread). Not inlined: every draw contains a possible
+// refill, and the stepper kernel's cold paths should stay small.
+CLOTH_HD __attribute__((noinline)) inline void mt_twist_serial(uint32_t *key) {
     int i = 0;
     for (; i < MT_N - MT_M; i++) key[i] = mt_twist_word(key[i], key[i + 1], key[i + MT_M]);
     for (; i < MT_N - 1; i++) key[i] = mt_twist_word(key[i], key[i + 1], key[i + (MT_M - MT_N)]);

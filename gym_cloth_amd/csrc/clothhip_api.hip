@@ -647,6 +647,8 @@ template <typename T> static void fill_fused(clothhip_handle *h, FusedArgs<T> &f
     f.obs = have_obs ? (float *)h->d_fobs : nullptr;
     f.reset_obs = have_robs ? (float *)h->d_frobs : nullptr;
     f.flat = (const T *)h->d_flat;
+    f.lv_ent = h->d_lv_ent; f.lv_off = h->d_lv_off; f.lv_off8 = h->d_lv_off8; f.pt_lev = h->d_pt_lev;
+    f.rest = (const T *)h->d_rest; f.rest_stride = h->rest_stride;
     f.levels = h->d_levels; f.n_glevels = h->n_grab_levels; f.E = h->E; f.n_scripts = n_scripts; f.budget_ticks = budget_ticks;
     f.mt = have_mt ? h->d_fmt : nullptr; f.rng_tier = rng_tier; f.domrand_words = domrand_words;
     f.two_thickness = 2 * h->prm.thickness; f.half_thickness = h->prm.thickness / 2.0;

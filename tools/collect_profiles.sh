@@ -5,22 +5,29 @@ set -u
 OUT=gpurun_out/prof_${1:-final}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-T="timeout 300"
-# 1. kernel trace + stats of the bench command
-$T rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o run -- python3 bench.py > "$OUT/bench_traced.json" 2> "$OUT/trace.log"
-# 2. the same command untraced (the number quoted)
+T="timeout 600"
+HEAD="--no-extra --no-cpu-baseline"        # the headline configuration only (512 cloths, fp32, fused time slices)
+# 1. kernel trace + stats of the headline bench command
+$T rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o run -- python3 bench.py $HEAD > "$OUT/bench_traced.json" 2> "$OUT/trace.log"
+# 2. the full default command untraced (the numbers quoted: headline + companions + CPU baseline)
 $T python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.log"
 # 3. HBM traffic counters, separate passes
 for C in FETCH_SIZE WRITE_SIZE; do
-  $T rocprofv3 --pmc $C -d "$OUT/pmc_$C" -o run -- python3 bench.py --no-cpu-baseline --steps 2 > "$OUT/pmc_$C.out" 2> "$OUT/pmc_$C.log"
+  $T rocprofv3 --pmc $C -d "$OUT/pmc_$C" -o run -- python3 bench.py $HEAD > "$OUT/pmc_$C.out" 2> "$OUT/pmc_$C.log"
 done
-# 4. instruction mix / wait counters over one real action split in six launches
+# 4. instruction mix / wait counters over the same command
 for C in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS"; do
   N=$(echo $C | tr ' ' '_')
-  $T rocprofv3 --pmc $C -d "$OUT/pmc_$N" -o run -- python3 tools/phase_profile.py > "$OUT/pmc_$N.out" 2> "$OUT/pmc_$N.log"
+  $T rocprofv3 --pmc $C -d "$OUT/pmc_$N" -o run -- python3 bench.py $HEAD --steps 10 > "$OUT/pmc_$N.out" 2> "$OUT/pmc_$N.log"
 done
-# 5. phase profiles (fp32, fp64) and per-cloth diagnostics
+# 5. where the time of the bench workload goes: balance of a launch, then the per-phase stamps (profiling build)
+$T python3 tools/fused_profile.py > "$OUT/fused_balance.txt" 2>&1
+if [ -f gym_cloth_amd/libclothhip_stamps.so ]; then
+  CLOTHHIP_LIB=$PWD/gym_cloth_amd/libclothhip_stamps.so CLOTHHIP_DEBUG_PHASES=47 $T python3 tools/fused_profile.py > "$OUT/fused_phases.txt" 2>&1
+fi
+# 6. one real pick-and-place (the reference's oracle action) phase by phase, fp32 and fp64
 $T python3 tools/phase_profile.py > "$OUT/phase_f32.txt" 2>&1
 $T python3 tools/phase_profile.py --precision f64 > "$OUT/phase_f64.txt" 2>&1
-$T python3 tools/bench_diag.py > "$OUT/bench_diag.txt" 2>&1
-find "$OUT" -name "*.csv" | head -40
+# 7. rocprofv3 trace of the 50x50 companion (configs[4]) alone
+$T rocprofv3 --kernel-trace --stats -d "$OUT/trace50" -o run -- python3 bench.py $HEAD --n-side 50 --envs 1024 --steps 5 --warmup 0 --fuse 5 --step-ms 2400 > "$OUT/bench50_traced.json" 2> "$OUT/trace50.log"
+find "$OUT" -name "*.db" | head -40

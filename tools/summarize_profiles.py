@@ -2,7 +2,8 @@
 """Turn a tools/collect_profiles.sh output directory (rocprofv3 rocpd databases + text logs) into the small
 summaries kept under profiles/ (dev tool, runs anywhere: only needs sqlite3).
 
-  python tools/summarize_profiles.py gpurun_out/prof_r1d profiles/r01_final
+  python tools/summarize_profiles.py gpurun_out/prof_r2 profiles/r02
+Also writes profiles/r02_traffic.json: the per-launch HBM bytes bench.py reports as roofline.traffic.
 """
 import csv
 import glob
@@ -33,7 +34,9 @@ def main():
             w.writerow([r[0], r[1], int(r[2]), "%.1f" % r[3], "%.4f" % (100.0 * r[2] / tot), int(r[4]), int(r[5])])
     disp = c.execute("select name, duration, grid_x, workgroup_x, lds_size, vgpr_count, scratch_size from kernels "
                      "where name like '%k_run_schedule%' order by start").fetchall()
-    out = {"command": "rocprofv3 --kernel-trace --stats -- python3 bench.py",
+    out = {"command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-extra --no-cpu-baseline",
+           "note": "vgprs below is rocprofv3's per-dispatch field (arch VGPR granules as the tool reports them); the compiler's "
+                   "count per kernel variant is in *_kernel_resources.txt (tools/kernel_resources.sh)",
            "k_run_schedule_dispatches_ms": [round(d[1] / 1e6, 3) for d in disp],
            "k_run_schedule_launch": ({"grid_threads": disp[0][2], "workgroup": disp[0][3], "lds_bytes": disp[0][4],
                                       "vgprs": disp[0][5], "scratch_bytes": disp[0][6]} if disp else None)}
@@ -60,11 +63,36 @@ def main():
             if name in ("FETCH_SIZE", "WRITE_SIZE"):
                 pmc["per_dispatch"][name + "_KB"] = [round(v, 1) for v in vals]
     json.dump(pmc, open(dst + "_pmc_summary.json", "w"), indent=1)
+    # per-launch HBM traffic of the dominant kernel for bench.py's roofline.traffic: the timed launches are the last ones of
+    # the profiled command; FETCH_SIZE is doubled (gfx950: it tallies 128-byte requests at 64 bytes, MI355X_MICROARCH.md)
+    tb = out.get("bench_traced") or {}
+    nl = int(tb.get("roofline", {}).get("launches", 0) or 0)
+    fk, wk = pmc["per_dispatch"].get("FETCH_SIZE_KB"), pmc["per_dispatch"].get("WRITE_SIZE_KB")
+    if nl and fk and wk and len(fk) >= nl and len(wk) >= nl:
+        fetch = sum(fk[-nl:]) / nl * 1024.0
+        write = sum(wk[-nl:]) / nl * 1024.0
+        cfg = tb["config"]
+        rec = {"mode": "fused" if cfg["mode"].startswith("fused") else "step", "envs": cfg["envs_per_gpu"], "n_side": cfg["n_side"],
+               "precision": tb["dtype"], "fuse": None, "fetch_size_bytes_per_launch_raw": fetch, "write_size_bytes_per_launch": write,
+               "hbm_bytes_per_launch": 2.0 * fetch + write,
+               "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) -- python3 bench.py --no-extra --no-cpu-baseline",
+               "algorithmic_bytes_per_launch": tb["roofline"]["substeps_per_launch"] * tb["roofline"]["alg_bytes_per_substep"]}
+        json.dump({"records": [rec]}, open(os.path.join(os.path.dirname(dst) or ".", os.path.basename(dst).split("_")[0] + "_traffic.json"), "w"), indent=1)
     for nm, to in (("phase_f32.txt", "_phase_profile_f32.txt"), ("phase_f64.txt", "_phase_profile_f64.txt"),
-                   ("bench_diag.txt", "_bench_diag.txt")):
+                   ("fused_balance.txt", "_fused_balance.txt"), ("fused_phases.txt", "_fused_phases.txt")):
         p = os.path.join(src, nm)
         if os.path.exists(p):
             shutil.copy(p, dst + to)
+    c50 = db_of(os.path.join(src, "trace50"))
+    if c50 is not None:
+        rows = c50.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels "
+                           "group by name order by sum(duration) desc").fetchall()
+        tot = float(sum(r[2] for r in rows))
+        with open(dst + "_50x50_kernel_stats.csv", "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+            for r in rows:
+                w.writerow([r[0], r[1], int(r[2]), "%.1f" % r[3], "%.4f" % (100.0 * r[2] / tot), int(r[4]), int(r[5])])
     print(open(dst + "_kernel_stats.csv").read())
     print(json.dumps(pmc, indent=1)[:1500])
 
