@@ -211,3 +211,34 @@ def test_device_drawn_reset_equals_host_reset_f64(tier, seed, oracle_lib):
         g = oracle_lib.load_golden("g_env_tier1_1337.npz")
         assert np.array_equal(out["reset_obs"][0, 0], g["reset_obs"].astype(np.float32))
     h.close(); d.close()
+
+
+def test_demo_writer_device_equals_host_loop_f64(tmp_path):
+    """collect_demos with the oracle-corner policy evaluated in the kernel (policy, steps and episode resets in one
+    launch) writes the same episodes as the reference-shaped host loop (policy object -> step -> reset), env by env."""
+    import pickle
+    from gym_cloth_amd.demos import collect_demos
+    from gym_cloth_amd.envs import ClothVecEnv
+    from gym_cloth_amd.policies import OracleCornerPolicy
+
+    def make():
+        v = ClothVecEnv(base_cfg("tier1", 1337), n_envs=3, precision="f64", consume_domrand_draws=False)
+        v.seed([1337, 1338, 1339])
+        return v
+    a, b = make(), make()
+    dev = collect_demos(a, "oracle_corner", max_episodes=6, slots_per_launch=6, path=str(tmp_path / "demos.pkl"))
+    host = collect_demos(b, OracleCornerPolicy(b), max_episodes=6)
+    assert pickle.load(open(str(tmp_path / "demos.pkl"), "rb"))[0]["act"] == dev[0]["act"]
+    by_env = lambda eps: {e: [ep for ep in eps if ep["env"] == e] for e in range(3)}
+    d, h = by_env(dev), by_env(host)
+    compared = 0
+    for e in range(3):
+        for ed, eh in zip(d[e], h[e]):
+            assert ed["act"] == eh["act"] and ed["rew"] == eh["rew"] and ed["done"] == eh["done"]
+            assert len(ed["obs"]) == len(eh["obs"]) == len(ed["act"]) + 1
+            for od, oh in zip(ed["obs"], eh["obs"]):
+                assert np.array_equal(od, oh.astype(np.float32))
+            assert ed["info"] == eh["info"]
+            compared += 1
+    assert compared >= 3
+    a.close(); b.close()
