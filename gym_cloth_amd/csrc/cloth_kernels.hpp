@@ -45,6 +45,8 @@ template <typename T> struct DevConsts {
     T c11;             // 1.1                                    cloth.pyx:275
 };
 
+struct EpResume;
+
 template <typename T> struct FusedArgs {
     int32_t nT, policy, NS, NH;       // action slots per launch, CLOTHHIP_POLICY_*, metrics sort / hull buffer sizes
     const double *actions;            // [nT][E][4]
@@ -66,6 +68,7 @@ template <typename T> struct FusedArgs {
     uint32_t *mt;                     // [E][MT_WORDS] numpy RandomState of every env, or nullptr (resets come from `scripts`)
     uint64_t domrand_words;           // 32-bit words the domain-randomisation draws after a reset consume (cloth_env.py:786-789), or 0
     int32_t rng_tier, _pad2;          // with mt: 1 or 3, the reset procedure to draw (cloth_env.py:843-891, :951-982)
+    EpResume *resume;                 // [E] or nullptr: operations cut by the previous launch's time slice / to be cut by this one
     uint64_t budget_ticks;            // 0 = none; else no new action / reset starts once the launch has run this many 100 MHz ticks
     double two_thickness, half_thickness;
     ClothEpisodeParams ep;
@@ -87,6 +90,19 @@ struct EpState {
     int32_t side, _pad;    // device-RNG resets: Cloth.init_side of the reset in progress (cloth.pyx:75)
     double act[4];
     ClothResetPull pull;   // device-RNG resets: the draws of the pull being executed
+};
+
+// An operation cut by the end of a time slice (clothhip_run_actions with a time budget): everything needed to continue it in
+// the next launch. The particle state itself goes through pos / prev / cnt / tear as for any launch end; a substep
+// boundary is a complete state (the hash table and sweep flags are rebuilt every substep).
+struct EpResume {
+    int32_t valid;             // 0 none; 1 an operation of this env is in flight
+    int32_t it;                // >= 0: the substep loop of `sc` continues at this iteration; -1: between two operations of a reset
+    int32_t done_partial;      // update() calls the interrupted run had executed
+    int32_t _pad;
+    ClothSchedule sc;
+    EpState eps;
+    ClothResetRecord rr;       // the partly filled record of the reset in flight (eps.rp >= 0)
 };
 
 template <typename T> struct StepArgs {
@@ -721,14 +737,44 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
         if (tid == 0) {
             eps->t_slot = 0; eps->rp = -1; eps->n_resets = 0; eps->chain_ok = 1; eps->rs_pulls = 0; eps->reset_mark = 0;
             eps->ep_steps = Fp->num_steps[e]; eps->ep_done = Fp->done[e] ? 1 : 0; eps->done_total = 0; eps->stop = 0;
+            misc[7] = 0;
+            if (Fp->resume != nullptr && Fp->resume[e].valid) {        // continue the operation the previous time slice cut
+                const EpResume *rs_ = Fp->resume + e;
+                const EpState &o = rs_->eps;
+                eps->rp = o.rp; eps->chain_ok = o.chain_ok; eps->rs_pulls = o.rs_pulls; eps->ep_steps = o.ep_steps;
+                eps->ep_done = o.ep_done; eps->op = o.op; eps->n_grab = o.n_grab; eps->iters_pull = o.iters_pull;
+                eps->decode_err = o.decode_err; eps->side = o.side; eps->pull = o.pull;
+                eps->act[0] = o.act[0]; eps->act[1] = o.act[1]; eps->act[2] = o.act[2]; eps->act[3] = o.act[3];
+                if (o.rp >= 0 && Fp->resets != nullptr) Fp->resets[(size_t)e * Fp->n_scripts] = rs_->rr;   // its record, now slot 0
+            }
         }
         __syncthreads();
+    }
+    // resume_it >= 0: the first trip of the loop below continues an interrupted run instead of planning an operation
+    int resume_it = -1, resume_done = 0;
+    if (FUSED) {
+        if (Fp->resume != nullptr && Fp->resume[e].valid) {
+            const EpResume *rs_ = Fp->resume + e;
+            resume_it = rs_->it; resume_done = rs_->done_partial;
+            if (resume_it >= 0) sc = rs_->sc;
+        }
+        __syncthreads();
+        if (tid == 0 && Fp->resume != nullptr) Fp->resume[e].valid = 0;
     }
     const uint64_t t_launch = FUSED ? __builtin_amdgcn_s_memrealtime() : 0;   // 100 MHz, constant rate (thread 0's copy is used)
     int done_nf = 0;                   // executed substeps of the external schedule (not fused)
     for (;;) {
         bool do_run = true;
-        if (fused) {
+        const bool resumed_run = FUSED && resume_it >= 0;
+        if (fused && resumed_run) {
+            sc.n_up_end = __builtin_amdgcn_readfirstlane(sc.n_up_end);
+            sc.n_uprest_end = __builtin_amdgcn_readfirstlane(sc.n_uprest_end);
+            sc.n_pull_end = __builtin_amdgcn_readfirstlane(sc.n_pull_end);
+            sc.n_griprest_end = __builtin_amdgcn_readfirstlane(sc.n_griprest_end);
+            sc.n_total = __builtin_amdgcn_readfirstlane(sc.n_total);
+            sc.break_on_tear = __builtin_amdgcn_readfirstlane(sc.break_on_tear);
+        }
+        if (fused && !resumed_run) {
             // ---- plan the next operation. Every thread evaluates the same transitions on the same LDS-resident state.
             const FusedArgs<T> &F = *Fp;
             int t_slot = eps->t_slot, rp = eps->rp;
@@ -815,6 +861,17 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                     act[0] = ap[0]; act[1] = ap[1]; act[2] = ap[2]; act[3] = ap[3];
                 }
             } else {
+                if (eps->stop && F.resume != nullptr) {  // the slice ends between two operations of a reset
+                    if (tid == 0) {
+                        EpResume *rs_ = F.resume + e;
+                        rs_->valid = 1; rs_->it = -1; rs_->done_partial = 0; rs_->eps = *eps;
+                        if (F.resets != nullptr) {
+                            ClothResetRecord *rr_ = F.resets + ((size_t)e * F.n_scripts + n_resets);
+                            rs_->rr = *rr_; rr_->consumed = 2;
+                        }
+                    }
+                    break;
+                }
                 for (;;) {                               // skip the stages this script does not have
                     if (rp < 6) {
                         const int p_ = rp >> 1;
@@ -970,10 +1027,13 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
             sc.n_total = __builtin_amdgcn_readfirstlane(do_run ? sc.n_total : 0);
             sc.break_on_tear = __builtin_amdgcn_readfirstlane(sc.break_on_tear);
         }
-        int done = 0;
+        int done = resumed_run ? resume_done : 0;
+        int it_next = -1;                  // >= 0: the time slice ended inside this run, which continues there in the next launch
         {
         const T dz_up = (T)sc.dz_up, dxp = (T)sc.dx_pull, dyp = (T)sc.dy_pull, dzp = (T)sc.dz_pull;
-    for (int it = 0; it < sc.n_total; it++) {
+        const bool sliced = FUSED && Fp->budget_ticks != 0 && Fp->resume != nullptr;
+    for (int it = resumed_run ? resume_it : 0; it < sc.n_total; it++) {
+
         // ---- ClothEnv._pull (cloth_env.py:352-367): adjust / nothing / release -------------------
         int mode = 0; T ax = 0, ay = 0, az = 0;
         if (it < sc.n_up_end) { mode = 1; az = dz_up; }
@@ -1287,6 +1347,11 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                 cur[i] = Pt<T>{px + cx * k.one_m_fric, py + cy * k.one_m_fric, pz + cz * k.one_m_fric, me.w};
             }
         }
+        if (FUSED && sliced) {             // thread 0 looks at the clock here, between two barriers that every thread passes in
+                                           // every substep; everyone reads its verdict at the end of the substep
+            const bool over = __builtin_amdgcn_s_memrealtime() - t_launch >= Fp->budget_ticks;
+            if (tid == 0) misc[7] = over ? 1 : 0;
+        }
         __syncthreads();
 
         TSTAMP(7)
@@ -1584,13 +1649,28 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
         if (timing) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory"); }
         done++;
         if (sc.break_on_tear && misc[0]) break;                                            // cloth_env.py:511-514
+        if (FUSED && sliced && misc[7] && it + 1 < sc.n_total) { it_next = it + 1; break; }
     }
         }   // the run
+        resume_it = -1;
         if (!fused) { done_nf = done; break; }
         // ---- after the run: everything is re-read from LDS -----------------------------------------------------------
         {
             const FusedArgs<T> &F = *Fp;
             __syncthreads();
+            if (it_next >= 0) {                          // cut by the time slice: park the run and leave
+                if (tid == 0) {
+                    eps->done_total += done - (resumed_run ? resume_done : 0);
+                    EpResume *rs_ = F.resume + e;
+                    rs_->valid = 1; rs_->it = it_next; rs_->done_partial = done; rs_->sc = sc; rs_->eps = *eps;
+                    if (eps->rp >= 0 && F.resets != nullptr) {
+                        ClothResetRecord *rr_ = F.resets + ((size_t)e * F.n_scripts + eps->n_resets);
+                        rs_->rr = *rr_; rr_->consumed = 2;
+                    }
+                }
+                __syncthreads();
+                break;
+            }
             const int tear_now = __builtin_amdgcn_readfirstlane(misc[0]);
             const int op = eps->op, rp = eps->rp, t_slot = eps->t_slot, n_resets = eps->n_resets;
             double mo[4] = {0.0, 0.0, 0.0, 0.0};
@@ -1611,7 +1691,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
             }
             if (tid == 0) {
                 if (F.budget_ticks != 0 && __builtin_amdgcn_s_memrealtime() - t_launch >= F.budget_ticks) eps->stop = 1;
-                eps->done_total += done;
+                eps->done_total += done - (resumed_run ? resume_done : 0);
                 if (op == OP_ACTION) {
                     const int ep_steps = eps->ep_steps + 1;
                     const bool oob_ = mo[2] != 0.0;

@@ -65,6 +65,7 @@ struct clothhip_handle {
     // clothhip_run_actions staging (device), grown on demand
     void *d_fz = nullptr, *d_fact = nullptr, *d_fscr = nullptr, *d_frec = nullptr, *d_frst = nullptr, *d_fobs = nullptr, *d_frobs = nullptr;
     int32_t *d_fsteps = nullptr, *d_fparg = nullptr;
+    EpResume *d_resume = nullptr;   // [E] operations cut by a time slice (clothhip_run_actions), continued by the next launch
     uint32_t *d_fmt = nullptr;      // [E][MT_WORDS] numpy RandomState of every env (device-drawn resets)
     uint8_t *d_fdone = nullptr;
     int f_T = 0; size_t f_nscr = 0; bool f_pending = false, f_resets = false, f_obs = false, f_robs = false, f_mt = false;
@@ -163,7 +164,7 @@ static void free_handle(clothhip_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_pos, h->d_prev, h->d_rest, h->d_cnt, h->d_active, h->d_tear, h->d_exec, h->d_ngrab, h->d_stats,
-                    h->d_sched, h->d_flat, h->d_flat_rest, h->d_hcnt, h->d_fz, h->d_fact, h->d_fscr, h->d_frec, h->d_frst, h->d_fobs, h->d_frobs, h->d_fsteps, h->d_fparg, h->d_fdone, h->d_fmt, h->d_gather, h->d_lv_ent, h->d_lv_off, h->d_lv_off8, h->d_pt_lev, h->d_levels, h->d_xy, h->d_radius, h->d_cov, h->d_vinv, h->d_oob};
+                    h->d_sched, h->d_flat, h->d_flat_rest, h->d_hcnt, h->d_fz, h->d_fact, h->d_fscr, h->d_frec, h->d_frst, h->d_fobs, h->d_frobs, h->d_fsteps, h->d_fparg, h->d_fdone, h->d_fmt, h->d_resume, h->d_gather, h->d_lv_ent, h->d_lv_off, h->d_lv_off8, h->d_pt_lev, h->d_levels, h->d_xy, h->d_radius, h->d_cov, h->d_vinv, h->d_oob};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->h_sched) (void)hipHostFree(h->h_sched);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -244,6 +245,8 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
     HC(hipMalloc(&h->d_vinv, E * 8));
     HC(hipMalloc(&h->d_oob, E));
     HC(hipMalloc(&h->d_hcnt, E * 4));
+    HC(hipMalloc(&h->d_resume, E * sizeof(EpResume)));
+    HC(hipMemset(h->d_resume, 0, E * sizeof(EpResume)));
     HC(hipMalloc(&h->d_flat, (size_t)3 * h->Ppad * h->tsz));
     HC(hipMalloc(&h->d_flat_rest, (size_t)h->Spad * h->tsz));
     HC(hipMemcpy(h->d_gather, gather.data(), gather.size() * 4, hipMemcpyHostToDevice));
@@ -340,6 +343,13 @@ extern "C" int clothhip_num_envs(const clothhip_handle *h) { return h ? h->E : f
 extern "C" int clothhip_precision(const clothhip_handle *h) { return h ? h->precision : fail(CLOTHHIP_EINVAL, "handle is NULL"); }
 extern "C" void *clothhip_stream(clothhip_handle *h) { return h ? (void *)h->stream : nullptr; }
 
+// Any state change from outside the episode launches (uploads, resets, grabs, raw schedules) voids the operations a time
+// slice left in flight.
+static int drop_in_flight(clothhip_handle *h) {
+    if (h->d_resume) HIPCHECK(hipMemsetAsync(h->d_resume, 0, (size_t)h->E * sizeof(EpResume), h->stream));
+    return 0;
+}
+
 static int check_range(const clothhip_handle *h, int env0, int n) {
     if (!h) return fail(CLOTHHIP_EINVAL, "handle is NULL");
     if (env0 < 0 || n < 0 || env0 + n > h->E) return fail(CLOTHHIP_EINVAL, "env range [%d,%d) outside [0,%d)", env0, env0 + n, h->E);
@@ -366,6 +376,7 @@ template <typename T> static void soa_to_aos(const T *src, double *dst, int n, i
 extern "C" int clothhip_set_state(clothhip_handle *h, int32_t env0, int32_t n, const double *pos, const double *prev,
                                   const uint8_t *pinned, const double *rest, int32_t flags) {
     if (int rc = check_range(h, env0, n)) return rc;
+    if (int rc = drop_in_flight(h)) return rc;
     const bool rest_shared = (flags & CLOTHHIP_REST_SHARED) != 0;
     HIPCHECK(hipSetDevice(h->device));
     HIPCHECK(hipStreamSynchronize(h->stream));
@@ -451,6 +462,7 @@ extern "C" int clothhip_get_rest(clothhip_handle *h, int32_t env0, int32_t n, do
 extern "C" int clothhip_reset_flat(clothhip_handle *h, const uint8_t *mask) {
     if (!h) return fail(CLOTHHIP_EINVAL, "handle is NULL");
     HIPCHECK(hipSetDevice(h->device));
+    if (int rc = drop_in_flight(h)) return rc;
     if (mask) HIPCHECK(hipMemcpyAsync(h->d_active, mask, (size_t)h->E, hipMemcpyHostToDevice, h->stream));
     if (h->precision == CLOTHHIP_F64)
         hipLaunchKernelGGL(k_reset_flat<double>, dim3(h->E), dim3(256), 0, h->stream, (double *)h->d_pos, (double *)h->d_prev, h->d_cnt,
@@ -489,6 +501,7 @@ static int do_grab(clothhip_handle *h, const double *xy, const double *radius, c
                    int32_t *n_grabbed, int top) {
     if (!h || !xy) return fail(CLOTHHIP_EINVAL, "NULL argument");
     HIPCHECK(hipSetDevice(h->device));
+    if (int rc = drop_in_flight(h)) return rc;
     HIPCHECK(hipMemcpyAsync(h->d_xy, xy, (size_t)h->E * 16, hipMemcpyHostToDevice, h->stream));
     if (radius) HIPCHECK(hipMemcpyAsync(h->d_radius, radius, (size_t)h->E * 8, hipMemcpyHostToDevice, h->stream));
     if (active) HIPCHECK(hipMemcpyAsync(h->d_active, active, (size_t)h->E, hipMemcpyHostToDevice, h->stream));
@@ -585,6 +598,7 @@ template <typename T, bool FUSED> static void launch_run(clothhip_handle *h, con
 }
 
 static int run_common(clothhip_handle *h, const ClothSchedule *d_sched) {
+    if (int rc = drop_in_flight(h)) return rc;
     HIPCHECK(hipEventRecord(h->ev0, h->stream));
     if (h->precision == CLOTHHIP_F64) launch_run<double, false>(h, d_sched, nullptr);
     else launch_run<float, false>(h, d_sched, nullptr);
@@ -650,6 +664,7 @@ template <typename T> static void fill_fused(clothhip_handle *h, FusedArgs<T> &f
     f.lv_ent = h->d_lv_ent; f.lv_off = h->d_lv_off; f.lv_off8 = h->d_lv_off8; f.pt_lev = h->d_pt_lev;
     f.rest = (const T *)h->d_rest; f.rest_stride = h->rest_stride;
     f.levels = h->d_levels; f.n_glevels = h->n_grab_levels; f.E = h->E; f.n_scripts = n_scripts; f.budget_ticks = budget_ticks;
+    f.resume = h->d_resume;
     f.mt = have_mt ? h->d_fmt : nullptr; f.rng_tier = rng_tier; f.domrand_words = domrand_words;
     f.two_thickness = 2 * h->prm.thickness; f.half_thickness = h->prm.thickness / 2.0;
     f.ep = *ep;

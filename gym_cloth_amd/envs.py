@@ -453,6 +453,7 @@ class ClothVecEnv(object):
             for e in range(E):
                 st = self.np_randoms[e].get_state()
                 mt[e, :624], mt[e, 624], gauss[e] = st[1], st[2], st[3:]
+            mt_before = mt.copy()
         parg = None
         if pol == _lib.POLICY_ORACLE_CORNER and self._init_type == 'tier2':
             parg = (~self.init_side).astype(np.int32)                                    # analytic.py:108-114
@@ -508,16 +509,20 @@ class ClothVecEnv(object):
             out['variance_inv'][t], out['start_variance_inv'][t] = r['variance_inv'], self._start_variance_inv
             out['have_tear'][t], out['out_of_bounds'][t] = self.have_tear, oob
         if dev_reset:                                                 # a time slice may end right after a reset
-            tail = np.nonzero(rst['consumed'].sum(axis=1) > n_consumed)[0]
+            tail = np.nonzero((rst['consumed'] == 1).sum(axis=1) > n_consumed)[0]
             if len(tail):
                 rb = np.zeros(E, dtype=np.int64)
                 rb[tail] = n_consumed[tail] + 1
                 out['tail_reset_substeps'] = np.zeros(E, dtype=np.int64)
                 self._apply_reset_records(tail, rb, rst, n_consumed, out['tail_reset_substeps'], use_rng)
-        assert np.array_equal(self.num_steps.astype(np.int32), nsteps) and np.array_equal(self._ep_done, done_io != 0)
+        # the device's view of the episode state must be the host's, except where a time slice cut a reset in the middle (the
+        # device has already zeroed that env's counters; the host learns of the reset from the launch that completes it)
+        settled = np.ones(E, dtype=bool) if rst is None else ~(rst['consumed'] == 2).any(axis=1)
+        assert np.array_equal(self.num_steps.astype(np.int32)[settled], nsteps[settled])
+        assert np.array_equal(self._ep_done[settled], (done_io != 0)[settled])
         _lap('bookkeeping')
-        if use_rng:                                                   # the streams as the device left them
-            for e in np.nonzero(n_consumed)[0]:
+        if use_rng:                                                   # the streams as the device left them (a reset cut by the
+            for e in np.nonzero((mt != mt_before).any(axis=1))[0]:    # time slice has drawn too, before any record of it is complete)
                 self.np_randoms[e].set_state(('MT19937', mt[e, :624], int(mt[e, 624])) + tuple(gauss[e]))
         elif dev_reset:                                               # commit the RNG draws the device consumed
             for e in np.nonzero(n_consumed)[0]:

@@ -219,7 +219,7 @@ typedef struct ClothStepRecord {
 
 /* one consumed reset script */
 typedef struct ClothResetRecord {
-    int32_t consumed;                /* 0 / 1 */
+    int32_t consumed;                /* 0 no; 1 yes (complete record); 2 cut by the time slice, completed by the next launch */
     int32_t pulls_run;               /* scripted pulls executed (tier 1: 2 or 3) */
     int32_t executed[3];             /* update() calls of each pull */
     int32_t settle_executed;
@@ -242,8 +242,12 @@ typedef struct ClothResetRecord {
  * time_budget_ms > 0 makes the launch a TIME SLICE: an env starts no further action once the launch has run that long
  * (constant-rate 100 MHz clock), so envs advance at their own pace and the launch does not wait for the env with the most
  * work; the unused slots of an env stay `ran == 0` at the END of its column and the caller passes those actions again in
- * the next launch; a slice may also end right after a reset (ClothResetRecord.consumed set, no record with that
- * reset_before). Which launch executes an action never changes its result (envs are independent); only the partition
+ * the next launch. The slice cuts operations in the middle (at a substep boundary): the handle keeps what is needed to
+ * continue them, the next launch does so first, and the action's record appears in the launch that completes it (slot 0
+ * of that env). A reset cut that way has consumed == 2 in this launch's record and its complete record (consumed == 1) in the
+ * next one's slot 0; a slice may also end right after a reset (consumed == 1, no record with that reset_before). Any
+ * other state-changing call on the handle (set_state, reset_flat, grab*, run*, update) drops the operations in flight.
+ * Which launch executes an action never changes its result (envs are independent); only the partition
  * of an env's action sequence into launches depends on timing. 0 = every env executes all T slots.
  * Returns CLOTHHIP_ESTATE when the handle's variant cannot run fused (per-env rest tables with reset scripts,
  * non-25x25 oracle policy, grid too large for the in-kernel metrics). Synchronous. */

@@ -164,8 +164,8 @@ def test_time_sliced_launches_give_the_same_trajectories_f64():
     while (cnt < N).any():
         idx = np.minimum(cnt[None, :] + np.arange(slots)[:, None], N - 1)
         tbl = streams[np.arange(E)[None, :], idx]
-        # an env that has used up its stream must not act again: a budget of ~3 ms ends every env after 1-2 actions anyway
-        out = b.step_many(tbl, max_resets=8, time_budget_ms=3.0)
+        # ~25 ms per slice: every launch cuts the running action or reset of every env somewhere in the middle
+        out = b.step_many(tbl, max_resets=8, time_budget_ms=25.0)
         launches += 1
         for e in range(E):
             n_e = int(out["ran"][:, e].sum())
@@ -176,12 +176,27 @@ def test_time_sliced_launches_give_the_same_trajectories_f64():
                 cnt[e] = N + 1000
             else:
                 cnt[e] += n_e
-        assert launches < 200
-    assert launches > 2, "the budget must actually cut the sequences"
+        assert launches < 3000
+    assert launches > 10, "the budget must actually cut the sequences"
     for e in range(E):
         want = [(ref["rew"][t, e], bool(ref["done"][t, e]), int(ref["executed"][t, e])) for t in range(N) if ref["ran"][t, e]]
         n = min(len(want), len(got[e]))
         assert n >= 2 and got[e][:n] == want[:n], (e, got[e][:n], want[:n])
+    a.close(); b.close()
+
+
+def test_in_flight_operations_are_dropped_by_outside_state_changes():
+    """A time slice leaves operations in flight inside the handle; a host-side reset (or any other state upload) must void
+    them: the next launch then starts from the uploaded state like a fresh env."""
+    E = 4
+    acts = np.stack([np.random.RandomState(2000 + e).uniform(-0.5, 0.5, size=(3, 4)) for e in range(E)], axis=1)
+    a = _bench_env(E, "f64"); a.reset()
+    a.step_many(acts, time_budget_ms=5.0)                  # cut in the middle of the first action
+    a.reset()                                              # host-side reset: flat grid + scripted pulls, in-flight ops dropped
+    b = _bench_env(E, "f64"); b.reset(); b.reset()         # same RNG consumption: two host resets
+    oa = a.step_many(acts)
+    ob = b.step_many(acts)
+    assert np.array_equal(oa["rew"], ob["rew"]) and np.array_equal(oa["obs"], ob["obs"])
     a.close(); b.close()
 
 
