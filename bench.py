@@ -325,8 +325,9 @@ def main():
                   init=args.init, mode="step" if args.mode == "fused" else "fused", steps=10, warmup=5, fuse_max=10,
                   step_ms=args.step_ms, **k5)
         if args.init != "tier2":
-            companion("BASELINE configs[3] shape: tier-2 start, 512 cloths per GPU (per-env rest tables; resets on the host)",
-                      n_side=25, E=512, precision=args.precision, init="tier2", mode="step", steps=5, warmup=1, fuse_max=1, **k5)
+            companion("BASELINE configs[3] shape: tier-2 start and tier-2 episode resets (per-env rest tables), 512 cloths per GPU",
+                      n_side=25, E=512, precision=args.precision, init="tier2", mode=args.mode, steps=10, warmup=5, fuse_max=10,
+                      step_ms=args.step_ms, **k5)
         if args.envs < 2048 and args.n_side == 25:
             companion("2048 cloths per GPU (4 resident generations of workgroups per launch)", n_side=25, E=2048,
                       precision=args.precision, init="tier1", mode="fused", steps=5, warmup=0, fuse_max=5,

@@ -106,6 +106,13 @@ class ClothBatch(object):
         check(self._L.clothhip_get_rest(self._h, env0, n, _lib.dp(rest)))
         return rest
 
+    def ensure_per_env_rest(self):
+        """Give every env its own rest-length table (what tier 2 needs: cloth.pyx:417 measures them on the noisy sheet);
+        a no-op once done. The tables start as copies of the current ones."""
+        if not getattr(self, "_per_env_rest", False):
+            self.set_state(rest=self.get_rest(), rest_shared=False)
+            self._per_env_rest = True
+
     def reset_flat(self, mask=None):
         """Cloth(...) rebuild of the flat tiers (1, 3) on the device for the masked envs (None = all)."""
         m = None if mask is None else np.ascontiguousarray(np.broadcast_to(np.asarray(mask, dtype=np.uint8), (self.E,)))

@@ -65,6 +65,8 @@ template <typename T> struct FusedArgs {
     // copies of StepArgs' static-table pointers: the LDS re-initialisation after the in-kernel metrics loads them from
     // here (plain global loads at the point of use) instead of keeping the kernel arguments alive across the substep loop
     const uint32_t *lv_ent; const uint16_t *lv_off, *lv_off8, *pt_lev; const T *rest; int32_t rest_stride, _pad3;
+    T *rest_rw;                       // the same table, writable: a tier-2 reset rebuilds the env's rest lengths (cloth.pyx:417)
+    double grid_dx, grid_dy;          // width / (N - 1), height / (N - 1) (cloth.pyx:55-56)
     uint32_t *mt;                     // [E][MT_WORDS] numpy RandomState of every env, or nullptr (resets come from `scripts`)
     uint64_t domrand_words;           // 32-bit words the domain-randomisation draws after a reset consume (cloth_env.py:786-789), or 0
     int32_t rng_tier, _pad2;          // with mt: 1 or 3, the reset procedure to draw (cloth_env.py:843-891, :951-982)
@@ -87,7 +89,9 @@ struct EpState {
     int32_t op, n_grab, iters_pull, decode_err;
     int32_t done_total;
     int32_t stop;          // the launch's time slice is used up: no new action or reset starts
-    int32_t side, _pad;    // device-RNG resets: Cloth.init_side of the reset in progress (cloth.pyx:75)
+    int32_t side;          // device-RNG resets: Cloth.init_side of the reset in progress (cloth.pyx:75)
+    int32_t choice;        // tier-2 reset: the corner picked for the first pull (-25 or -1, cloth_env.py:907)
+    int32_t swap, _pad;    // oracle-corner policy: corner indices swapped (tier-2 cloth with init_side False, analytic.py:108-114)
     double act[4];
     ClothResetPull pull;   // device-RNG resets: the draws of the pull being executed
 };
@@ -225,7 +229,7 @@ struct LdsLayout {
         int o = 0;
         auto take = [&](int bytes) { int r = o; o += (bytes + 15) / 16 * 16; return r; };
         cur = take(4 * Ppad * tsz);
-        eps = take(160);             // EpState (fused episodes)
+        eps = take(176);             // EpState (fused episodes)
         ent = take(tab >= 1 ? Spad * 4 : 0);
         rest = take(tab >= 1 ? Spad * tsz : 0);
         off = take(tab >= 1 ? (nL + 40) * 2 : 0);       // padded: levels past the end are empty
@@ -611,8 +615,10 @@ __device__ __forceinline__ void metrics_block(const Src &src, int P, int NS, int
 // registers for the whole schedule, as do the particle's static gather entries (and, with REST_REG, the rest
 // lengths of its incident springs). Only the current positions are shared, through LDS.
 //   TAB: 0 static tables in global memory, 1 ent/rest/offsets in LDS, 2 also the per-point level table.
-//   FUSED: whole episodes per launch (clothhip_run_actions); false = one externally decoded schedule per env (clothhip_run).
-template <typename T, int NT, int PPT, int TAB, bool REST_REG, bool FUSED>
+//   FUSED: 0 = one externally decoded schedule per env (clothhip_run); 1 = whole episodes per launch (clothhip_run_actions)
+//          with the resets of the flat tiers 1 and 3; 2 = also tier-2 resets. (The tier-2 reset code is cold, but its presence
+//          costs the substep loop registers: -7 % on the headline workload, so it is compiled in only where it is asked for.)
+template <typename T, int NT, int PPT, int TAB, bool REST_REG, int FUSED>
 __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule(StepArgs<T> A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int e = blockIdx.x;
@@ -621,7 +627,8 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
     // fz == nullptr: ONE externally decoded schedule per env (clothhip_run). Otherwise: nT whole ClothEnv.step calls per env with
     // action decoding, grab_top, metrics, terminal test and episode resets in the kernel (clothhip_run_actions).
     const FusedArgs<T> *const Fp = A.fz;
-    constexpr bool fused = FUSED;
+    constexpr bool fused = FUSED != 0;
+    constexpr bool with_tier2 = FUSED == 2;
     ClothSchedule sc;
     if (!fused) {
         sc = A.sched[e];
@@ -738,12 +745,13 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
             eps->t_slot = 0; eps->rp = -1; eps->n_resets = 0; eps->chain_ok = 1; eps->rs_pulls = 0; eps->reset_mark = 0;
             eps->ep_steps = Fp->num_steps[e]; eps->ep_done = Fp->done[e] ? 1 : 0; eps->done_total = 0; eps->stop = 0;
             misc[7] = 0;
+            eps->swap = (Fp->policy_arg != nullptr && Fp->policy_arg[e] != 0) ? 1 : 0; eps->choice = 0;
             if (Fp->resume != nullptr && Fp->resume[e].valid) {        // continue the operation the previous time slice cut
                 const EpResume *rs_ = Fp->resume + e;
                 const EpState &o = rs_->eps;
                 eps->rp = o.rp; eps->chain_ok = o.chain_ok; eps->rs_pulls = o.rs_pulls; eps->ep_steps = o.ep_steps;
                 eps->ep_done = o.ep_done; eps->op = o.op; eps->n_grab = o.n_grab; eps->iters_pull = o.iters_pull;
-                eps->decode_err = o.decode_err; eps->side = o.side; eps->pull = o.pull;
+                eps->decode_err = o.decode_err; eps->side = o.side; eps->pull = o.pull; eps->choice = o.choice; eps->swap = o.swap;
                 eps->act[0] = o.act[0]; eps->act[1] = o.act[1]; eps->act[2] = o.act[2]; eps->act[3] = o.act[3];
                 if (o.rp >= 0 && Fp->resets != nullptr) Fp->resets[(size_t)e * Fp->n_scripts] = rs_->rr;   // its record, now slot 0
             }
@@ -786,10 +794,10 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
             // proceeds, in the reference's order; its shape depends on the tier only
             uint32_t *const mt = F.mt ? F.mt + (size_t)e * MT_WORDS : nullptr;
             const bool rngm = mt != nullptr;
-            const int tier = F.rng_tier;
-            auto s_n_pulls = [&]() { return rngm ? (tier == 1 ? 3 : 1) : scr->n_pulls; };
-            auto s_settle = [&]() { return rngm ? (tier == 3 ? 800 : 0) : scr->settle_after; };
-            auto s_need_cov = [&](int p_) { return rngm ? (tier == 1 && p_ == 2) : (scr->pull[p_].need_coverage != 0); };
+            const int tier = with_tier2 ? F.rng_tier : (F.rng_tier == 3 ? 3 : 1);
+            auto s_n_pulls = [&]() { return rngm ? (tier == 1 ? 3 : (tier == 2 ? 2 : 1)) : scr->n_pulls; };
+            auto s_settle = [&]() { return rngm ? (tier == 3 ? 800 : (tier == 2 ? 500 : 0)) : scr->settle_after; };
+            auto s_need_cov = [&](int p_) { return rngm ? (tier == 1 && p_ == 2) : ((scr->pull[p_].need_coverage & 1) != 0); };
             int op = OP_ACTION;
             bool do_decode = false;
             double act[4] = {0.0, 0.0, 0.0, 0.0};
@@ -805,20 +813,73 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                 if (eps->ep_done) {
                     __syncthreads();                     // everyone has read the state
                     if (rngm ? (n_resets < F.n_scripts) : (scr != nullptr && scr->valid)) {
-                        // the Cloth(...) rebuild of ClothEnv.reset (cloth_env.py:737-746): flat grid, nothing pinned, no tear
-                        for (int i = tid; i < Ppad; i += NT)
-                            cur[i] = Pt<T>{F.flat[i], F.flat[Ppad + i], F.flat[2 * Ppad + i], w_make<T>(0u)};
+                        // the Cloth(...) rebuild of ClothEnv.reset (cloth_env.py:737-746): nothing pinned, no tear
+                        int side_ = 0;
+                        bool t2_ = false;
+                        if constexpr (with_tier2) t2_ = rngm && tier == 2;
+                        if constexpr (with_tier2) if (t2_) {
+                            // tier 2 (cloth.pyx:94-116): a vertical sheet at x = |noise| (init_side) or 1 - |noise|, one rand()
+                            // per point in r-major order (row 0 draws too, its noise is zeroed), and rest lengths measured on
+                            // these positions (cloth.pyx:417) -- in double, as the host's clothhip_init_grid does, through a
+                            // scratch copy behind the particle records
+                            double *dpos = reinterpret_cast<double *>(smem + lay.ent);
+                            if (tid == 0) {
+                                side_ = mt_double(mt) > 0.5 ? 1 : 0;                             // cloth.pyx:75
+                                const int N_ = A.N;
+                                for (int r_ = 0; r_ < N_; r_++)
+                                    for (int c_ = 0; c_ < N_; c_++) {
+                                        double noise = mt_double(mt) * 0.01 - 0.005;             // :101
+                                        if (r_ == 0) noise = 0;                                  // :102-103
+                                        const int i = r_ * N_ + c_;
+                                        dpos[3 * i] = side_ ? 0.0 + fabs(noise) : 1.0 - fabs(noise);   // :104-107
+                                        dpos[3 * i + 1] = F.grid_dx * c_; dpos[3 * i + 2] = F.grid_dy * r_;   // :109-110
+                                    }
+                                eps->side = side_;
+                            }
+                            __syncthreads();
+                            side_ = eps->side;
+                            for (int i = tid; i < Ppad; i += NT)
+                                cur[i] = i < P ? Pt<T>{(T)dpos[3 * i], (T)dpos[3 * i + 1], (T)dpos[3 * i + 2], w_make<T>(0u)}
+                                               : Pt<T>{(T)0, (T)0, (T)0, w_make<T>(0u)};
 #pragma unroll
-                        for (int q = 0; q < PPT; q++) {
-                            const int i = tid + q * NT;
-                            if (i < P) { pvx[q] = F.flat[i]; pvy[q] = F.flat[Ppad + i]; pvz[q] = F.flat[2 * Ppad + i]; }
+                            for (int q = 0; q < PPT; q++) {
+                                const int i = tid + q * NT;
+                                if (i < P) { pvx[q] = (T)dpos[3 * i]; pvy[q] = (T)dpos[3 * i + 1]; pvz[q] = (T)dpos[3 * i + 2]; }
+                            }
+                            T *rw = F.rest_rw + (size_t)e * F.rest_stride;
+                            for (int p_ = tid; p_ < A.S; p_ += NT) {
+                                const uint32_t en = F.lv_ent[p_];
+                                const double *PA = dpos + 3 * (en & 0xFFFFu), *PB = dpos + 3 * (en >> 16);
+                                const double ux = PA[0] - PB[0], uy = PA[1] - PB[1], uz = PA[2] - PB[2];
+                                rw[p_] = (T)sqrt(ux * ux + uy * uy + uz * uz);                    // cloth.pyx:417 via :17-18
+                            }
+                            __syncthreads();
+                            init_lds(0, F.lv_ent, F.rest + (size_t)e * F.rest_stride, F.lv_off, F.lv_off8, F.pt_lev);
+                            if (REST_REG) {
+#pragma unroll
+                                for (int q = 0; q < PPT; q++)
+#pragma unroll
+                                    for (int sl = 0; sl < HK_SLOTS; sl++) {
+                                        const uint32_t g0 = GT_REG ? gt[GT_REG ? q : 0][sl] : 0u;
+                                        rr[REST_REG ? q : 0][sl] = rw[(g0 >> HK_POS_SHIFT) & HK_POS_MASK];
+                                    }
+                            }
+                        }
+                        if (!t2_) {
+                            for (int i = tid; i < Ppad; i += NT)
+                                cur[i] = Pt<T>{F.flat[i], F.flat[Ppad + i], F.flat[2 * Ppad + i], w_make<T>(0u)};
+#pragma unroll
+                            for (int q = 0; q < PPT; q++) {
+                                const int i = tid + q * NT;
+                                if (i < P) { pvx[q] = F.flat[i]; pvy[q] = F.flat[Ppad + i]; pvz[q] = F.flat[2 * Ppad + i]; }
+                            }
                         }
                         if (tid == 0) {
                             misc[0] = 0;
-                            eps->rp = 0; eps->rs_pulls = 0; eps->ep_steps = 0; eps->ep_done = 0;
-                            int side_ = 0;
-                            if (rngm) side_ = mt_double(mt) > 0.5 ? 1 : 0;                       // cloth.pyx:75
+                            eps->rp = t2_ ? 8 : 0; eps->rs_pulls = 0; eps->ep_steps = 0; eps->ep_done = 0;
+                            if (rngm && !t2_) side_ = mt_double(mt) > 0.5 ? 1 : 0;               // cloth.pyx:75
                             eps->side = side_;
+                            if (t2_) eps->swap = side_ ? 0 : 1;
                             if (F.resets) {
                                 ClothResetRecord *rr_ = F.resets + ((size_t)e * F.n_scripts + n_resets);
                                 rr_->init_side = side_;
@@ -838,7 +899,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                 if (F.policy == CLOTHHIP_POLICY_ORACLE_CORNER) {
                     // examples/analytic.py:105-155 ('distance' method, delta actions): pull the inset corner that is
                     // farthest from its plane corner; candidates in the order ur, lr, ll, ul, the first maximum wins
-                    const bool sw = F.policy_arg != nullptr && F.policy_arg[e] != 0;     // tier 2, init_side False (:108-114)
+                    const bool sw = eps->swap != 0;                                       // tier 2, init_side False (:108-114)
                     double best = -1.0;
 #pragma unroll
                     for (int c = 0; c < 4; c++) {
@@ -873,6 +934,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                     break;
                 }
                 for (;;) {                               // skip the stages this script does not have
+                    if (with_tier2 && rp == 8) break;    // tier 2: 1500 updates before the pulls (cloth_env.py:902-903)
                     if (rp < 6) {
                         const int p_ = rp >> 1;
                         if (p_ >= s_n_pulls()) { rp = 6; continue; }
@@ -881,7 +943,12 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                     if (rp == 6 && s_settle() <= 0) { rp = 7; continue; }
                     break;
                 }
-                if (rp < 6 && !(rp & 1)) op = OP_RESET_COND;
+                if (with_tier2 && rp == 8) {
+                    op = OP_RESET_SETTLE; do_run = true;
+                    sc.n_up_end = sc.n_uprest_end = sc.n_pull_end = 0;
+                    sc.n_griprest_end = sc.n_total = 1500;
+                    sc.break_on_tear = 0;
+                } else if (rp < 6 && !(rp & 1)) op = OP_RESET_COND;
                 else if (rp < 6) {
                     op = OP_RESET_PULL; do_decode = true;
                     if (rngm) {                          // draw this pull now (cloth_env.py:851-877 tier 1, :959-972 tier 3)
@@ -894,6 +961,23 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                                 d_.dx = mt_randval_minabs(mt, -0.20, 0.20, 0.08);
                                 d_.dy = mt_randval_minabs(mt, -0.20, 0.20, 0.08);
                                 d_.iters_up = F.ep.iters_up;
+                            } else if (with_tier2 && tier == 2) {   // cloth_env.py:905-947: hard-coded corner points, no _prevent_oob
+                                const double sd = eps->side ? 1.0 : -1.0;
+                                d_.need_coverage = 2;     // bit 1: no _prevent_oob
+                                d_.x = d_.y = 0.0;
+                                d_.iters_up = F.ep.iters_up;
+                                if ((rp >> 1) == 0) {
+                                    const int ch = mt_double(mt) < 0.5 ? -25 : -1;               // :907
+                                    eps->choice = ch;
+                                    d_.point = P + ch;
+                                    d_.dx = mt_uniform(mt, 0.30, 0.50) * sd;
+                                    d_.dy = ch == -25 ? mt_uniform(mt, 0.30, 0.60) : mt_uniform(mt, -0.60, -0.30);
+                                } else {
+                                    const bool c25 = eps->choice == -25;
+                                    d_.point = P + (c25 ? -19 : -7);
+                                    d_.dx = mt_uniform(mt, 0.30, 0.60) * sd;
+                                    d_.dy = c25 ? mt_uniform(mt, -0.30, -0.60) : mt_uniform(mt, 0.30, 0.60);
+                                }
                             } else {
                                 d_.iters_up = mt_uniform(mt, 200.0, 280.0);
                                 d_.point = -1;
@@ -912,8 +996,10 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                     if (pt_ >= 0) { const Pt<T> pp = cur[pt_ < P ? pt_ : 0]; px_ = (double)pp.x; py_ = (double)pp.y; }
                     // _prevent_oob (cloth_env.py:834-840)
                     double dx0 = pl->dx, dy0 = pl->dy;
-                    if (px_ + dx0 < 0.0) dx0 = 0.0 - px_; else if (px_ + dx0 > 1.0) dx0 = 1.0 - px_;
-                    if (py_ + dy0 < 0.0) dy0 = 0.0 - py_; else if (py_ + dy0 > 1.0) dy0 = 1.0 - py_;
+                    if (!(pl->need_coverage & 2)) {
+                        if (px_ + dx0 < 0.0) dx0 = 0.0 - px_; else if (px_ + dx0 > 1.0) dx0 = 1.0 - px_;
+                        if (py_ + dy0 < 0.0) dy0 = 0.0 - py_; else if (py_ + dy0 > 1.0) dy0 = 1.0 - py_;
+                    }
                     // _convert_action_to_clip_space (cloth_env.py:1207-1215), delta actions
                     act[0] = F.ep.clip_act_space ? (px_ - 0.5) * 2 : px_;
                     act[1] = F.ep.clip_act_space ? (py_ - 0.5) * 2 : py_;
@@ -1721,8 +1807,8 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                         }
                         eps->rs_pulls += 1; eps->rp = rp + 1;
                     } else if (op == OP_RESET_SETTLE) {
-                        if (rr_) rr_->settle_executed = done;
-                        eps->rp = 7;
+                        if (rr_) rr_->settle_executed += done;
+                        eps->rp = (with_tier2 && rp == 8) ? 0 : 7;
                     } else {                                                                      // OP_RESET_END
                         if (rr_) { rr_->start_coverage = mo[0]; rr_->start_variance_inv = mo[1]; rr_->tear = tear_now; }
                         // a conditional pull that ran consumed RNG draws the later scripts were drawn without (clothhip.h)

@@ -173,7 +173,7 @@ static void free_handle(clothhip_handle *h) {
     delete h;
 }
 
-static const void *stepper_fn(const clothhip_handle *h, bool fused);
+static const void *stepper_fn(const clothhip_handle *h, int fused);
 
 extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_t device, int32_t precision,
                                clothhip_handle **out) {
@@ -301,9 +301,10 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
         if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) h->cell_copy = h->cell_copy && atoi(t);
         h->lds_bytes = LdsLayout(tsz, h->Ppad, h->Spad, h->lv.n_levels, h->n_levels8, h->HT, h->tab, h->cell_copy).total;
         if (h->lds_bytes > 160 * 1024) { free_handle(h); return fail(CLOTHHIP_EINVAL, "n_side %d needs %d B of LDS (> 160 KiB)", h->N, h->lds_bytes); }
-        const void *fn = stepper_fn(h, false), *fnf = stepper_fn(h, true);
-        if (!fn || !fnf) { free_handle(h); return fail(CLOTHHIP_EINVAL, "no stepper variant for n_side %d", h->N); }
+        const void *fn = stepper_fn(h, 0), *fnf = stepper_fn(h, 1), *fnf2 = stepper_fn(h, 2);
+        if (!fn || !fnf || !fnf2) { free_handle(h); return fail(CLOTHHIP_EINVAL, "no stepper variant for n_side %d", h->N); }
         HC(hipFuncSetAttribute(fnf, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HC(hipFuncSetAttribute(fnf2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         // the attribute is per kernel function and process-global: always the CU's full 160 KiB, so that a later handle
         // with a smaller footprint can never lower it under an earlier one
         HC(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -573,19 +574,20 @@ template <typename T> static StepArgs<T> make_args(clothhip_handle *h, const Clo
     X(T, 256, 3, 2, true) X(T, 256, 3, 2, false) X(T, 256, 3, 1, false) X(T, 256, 3, 0, false)   \
     X(T, 512, 5, 0, false) X(T, 512, 5, 1, false) X(T, 1024, 3, 0, false) X(T, 1024, 3, 1, false) X(T, 1024, 4, 0, false)
 
-template <typename T, bool FUSED> static const void *stepper_fn_t(const clothhip_handle *h) {
+template <typename T, int FUSED> static const void *stepper_fn_t(const clothhip_handle *h) {
 #define X(T_, NT, PPT, TAB, RR) \
     if (h->nt == NT && h->ppt == PPT && h->tab == TAB && h->rest_reg == RR) return (const void *)k_run_schedule<T_, NT, PPT, TAB, RR, FUSED>;
     CLOTH_VARIANTS(X, T)
 #undef X
     return nullptr;
 }
-static const void *stepper_fn(const clothhip_handle *h, bool fused) {
-    if (fused) return h->precision == CLOTHHIP_F64 ? stepper_fn_t<double, true>(h) : stepper_fn_t<float, true>(h);
-    return h->precision == CLOTHHIP_F64 ? stepper_fn_t<double, false>(h) : stepper_fn_t<float, false>(h);
+static const void *stepper_fn(const clothhip_handle *h, int fused) {
+    if (fused == 2) return h->precision == CLOTHHIP_F64 ? stepper_fn_t<double, 2>(h) : stepper_fn_t<float, 2>(h);
+    if (fused == 1) return h->precision == CLOTHHIP_F64 ? stepper_fn_t<double, 1>(h) : stepper_fn_t<float, 1>(h);
+    return h->precision == CLOTHHIP_F64 ? stepper_fn_t<double, 0>(h) : stepper_fn_t<float, 0>(h);
 }
 
-template <typename T, bool FUSED> static void launch_run(clothhip_handle *h, const ClothSchedule *d_sched, const void *d_fz) {
+template <typename T, int FUSED> static void launch_run(clothhip_handle *h, const ClothSchedule *d_sched, const void *d_fz) {
     StepArgs<T> a = make_args<T>(h, d_sched);
     a.fz = (const FusedArgs<T> *)d_fz;
 #define X(T_, NT, PPT, TAB, RR)                                                                         \
@@ -600,8 +602,8 @@ template <typename T, bool FUSED> static void launch_run(clothhip_handle *h, con
 static int run_common(clothhip_handle *h, const ClothSchedule *d_sched) {
     if (int rc = drop_in_flight(h)) return rc;
     HIPCHECK(hipEventRecord(h->ev0, h->stream));
-    if (h->precision == CLOTHHIP_F64) launch_run<double, false>(h, d_sched, nullptr);
-    else launch_run<float, false>(h, d_sched, nullptr);
+    if (h->precision == CLOTHHIP_F64) launch_run<double, 0>(h, d_sched, nullptr);
+    else launch_run<float, 0>(h, d_sched, nullptr);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipEventRecord(h->ev1, h->stream));
     h->have_timing = true;
@@ -662,7 +664,8 @@ template <typename T> static void fill_fused(clothhip_handle *h, FusedArgs<T> &f
     f.reset_obs = have_robs ? (float *)h->d_frobs : nullptr;
     f.flat = (const T *)h->d_flat;
     f.lv_ent = h->d_lv_ent; f.lv_off = h->d_lv_off; f.lv_off8 = h->d_lv_off8; f.pt_lev = h->d_pt_lev;
-    f.rest = (const T *)h->d_rest; f.rest_stride = h->rest_stride;
+    f.rest = (const T *)h->d_rest; f.rest_rw = (T *)h->d_rest; f.rest_stride = h->rest_stride;
+    f.grid_dx = h->prm.width * 1.0 / (h->N - 1); f.grid_dy = h->prm.height * 1.0 / (h->N - 1);
     f.levels = h->d_levels; f.n_glevels = h->n_grab_levels; f.E = h->E; f.n_scripts = n_scripts; f.budget_ticks = budget_ticks;
     f.resume = h->d_resume;
     f.mt = have_mt ? h->d_fmt : nullptr; f.rng_tier = rng_tier; f.domrand_words = domrand_words;
@@ -709,10 +712,14 @@ extern "C" int clothhip_run_actions_begin(clothhip_handle *h, const ClothEpisode
         return fail(CLOTHHIP_ESTATE, "the oracle-corner policy is defined for 25x25 cloths only (analytic.py:106)");
     if ((scripts || rng_states) && (n_scripts < 1 || n_scripts > 255)) return fail(CLOTHHIP_EINVAL, "n_scripts must be in [1, 255]");
     if (scripts && rng_states) return fail(CLOTHHIP_EINVAL, "resets come either from scripts or from the device-side RNG streams, not both");
-    if (rng_states && rng_tier != 1 && rng_tier != 3) return fail(CLOTHHIP_EINVAL, "device-drawn resets exist for tiers 1 and 3");
+    if (rng_states && (rng_tier < 1 || rng_tier > 3)) return fail(CLOTHHIP_EINVAL, "rng_tier must be 1, 2 or 3");
     if (!scripts && !rng_states) n_scripts = 0;
-    if ((scripts || rng_states) && h->rest_stride != 0)
-        return fail(CLOTHHIP_ESTATE, "in-kernel resets need the shared flat rest table (tiers 1 and 3); this handle has per-env rest lengths");
+    const bool tier2 = rng_states && rng_tier == 2;
+    if ((scripts || rng_states) && !tier2 && h->rest_stride != 0)
+        return fail(CLOTHHIP_ESTATE, "in-kernel resets of the flat tiers need the shared flat rest table; this handle has per-env rest lengths");
+    if (tier2 && h->rest_stride == 0)
+        return fail(CLOTHHIP_ESTATE, "in-kernel tier-2 resets rebuild per-env rest lengths; upload per-env rest tables first (clothhip_set_state without CLOTHHIP_REST_SHARED)");
+    if (tier2 && (size_t)3 * h->P * 8 > (size_t)160 * 1024) return fail(CLOTHHIP_ESTATE, "grid too large for the tier-2 reset scratch");
     if (!(ep->reduce_factor > 0) || ep->max_actions < 1) return fail(CLOTHHIP_EINVAL, "bad episode parameters");
     int NS = 1; while (NS < h->P) NS <<= 1;
     const int NH = h->Ppad + 8;
@@ -770,8 +777,11 @@ extern "C" int clothhip_run_actions_begin(clothhip_handle *h, const ClothEpisode
     HIPCHECK(hipMemcpyAsync(h->d_fz, fzbuf, 1024, hipMemcpyHostToDevice, h->stream));
     HIPCHECK(hipStreamSynchronize(h->stream));          // fzbuf is on this stack frame
     HIPCHECK(hipEventRecord(h->ev0, h->stream));
-    if (h->precision == CLOTHHIP_F64) launch_run<double, true>(h, h->d_sched, h->d_fz);
-    else launch_run<float, true>(h, h->d_sched, h->d_fz);
+    if (tier2) {                                        // the variant that also carries the tier-2 reset code
+        if (h->precision == CLOTHHIP_F64) launch_run<double, 2>(h, h->d_sched, h->d_fz);
+        else launch_run<float, 2>(h, h->d_sched, h->d_fz);
+    } else if (h->precision == CLOTHHIP_F64) launch_run<double, 1>(h, h->d_sched, h->d_fz);
+    else launch_run<float, 1>(h, h->d_sched, h->d_fz);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipEventRecord(h->ev1, h->stream));
     h->have_timing = true;

@@ -399,11 +399,10 @@ class ClothVecEnv(object):
         run in the kernel, envs never wait for each other, and the host only does the reward / info bookkeeping below.
 
         actions: float64[T, E, 4], or policy='oracle_corner' (examples/analytic.py's oracle, evaluated on the device)
-        with n_actions=T. Resets inside the launch need init type tier1 or tier3 (tier 2 rebuilds per-env rest lengths
-        on the host): with tier2, or auto_reset=False, an env whose episode ends idles for the rest of the launch
-        (`ran` False). Up to `max_resets` (default T) resets per env and launch. The resets are drawn on the device from
+        with n_actions=T. With auto_reset=False an env whose episode ends idles for the rest of the launch (`ran` False). Up to `max_resets` (default T) resets per env and launch. The resets are drawn on the device from
         each env's numpy RandomState stream (device_rng=True: the states are uploaded before and read back after the
-        launch; csrc/cloth_rng.hpp reproduces numpy's MT19937 draws bit for bit), or, with device_rng=False, pre-drawn
+        launch; csrc/cloth_rng.hpp reproduces numpy's MT19937 draws bit for bit; all three tiers, tier 2 rebuilding the
+        env's noisy sheet and rest lengths in the kernel), or, with device_rng=False (tiers 1 and 3), pre-drawn
         on the host as a chain of scripts -- then, when tier 1's coverage-conditional third reset pull runs, that env's
         later scripts are void (the RNG stream forked) and it idles after its next episode until the launch ends.
         An episode that ends in the last slot is reset by the NEXT launch, or here on the host with reset_tail=True (then
@@ -440,12 +439,14 @@ class ClothVecEnv(object):
             raise ValueError(policy)
         if not self._delta_actions:
             raise NotImplementedError("non-delta actions are decoded on the host only (cos/sin, cloth_env.py:452-453)")
-        dev_reset = auto_reset and self._init_type in ('tier1', 'tier3')
+        dev_reset = auto_reset and (self._init_type in ('tier1', 'tier3') or (self._init_type == 'tier2' and device_rng))
         R = T if max_resets is None else int(max_resets)
         use_rng = dev_reset and device_rng
         scripts = self._prepare_scripts(R) if (dev_reset and not use_rng) else None
         mt = gauss = None
         if use_rng:                                                   # every env's numpy stream, as RandomState.get_state() has it
+            if self._init_type == 'tier2':
+                self.batch.ensure_per_env_rest()                      # the kernel rebuilds each env's rest lengths at a reset
             for e in range(E):
                 self._drop_pending(e)
             mt = np.zeros((E, _lib.MT_WORDS), dtype=np.uint32)
@@ -463,7 +464,7 @@ class ClothVecEnv(object):
         self.batch.run_actions_begin(self._episode_params(), T, nsteps, done_io, actions=actions, policy=pol,
                                      policy_arg=parg, scripts=scripts, want_obs=want_obs,
                                      actions_device_ptr=actions_device_ptr, time_budget_ms=time_budget_ms,
-                                     rng_states=mt, rng_tier={'tier1': 1, 'tier3': 3}.get(self._init_type, 0),
+                                     rng_states=mt, rng_tier={'tier1': 1, 'tier2': 2, 'tier3': 3}.get(self._init_type, 0),
                                      domrand_words=2 * (3 + self._wd * self._hd * 3) if self._consume_domrand else 0,
                                      reset_capacity=R)
         _lap('launch')

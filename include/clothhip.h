@@ -188,7 +188,8 @@ enum { CLOTHHIP_POLICY_TABLE = 0,          /* actions[t][e][4] given by the call
  * depends on the particle state (the picked point's position, _prevent_oob) is evaluated on the device. */
 typedef struct ClothResetPull {
     int32_t point;                   /* >= 0: pick at pts[point] (tier 1: np_random.randint(P)); < 0: pick at (x, y) */
-    int32_t need_coverage;           /* != 0: run this pull (and the later ones) only if coverage >= coverage_min (tier 1's 3rd) */
+    int32_t need_coverage;           /* bit 0: run this pull (and the later ones) only if coverage >= coverage_min (tier 1's 3rd);
+                                        bit 1: do not apply _prevent_oob (tier 2's pulls, cloth_env.py:905-947) */
     double x, y;                     /* pick point when point < 0 (tier 3: p0x, p0y) */
     double dx, dy;                   /* drawn deltas BEFORE _prevent_oob (cloth_env.py:834-840, applied on the device) */
     double iters_up;                 /* iters_up of this pull (tier 3: uniform(200, 280); else env.iters_up) */
@@ -253,8 +254,9 @@ typedef struct ClothResetRecord {
  * non-25x25 oracle policy, grid too large for the in-kernel metrics). Synchronous. */
 /* Resets drawn ON THE DEVICE (the _begin/_end form only): instead of `scripts`, pass rng_states[E][626] = every env's
  * numpy RandomState (get_state(): key[624], pos, one pad word). The kernel then draws each reset exactly as ClothEnv.reset
- * does from np_random (cloth.pyx:75; cloth_env.py:851-877 tier 1 incl. the coverage-conditional third pull, :959-972
- * tier 3; rng_tier = 1 or 3), bit for bit numpy's MT19937 / rand / uniform / randint stream (csrc/cloth_rng.hpp), skips
+ * does from np_random (cloth.pyx:75; cloth_env.py:851-877 tier 1 incl. the coverage-conditional third pull; :893-949 +
+ * cloth.pyx:94-116 tier 2: the noisy vertical sheet, its rest lengths, 1500 + 500 settling updates, the two corner pulls --
+ * the handle must hold per-env rest tables; :959-972 tier 3; rng_tier = 1, 2 or 3), bit for bit numpy's MT19937 / rand / uniform / randint stream (csrc/cloth_rng.hpp), skips
  * domrand_words 32-bit words after each reset (the domain-randomisation draws of cloth_env.py:786-789; 0 = none), and
  * _end returns the advanced states. n_scripts is then the capacity of resets[E][n_scripts] / reset_obs per env; any number
  * of resets per env and launch up to that capacity, no void scripts.

@@ -26,7 +26,7 @@ def _rng_equal(a, b):
 
 
 @pytest.mark.parametrize("tier,T,E,device_rng", [("tier1", 4, 24, True), ("tier1", 4, 24, False), ("tier3", 3, 12, True),
-                                                  ("tier3", 3, 12, False)])
+                                                  ("tier3", 3, 12, False), ("tier2", 3, 12, True)])
 def test_step_many_equals_sequential_steps_f64(tier, T, E, device_rng):
     """T actions per env with auto-reset: one fused launch == T calls of step(auto_reset=True). Every reward, done flag,
     info value, counter, the final particle state and the state of every env's RNG must be identical. Uniformly random
@@ -141,7 +141,7 @@ def test_fused_refuses_what_it_cannot_run():
     from gym_cloth_amd.envs import ClothVecEnv
     v = ClothVecEnv(base_cfg("tier2", 3), n_envs=2, precision="f32")
     v.seed(3); v.reset()                                   # tier 2: per-env rest tables
-    out = v.step_many(np.zeros((1, 2, 4)), auto_reset=True)    # allowed: resets simply stay on the host
+    out = v.step_many(np.zeros((1, 2, 4)), auto_reset=True, device_rng=False)    # allowed: resets simply stay on the host
     assert out["ran"].all()
     with pytest.raises(Exception):
         v.batch.run_actions(v._episode_params(), 1, np.zeros(2, dtype=np.int32), np.zeros(2, dtype=np.uint8),
@@ -200,7 +200,7 @@ def test_in_flight_operations_are_dropped_by_outside_state_changes():
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("tier,seed", [("tier1", 1337), ("tier1", 21), ("tier3", 1339)])
+@pytest.mark.parametrize("tier,seed", [("tier1", 1337), ("tier1", 21), ("tier3", 1339), ("tier2", 1337), ("tier2", 1338)])
 def test_device_drawn_reset_equals_host_reset_f64(tier, seed, oracle_lib):
     """The reset the kernel draws from the env's numpy stream (MT19937 on the device, csrc/cloth_rng.hpp) equals
     ClothEnv.reset on the host: same post-reset particles, same start coverage, same init_side, and -- with the
@@ -222,9 +222,11 @@ def test_device_drawn_reset_equals_host_reset_f64(tier, seed, oracle_lib):
     assert np.array_equal(d.init_side, h.init_side)
     for e in range(2):
         assert _rng_equal(d.np_randoms[e], h.np_randoms[e]), e
-    if seed == 1337 and tier == "tier1":
-        g = oracle_lib.load_golden("g_env_tier1_1337.npz")
+    if seed in (1337, 1338) and tier in ("tier1", "tier2"):          # the reference's own capture of this reset
+        g = oracle_lib.load_golden("g_env_%s_%d.npz" % (tier, seed))
         assert np.array_equal(out["reset_obs"][0, 0], g["reset_obs"].astype(np.float32))
+    if tier == "tier2":                                               # the rest lengths the kernel rebuilt (cloth.pyx:417)
+        assert np.array_equal(d.batch.get_rest(), h.batch.get_rest())
     h.close(); d.close()
 
 
