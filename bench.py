@@ -123,12 +123,24 @@ def load_traffic(mode, E, n_side, precision, fuse):
 def run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, rank, world, local_rank, thickness=None,
                  want_cpu=False, step_ms=170.0, slots=0, max_resets=0):
     """One bench configuration on this rank's GPU; returns the result record (rank 0) or None."""
-    from gym_cloth_amd.dist import LocalTransport, RcclTransport, StepExchange
+    from gym_cloth_amd.dist import LocalTransport, RcclTransport, SocketTransport, StepExchange
     from gym_cloth_amd.envs import ClothVecEnv
     thickness = thickness if thickness is not None else (0.02 if n_side <= 25 else 0.0095)
     cfg = bench_cfg(n_side, thickness, init)
     env = ClothVecEnv(cfg, n_envs=E, device=local_rank, precision=precision, consume_domrand_draws=False)
-    xch = StepExchange(E, RcclTransport(rank, world, env.batch) if world > 1 else LocalTransport())
+    transport_name = "none (1 GPU)"
+    if world > 1:
+        try:
+            transport, transport_name = RcclTransport(rank, world, env.batch), "RCCL (ctypes binding, handle stream)"
+        except Exception as exc:                             # never lose the measurement to the exchange of a few KB
+            print("bench: rank %d: RCCL transport failed (%s: %s); using the TCP transport" % (rank, type(exc).__name__, exc),
+                  file=sys.stderr)
+            transport = SocketTransport(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                                        int(os.environ.get("MASTER_PORT", "29500")) + 17)
+            transport_name = "TCP sockets (RCCL init failed: %s)" % type(exc).__name__
+    else:
+        transport = LocalTransport()
+    xch = StepExchange(E, transport)
     g0 = rank * E                                            # first global env index of this rank
     for e in range(E):                                       # SURVEY 8d: reset draws from RandomState(1000+e)
         env.np_randoms[e] = np.random.RandomState(1000 + g0 + e)
@@ -230,7 +242,7 @@ def run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, rank
                        "mode": ("fused: %d launches, each a %.0f ms time slice of back-to-back actions and episode resets per env "
                                 "(reset substeps counted)" % (stat["launches"], slice_ms))
                                if mode == "fused" else "step: one launch sequence per step, clock stopped around host-driven resets",
-                       "envs_per_gpu": E, "n_side": n_side, "init": init, "exact_order": True,
+                       "envs_per_gpu": E, "n_side": n_side, "init": init, "exact_order": True, "transport": transport_name,
                        "env_steps_executed": n_env_steps, "steps_equivalent": n_env_steps / (world * E),
                        "env_steps_per_s": n_env_steps / dt,
                        "substeps_per_env_step": n_sub_all / max(n_env_steps, 1),

@@ -54,6 +54,12 @@ class ClothEpisodeParams(C.Structure):
                 ("act_low", C.c_double * 4), ("act_high", C.c_double * 4), ("coverage_done", C.c_double)]
 
 
+class ClothRenderParams(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("cam_pos", C.c_float * 3), ("world_to_cam", C.c_float * 9),
+                ("lens_mm", C.c_float), ("sensor_mm", C.c_float), ("front", C.c_float * 3), ("back", C.c_float * 3),
+                ("background", C.c_float * 3), ("light_dir", C.c_float * 3), ("ambient", C.c_float), ("energy", C.c_float)]
+
+
 POLICY_TABLE, POLICY_ORACLE_CORNER = 0, 1
 MT_WORDS = 626                      # per-env RandomState image: key[624], pos, pad (csrc/cloth_rng.hpp)
 
@@ -113,6 +119,7 @@ SYMBOLS = [
     ("clothhip_hull_area", C.c_double, [_dp, C.c_int32]),
     ("clothhip_write_obs_f32_device", C.c_int, [_vp, _vp]),
     ("clothhip_run_device_sched_async", C.c_int, [_vp, _vp]),
+    ("clothhip_render", C.c_int, [_vp, C.POINTER(ClothRenderParams), _u8p, _u8p, C.POINTER(C.c_float)]),
     ("clothhip_device_alloc", C.c_int, [_vp, C.c_uint64, C.POINTER(_vp)]),
     ("clothhip_device_free", C.c_int, [_vp, _vp]),
     ("clothhip_device_upload", C.c_int, [_vp, _vp, _vp, C.c_uint64]),

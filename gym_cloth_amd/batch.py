@@ -153,6 +153,49 @@ class ClothBatch(object):
             return cov, vinv, oob.astype(bool), tear.astype(bool), nlow / float(self.P)
         return cov, vinv, oob.astype(bool), tear.astype(bool)
 
+    # ---- headless rendering ---------------------------------------------------------------
+    @staticmethod
+    def camera_matrix(cam_deg=(0.0, 0.0, 0.0)):
+        """world -> camera rotation for Blender's `rotation_euler` (XYZ order, degrees) of the reference's camera
+        (get_image_rep_279.py:119-122): camera-to-world = Rz Ry Rx, returned transposed as float32[9]."""
+        ax, ay, az = np.deg2rad(np.asarray(cam_deg, dtype=np.float64))
+        cx, sx, cy, sy, cz, sz = np.cos(ax), np.sin(ax), np.cos(ay), np.sin(ay), np.cos(az), np.sin(az)
+        m = np.array([[cz * cy, cz * sy * sx - sz * cx, cz * sy * cx + sz * sx],
+                      [sz * cy, sz * sy * sx + cz * cx, sz * sy * cx - cz * sx],
+                      [-sy, cy * sx, cy * cx]])
+        return np.ascontiguousarray(m.T.reshape(9), dtype=np.float32)
+
+    RENDER_DEFAULTS = dict(width=224, height=224, cam_pos=(0.5, 0.5, 1.45), cam_deg=(0.0, 0.0, 0.0), lens_mm=40.0,
+                           sensor_mm=36.0, front=(0.070, 0.050, 0.600), back=(0.070, 0.300, 0.900),
+                           background=(1.0, 1.0, 1.0), light_dir=(0.5169, 0.0730, 0.8530), ambient=0.05, energy=1.5)
+
+    def render_params(self, **kw):
+        """_lib.ClothRenderParams of the reference's scene (get_image_rep_279.py: camera :114-122, lens :273-276, side colours
+        :249-257, bed :172, lamp energy :450; light_dir = the direction from the cloth centre to Blender's default lamp);
+        any field can be overridden, cam_deg instead of world_to_cam."""
+        d = dict(self.RENDER_DEFAULTS); d.update(kw)
+        p = _lib.ClothRenderParams()
+        p.width, p.height = int(d["width"]), int(d["height"])
+        w2c = d["world_to_cam"] if "world_to_cam" in d else self.camera_matrix(d["cam_deg"])
+        for k in range(9):
+            p.world_to_cam[k] = float(w2c[k])
+        for name in ("cam_pos", "front", "back", "background", "light_dir"):
+            for k in range(3):
+                getattr(p, name)[k] = float(d[name][k])
+        p.lens_mm, p.sensor_mm, p.ambient, p.energy = float(d["lens_mm"]), float(d["sensor_mm"]), float(d["ambient"]), float(d["energy"])
+        return p
+
+    def render(self, want_rgb=True, want_depth=True, swap_sides=None, params=None, **kw):
+        """Rasterise every env's cloth mesh (cloth_env.py:212-330 without Blender): (rgb uint8 [E, H, W, 3] or None,
+        depth float32 [E, H, W] camera-space distance or None)."""
+        p = params if params is not None else self.render_params(**kw)
+        rgb = np.empty((self.E, p.height, p.width, 3), dtype=np.uint8) if want_rgb else None
+        dep = np.empty((self.E, p.height, p.width), dtype=np.float32) if want_depth else None
+        sw = None if swap_sides is None else np.ascontiguousarray(np.broadcast_to(np.asarray(swap_sides, dtype=np.uint8), (self.E,)))
+        check(self._L.clothhip_render(self._h, C.byref(p), _lib.u8p(sw), _lib.u8p(rgb),
+                                      None if dep is None else dep.ctypes.data_as(C.POINTER(C.c_float))))
+        return rgb, dep
+
     # ---- gripper ---------------------------------------------------------------------------------------
     def _grab(self, fn, xy, radius, active):
         xy = np.ascontiguousarray(np.broadcast_to(np.asarray(xy, dtype=np.float64), (self.E, 2)))

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "cloth_kernels.hpp"
+#include "cloth_render.hpp"
 
 using namespace clothhip;
 
@@ -911,6 +912,46 @@ extern "C" int clothhip_write_obs_f32_device(clothhip_handle *h, void *d_out) {
     else
         hipLaunchKernelGGL(k_write_obs<float>, dim3(h->E), dim3(256), 0, h->stream, (const float *)h->d_pos, (float *)d_out, h->P, h->Ppad);
     HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+// ---- headless rendering ------------------------------------------------------------------------------------
+extern "C" int clothhip_render(clothhip_handle *h, const ClothRenderParams *p, const uint8_t *swap_sides, uint8_t *rgb, float *depth) {
+    if (!h || !p) return fail(CLOTHHIP_EINVAL, "NULL argument");
+    if (p->width < 1 || p->height < 1 || p->width > 4096 || p->height > 4096) return fail(CLOTHHIP_EINVAL, "image size outside [1, 4096]");
+    if (!(p->lens_mm > 0) || !(p->sensor_mm > 0)) return fail(CLOTHHIP_EINVAL, "lens / sensor must be > 0");
+    if (!rgb && !depth) return 0;
+    HIPCHECK(hipSetDevice(h->device));
+    const size_t npx = (size_t)p->width * p->height, E = h->E;
+    unsigned long long *d_z = nullptr; uint8_t *d_rgb = nullptr, *d_sw = nullptr; float *d_dep = nullptr;
+    auto cleanup = [&]() { if (d_z) (void)hipFree(d_z); if (d_rgb) (void)hipFree(d_rgb); if (d_sw) (void)hipFree(d_sw); if (d_dep) (void)hipFree(d_dep); };
+#define RC(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(CLOTHHIP_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } } while (0)
+    RC(hipMalloc(&d_z, E * npx * 8));
+    if (rgb) RC(hipMalloc(&d_rgb, E * npx * 3));
+    if (depth) RC(hipMalloc(&d_dep, E * npx * 4));
+    if (swap_sides) { RC(hipMalloc(&d_sw, E)); RC(hipMemcpyAsync(d_sw, swap_sides, E, hipMemcpyHostToDevice, h->stream)); }
+    RenderArgs a;
+    a.N = h->N; a.P = h->P; a.Ppad = h->Ppad; a.W = p->width; a.H = p->height; a.E = h->E;
+    for (int k = 0; k < 9; k++) a.R[k] = p->world_to_cam[k];
+    for (int k = 0; k < 3; k++) { a.cam[k] = p->cam_pos[k]; a.front[k] = p->front[k]; a.back[k] = p->back[k]; a.bg[k] = p->background[k]; a.light[k] = p->light_dir[k]; }
+    a.fx = (p->lens_mm / p->sensor_mm) * (float)p->width; a.fy = a.fx;           // square pixels, horizontal sensor fit
+    a.cx = 0.5f * (float)p->width; a.cy = 0.5f * (float)p->height;
+    a.ambient = p->ambient; a.energy = p->energy;
+    a.swap = d_sw; a.zbuf = d_z; a.rgb = d_rgb; a.depth = d_dep;
+    const int lds = 7 * h->Ppad * 4;
+    if (h->precision == CLOTHHIP_F64) {
+        RC(hipFuncSetAttribute((const void *)k_render<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL(k_render<double>, dim3(h->E), dim3(256), lds, h->stream, (const double *)h->d_pos, a);
+    } else {
+        RC(hipFuncSetAttribute((const void *)k_render<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL(k_render<float>, dim3(h->E), dim3(256), lds, h->stream, (const float *)h->d_pos, a);
+    }
+    RC(hipGetLastError());
+    if (rgb) RC(hipMemcpyAsync(rgb, d_rgb, E * npx * 3, hipMemcpyDeviceToHost, h->stream));
+    if (depth) RC(hipMemcpyAsync(depth, d_dep, E * npx * 4, hipMemcpyDeviceToHost, h->stream));
+    RC(hipStreamSynchronize(h->stream));
+#undef RC
+    cleanup();
     return 0;
 }
 

@@ -203,6 +203,25 @@ class ClothVecEnv(object):
         """'1d' observation of every env, [E, 3P] (cloth_env.py:196-200)."""
         return self.batch.positions().reshape(self.E, 3 * self.P)
 
+    def image_obs(self, use_depth=False, rgbd=False, **render_kw):
+        """Image observations without Blender (the reference's obs_type 'blender', cloth_env.py:196-209, :212-330), rendered
+        by the library's own rasteriser from the device-resident particles: uint8 [E, H, W, 3] colour, or with use_depth the
+        depth image replicated to 3 channels (the Z pass normalised over the image, get_image_rep_279.py:390-406, minus the 50
+        grey levels of cloth_env.py:301-302), or with rgbd [E, H, W, 4] = colour + depth channel (:202-205). The camera /
+        colour parameters follow the reference's Blender script; the pixels are not Blender's (no smoothing filter, no
+        domain randomisation, own shading)."""
+        swap = (~self.init_side).astype(np.uint8) if self._init_type == 'tier2' else None      # get_image_rep_279.py:235-239
+        rgb, dep = self.batch.render(want_rgb=(rgbd or not use_depth), want_depth=(rgbd or use_depth), swap_sides=swap,
+                                     **render_kw)
+        d8 = None
+        if dep is not None:
+            lo = dep.min(axis=(1, 2), keepdims=True); hi = dep.max(axis=(1, 2), keepdims=True)
+            nz = np.where(hi > lo, (dep - lo) / np.where(hi > lo, hi - lo, 1.0), 0.0)
+            d8 = np.uint8(np.maximum(0.0, np.rint(nz * 255.0) - 50.0))
+        if rgbd:
+            return np.concatenate([rgb, d8[..., None]], axis=-1)
+        return np.repeat(d8[..., None], 3, axis=-1) if use_depth else rgb
+
     # ---- action decoding (cloth_env.py:396-475) -------------------------------------------------------
     def decode_actions(self, actions, iters_up=None):
         """-> dict(x, y, x_dir_r, y_dir_r, iters_pull, bounds[E,5])."""

@@ -304,6 +304,30 @@ double clothhip_hull_area(const double *xy, int32_t n);
 int clothhip_write_obs_f32_device(clothhip_handle *h, void *d_out);
 /* Same, schedules read from a DEVICE array of ClothSchedule[E] (e.g. after an RCCL broadcast). */
 int clothhip_run_device_sched_async(clothhip_handle *h, const void *d_sched);
+/* Headless RGB / depth rendering of every env's cloth mesh: what the reference obtains by exporting the
+ * particle grid as a triangle mesh (cloth_env.py:218-229) and calling a Blender subprocess
+ * (gym_cloth/blender/get_image_rep_279.py; cloth_env.py:212-330). The scene follows that script -- pinhole camera
+ * (default: at (0.5, 0.5, 1.45) looking straight down, lens 40 mm on a 36 mm sensor), the two cloth sides in different
+ * colours, a shadow-less lamp, a white bed plane -- but the pixels are this library's own rasterisation rules
+ * (csrc/cloth_render.hpp), pinned to a numpy restatement (oracle/render_oracle.py), not to Blender. */
+typedef struct ClothRenderParams {
+    int32_t width, height;           /* cfg: 224 x 224 (cloth_env.py:152-157) */
+    float cam_pos[3];                /* 0.5, 0.5, 1.45 (+ dom_rand camera_pos) */
+    float world_to_cam[9];           /* row-major rotation; the camera looks along -z_cam with +y_cam up. Identity = straight
+                                        down, image +x = world +x, image up = world +y. (Blender's rotation_euler XYZ of
+                                        get_image_rep_279.py:119-122 is camera-to-world = Rz Ry Rx: pass its transpose.) */
+    float lens_mm, sensor_mm;        /* 40, 36 */
+    float front[3], back[3];         /* (0.070, 0.050, 0.600), (0.070, 0.300, 0.900) */
+    float background[3];             /* bed plane, (1, 1, 1) */
+    float light_dir[3];              /* unit vector towards the lamp */
+    float ambient, energy;
+} ClothRenderParams;
+/* rgb: [E][height][width][3] uint8 or NULL; depth: [E][height][width] float32 camera-space depth (distance along the view
+ * axis; the bed plane where no cloth is) or NULL; swap_sides[E] or NULL: != 0 swaps the two side colours (a tier-2 cloth
+ * with init_side False, get_image_rep_279.py:235-239). */
+int clothhip_render(clothhip_handle *h, const ClothRenderParams *params, const uint8_t *swap_sides, uint8_t *rgb,
+                    float *depth);
+
 /* Raw device buffers on the handle's device, for the multi-GPU driver's RCCL staging (action tables in, result /
  * observation tables out; gym_cloth_amd/dist.py). upload/download run on the handle's stream and synchronise it, so
  * they are ordered with the stepper launches. */
