@@ -705,7 +705,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
         for (int h = tid; h < HT; h += NT) { hkey[h] = KEY_EMPTY; hco[h] = 0; }
         for (int i = tid; i < nL + 64; i += NT) lvflag[i] = 0;
         for (int i = tid; i < (A.Spad / 64 + 2) * 2; i += NT) reinterpret_cast<uint32_t *>(smem + lay.abits)[i] = 0u;
-        if (tid == 0) { misc[0] = tear_flag; misc[1] = 0; misc[2] = 0; misc[3] = 0; misc[4] = 0; misc[5] = 0; misc[6] = 0; }
+        if (tid == 0) { misc[0] = tear_flag; misc[1] = 0; misc[2] = 0; misc[3] = 0; misc[4] = 0; misc[5] = 0; misc[6] = 0; misc[10] = 0x7fffffff; }
     };
     init_lds(A.tear[e], A.lv_ent, g_rest, A.lv_off, A.lv_off8, A.pt_lev);
     __syncthreads();
@@ -1453,7 +1453,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                 // the owner holds the spring's gather entry (neighbour = ptA, level-order position) and, with
                 // REST_REG, its rest length in registers, so the pre-pass needs one 16-byte LDS read per spring.
                 uint32_t *abits32 = reinterpret_cast<uint32_t *>(smem + lay.abits);
-                int nact = 0;
+                int nact = 0, pmin = 0x7fffffff;     // flagged springs; the first of them in level order
 #pragma unroll
                 for (int q = 0; q < PPT; q++) {
                     if (tid + q * NT < P) {
@@ -1484,14 +1484,14 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                                 // not flagged, and a cloth at rest skips the sweep altogether
                                 bool flag = len2 > tmin * tmin * ((T)1 + filt_slack<T>());
                                 if (!flag) { const T len = dev_sqrt<T>(len2); flag = len > t11 || len > tt; }
-                                if (flag) { atomicOr(&abits32[pos_ >> 5], 1u << (pos_ & 31)); nact++; }
+                                if (flag) { atomicOr(&abits32[pos_ >> 5], 1u << (pos_ & 31)); nact++; pmin = (int)pos_ < pmin ? (int)pos_ : pmin; }
                             }
                         }
                     }
                 }
                 if (__any(nact)) {
-                    for (int o = 32; o > 0; o >>= 1) nact += __shfl_xor(nact, o);
-                    if (lane == 0) atomicAdd(&misc[1], nact);
+                    for (int o = 32; o > 0; o >>= 1) { nact += __shfl_xor(nact, o); const int v_ = __shfl_xor(pmin, o); pmin = v_ < pmin ? v_ : pmin; }
+                    if (lane == 0) { atomicAdd(&misc[1], nact); atomicMin(&misc[10], pmin); }
                 }
             }
             __syncthreads();
@@ -1527,6 +1527,17 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                     asm volatile("" : "+v"(kl.c11), "+v"(kl.tear_thresh));
                     const int sl = lane & (lvw - 1);
                     int myL = res;                               // the level this lane currently holds
+                    int Ls = 0;                                  // the sweep starts at the level of the first flagged spring:
+                    {                                            // every level before it is unflagged and nothing has moved yet
+                        const uint16_t *loffS = narrow ? (TAB >= 1 ? reinterpret_cast<const uint16_t *>(smem + lay.off8) : A.lv_off8) : loff;
+                        const int pfirst = misc[10];
+                        if (!(pm & PH_NOSKIP) && pfirst < A.S) {
+                            int lo_ = 0, hi_ = narrow ? A.n_levels8 : nL;
+                            while (hi_ - lo_ > 1) { const int mid_ = (lo_ + hi_) >> 1; if ((int)loffS[mid_] <= pfirst) lo_ = mid_; else hi_ = mid_; }
+                            Ls = __builtin_amdgcn_readfirstlane(lo_) & ~(GR - 1);
+                        }
+                        myL = res + Ls;
+                    }
                     {
                         // Lane-private stream over the compact level table (LDS, or L2 for the large grids): entry index = off[level] + slot,
                         // a slot beyond the level's width reads the all-zero padding entry S (ptA == ptB == 0).
@@ -1541,7 +1552,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                         uint32_t e1 = ent[pn]; T r1 = rest[pn];
                         int olo = (int)loffD[myL + 2 * GR], ohi = (int)loffD[myL + 2 * GR + 1];
                         Pt<T> PA = cur[ec & 0xFFFFu], PB = cur[ec >> 16];
-                        int L = 0;
+                        int L = Ls;
                         while (L < nLD) {
                             const int grp = myL - L;             // 0..GR-1: position of my level inside this pass
                             const int a = (int)(ec & 0xFFFFu), b = (int)(ec >> 16);
@@ -1724,13 +1735,15 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                     }
                 }
                 if (__any(tear) && lane == 0) misc[0] = 1;
-                if (lane == 0) misc[1] = 0;
+                if (lane == 0) { misc[1] = 0; misc[10] = 0x7fffffff; }
                 __builtin_amdgcn_s_setprio(0);
                 // the pre-pass ORs into the bitmask: clear the words it set (they are all consumed now)
                 for (int i = lane; i < (A.Spad / 64 + 2) * 2; i += 64) reinterpret_cast<uint32_t *>(smem + lay.abits)[i] = 0u;
             }
             __syncthreads();
+#ifndef CLOTHHIP_SWEEP_STAMPS          // (that build uses slots 9-11 for the sparse sweep's marks / passes)
             TSTAMP(9)
+#endif
         }
         if (timing) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory"); }
         done++;

@@ -55,7 +55,8 @@ struct clothhip_handle {
     uint32_t *d_gather = nullptr, *d_lv_ent = nullptr;
     uint16_t *d_lv_off = nullptr, *d_lv_off8 = nullptr, *d_pt_lev = nullptr;
     int n_levels8 = 0, narrow_thresh = 300, cell_copy = 0;
-    int dense_thresh = 14;        // pre-pass flagged springs above which the lean dense sweep beats exact pending-level tracking
+    int dense_thresh = 2;         // pre-pass flagged springs above which the dense sweep (which starts at the first flagged level) beats exact
+                                  // pending-level tracking; measured best at 1-3 on the bench workload and on a well-formed action
     int HT = 0, ht_bits = 0, lvw_shift = 4, lds_bytes = 0, phase_mask = 15, nt = 256, ppt = 3;
     int tab = 0;            // static tables resident in LDS: 0 none, 1 springs/rest/offsets, 2 + per-point levels
     bool rest_reg = false;
