@@ -149,15 +149,16 @@ def test_fused_refuses_what_it_cannot_run():
     v.close()
 
 
-def test_time_sliced_launches_give_the_same_trajectories_f64():
+@pytest.mark.parametrize("tier", ["tier1", "tier2", "tier3"])
+def test_time_sliced_launches_give_the_same_trajectories_f64(tier):
     """A launch with a time budget lets every env advance at its own pace; an env's unused slots are passed again in the
     next launch. However the action sequence of an env is cut into launches, its trajectory is the same: the concatenated
     per-env (reward, done, executed) sequences and the final states equal those of ONE launch over the whole sequence."""
-    E, N = 12, 6
+    E, N = (12, 6) if tier == "tier1" else (6, 4)
     streams = np.stack([np.random.RandomState(2000 + e).uniform(-1, 1, size=(N, 4)) for e in range(E)])   # [E, N, 4]
-    a = _bench_env(E, "f64"); a.reset()
+    a = _bench_env(E, "f64", tier); a.reset()
     ref = a.step_many(np.ascontiguousarray(streams.transpose(1, 0, 2)), max_resets=8)
-    b = _bench_env(E, "f64"); b.reset()
+    b = _bench_env(E, "f64", tier); b.reset()
     cnt = np.zeros(E, dtype=np.int64)
     got = [[] for _ in range(E)]
     slots, launches = 4, 0
@@ -258,4 +259,41 @@ def test_demo_writer_device_equals_host_loop_f64(tmp_path):
             assert ed["info"] == eh["info"]
             compared += 1
     assert compared >= 3
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("variant", ["force_grab", "no_clip", "grid50_f32"])
+def test_step_many_equals_sequential_other_configurations(variant):
+    """The episode launch against sequential step() calls in configurations the other tests do not touch: force_grab (the
+    in-kernel radius-growing loop, cloth_env.py:434-444), clip_act_space off (actions and reset pulls in world units, the
+    out-of-bounds action penalty computed from the recorded action), and the 50x50 grid in fp32 (the 512-thread x 5-particle
+    variant with float sort keys in the in-kernel metrics; same kernel arithmetic on both paths, so identical results)."""
+    import bench
+    from gym_cloth_amd.envs import ClothVecEnv
+    n_side, prec, E, T = (50, "f32", 3, 2) if variant == "grid50_f32" else (25, "f64", 8, 3)
+    cfg = bench.bench_cfg(n_side, 0.02 if n_side == 25 else 0.0095)
+    if variant == "force_grab":
+        cfg["env"]["force_grab"] = True
+    if variant == "no_clip":
+        cfg["env"]["clip_act_space"] = False
+    envs = []
+    for _ in range(2):
+        v = ClothVecEnv(cfg, n_envs=E, precision=prec, consume_domrand_draws=False)
+        for e in range(E):
+            v.np_randoms[e] = np.random.RandomState(1000 + e)
+        v.reset()
+        envs.append(v)
+    a, b = envs
+    lo, hi = (-1.2, 1.2) if variant != "no_clip" else (-0.3, 1.3)       # some actions outside the action space
+    acts = np.stack([np.random.RandomState(2000 + e).uniform(lo, hi, size=(T, 4)) for e in range(E)], axis=1)
+    seq = [a.step(acts[t], auto_reset=True) for t in range(T)]
+    out = b.step_many(acts, reset_tail=True)
+    for t in range(T):
+        obs, rew, done, info = seq[t]
+        assert out["ran"][t].all()
+        assert np.array_equal(rew, out["rew"][t]) and np.array_equal(done, out["done"][t]), (variant, t)
+        assert np.array_equal(info["executed"], out["executed"][t]) and np.array_equal(info["n_grabbed"], out["n_grabbed"][t])
+    if variant == "force_grab":
+        assert (out["n_grabbed"] > 0).all()
+    assert np.array_equal(a.batch.get_state()[0], b.batch.get_state()[0])
     a.close(); b.close()

@@ -26,7 +26,8 @@ env.reset()
 slots = 24
 streams = np.stack([np.random.RandomState(2000 + e).uniform(-1, 1, size=(slots * (launches + 2), 4)) for e in range(E)])
 cnt = np.zeros(E, dtype=np.int64)
-names = ["adjust", "hooke", "insert", "ranges", "fill", "precheck", "cells", "reset+plane", "prepass", "sweep", "(big cells)", "(small cells)"]
+names = ["adjust", "hooke + verlet", "hash insert", "cell ranges", "cell fill", "collision pre-check", "cell sweeps: tickets/wait", "table reset + plane",
+         "strain pre-pass", "strain sweep", "cell sweeps: big cells", "cell sweeps: small cells"]
 tot_ph = np.zeros(12)
 tot_sub = 0
 for w in range(launches + 1):
@@ -49,10 +50,11 @@ for w in range(launches + 1):
               (clk.min(), np.median(clk), clk.mean(), clk.max(), clk.mean() / clk.max()))
 if tot_sub:
     per = tot_ph / tot_sub
-    total = per[:10].sum()
+    total = per.sum()                                 # the twelve stamps partition wave 0's time in the substep loop
     print("cycles per cloth-substep, averaged over the whole workload (%d substeps): total %.0f" % (tot_sub, total))
     for n, v in zip(names, per):
-        print("   %-14s %8.0f  %5.1f %%" % (n, v, 100 * v / total))
+        print("   %-28s %8.0f  %5.1f %%" % (n, v, 100 * v / total))
+    print("   %-28s %8.0f  %5.1f %%" % ("(all cell sweeps)", per[6] + per[10] + per[11], 100 * (per[6] + per[10] + per[11]) / total))
     st = env.batch.debug_stats().astype(np.float64)
     print("strain sweep: %.3f sweeps/substep, dense share %.3f, levels run/substep %.1f, corrected/substep %.1f" %
           (st[:, 0].sum() / tot_sub * launches, st[:, 1].sum() / max(st[:, 0].sum(), 1), st[:, 2].sum() / tot_sub * launches,
