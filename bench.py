@@ -249,6 +249,9 @@ def run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, rank
                        "action_substeps_per_s": n_act_all / dt,
                        "grabbed_env_frac": stat["grabbed"] / max(stat["ran"], 1),       # env-steps whose pick point hit the cloth (else 0 substeps)
                        "envs_out_of_slots": stat["out_of_slots"],                       # fused: envs that used all their action slots of a launch
+                       # fraction of (env, launch) pairs in which the env was busy for the whole launch (fused: it did not run out
+                       # of action slots; step: it executed its action slot)
+                       "active_env_frac": 1.0 - stat["out_of_slots"] / max(E * stat["launches"], 1) if mode == "fused" else 1.0,
                        "episode_resets_in_timed_region": stat["resets"]},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": load_traffic(mode, E, n_side, precision, fuse),
