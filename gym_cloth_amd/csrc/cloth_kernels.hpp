@@ -190,6 +190,17 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true);     // lane 31 -> rows 2,3
     return v;
 }
+// inclusive min-scan over the 64 lanes (same DPP steps; lanes without a source keep their own value); lane 63 = the wave's min
+__device__ __forceinline__ int wave_incl_min(int v) {
+    int t;
+    t = __builtin_amdgcn_update_dpp(v, v, 0x111, 0xF, 0xF, false); v = t < v ? t : v;
+    t = __builtin_amdgcn_update_dpp(v, v, 0x112, 0xF, 0xF, false); v = t < v ? t : v;
+    t = __builtin_amdgcn_update_dpp(v, v, 0x114, 0xF, 0xF, false); v = t < v ? t : v;
+    t = __builtin_amdgcn_update_dpp(v, v, 0x118, 0xF, 0xF, false); v = t < v ? t : v;
+    t = __builtin_amdgcn_update_dpp(v, v, 0x142, 0xA, 0xF, false); v = t < v ? t : v;     // lane 15 of rows 0,2 -> rows 1,3
+    t = __builtin_amdgcn_update_dpp(v, v, 0x143, 0xC, 0xF, false); v = t < v ? t : v;     // lane 31 -> rows 2,3
+    return v;
+}
 // relative slack of the conservative "could this comparison against a sqrt be true" pre-filters
 template <typename T> __device__ __forceinline__ T filt_slack();
 template <> __device__ __forceinline__ double filt_slack<double>() { return 1e-9; }
@@ -1128,11 +1139,14 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
         else if (it < sc.n_griprest_end) { }
         else mode = 2;
         if (mode == 1) {
+            Pt<T> cq[PPT];
+#pragma unroll
+            for (int q = 0; q < PPT; q++) cq[q] = cur[tid + q * NT < P ? tid + q * NT : 0];     // batched: one LDS latency, not PPT
 #pragma unroll
             for (int q = 0; q < PPT; q++) {
                 const int i = tid + q * NT;
                 if (i >= P) continue;
-                Pt<T> c = cur[i];
+                Pt<T> c = cq[q];
                 const int m = (int)(w_cnt(c.w) & CNT_GRAB_MASK);
                 if (m) {
                     for (int r = 0; r < m; r++) {       // gripper.pyx:60-66: p <- x ; x <- delta + x
@@ -1174,11 +1188,29 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                     uint32_t gl[HK_SLOTS];
 #pragma unroll
                     for (int sl = 0; sl < HK_SLOTS; sl++) gl[sl] = GT_REG ? gt[GT_REG ? q : 0][sl] : A.gather[sl * Ppad + tid + q * NT];
+                    // software pipeline: the neighbour records of the next springs are in flight while spring sl is
+                    // evaluated (left to itself the scheduler, which minimises live registers at this kernel's pressure, issues
+                    // each 16-byte read right before its use and waits out the whole LDS latency 12 times per particle)
+                    constexpr int HK_AHEAD = 2;
+                    Pt<T> nbq[HK_AHEAD];
 #pragma unroll
-                    for (int sl = 0; sl < HK_SLOTS; sl++) {
+                    for (int sl = 0; sl < HK_AHEAD; sl++) {
                         uint32_t g = gl[sl];
                         asm volatile("" : "+v"(g));         // opaque: keeps the address math inside the substep loop
-                        const Pt<T> nb = cur[g & HK_NBR_MASK];
+                        gl[sl] = g;
+                        nbq[sl] = cur[g & HK_NBR_MASK];
+                    }
+#pragma unroll
+                    for (int sl = 0; sl < HK_SLOTS; sl++) {
+                        const uint32_t g = gl[sl];
+                        const Pt<T> nb = nbq[sl % HK_AHEAD];
+                        if (sl + HK_AHEAD < HK_SLOTS) {
+                            uint32_t gn = gl[sl + HK_AHEAD];
+                            asm volatile("" : "+v"(gn));
+                            gl[sl + HK_AHEAD] = gn;
+                            nbq[sl % HK_AHEAD] = cur[gn & HK_NBR_MASK];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);  // the reads above stay above the arithmetic below
                         const T r = REST_REG ? rr[REST_REG ? q : 0][sl] : rest[(g >> HK_POS_SHIFT) & HK_POS_MASK];
                         const T kk = (g & HK_BEND) ? k.ks_bend : k.ks_str;
                         const T dx = nb.x - me.x, dy = nb.y - me.y, dz = nb.z - me.z;
@@ -1419,11 +1451,14 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
 
         // ---- plane (cloth.pyx:345-370), by the owner (it holds the previous position) --------------------
         if (pm & PH_PLANE) {
+            Pt<T> mq[PPT];
+#pragma unroll
+            for (int q = 0; q < PPT; q++) mq[q] = cur[tid + q * NT < P ? tid + q * NT : 0];     // batched: one LDS latency, not PPT
 #pragma unroll
             for (int q = 0; q < PPT; q++) {
                 const int i = tid + q * NT;
                 if (i >= P) continue;
-                const Pt<T> me = cur[i];
+                const Pt<T> me = mq[q];
                 if (w_cnt(me.w) || me.z >= k.min_z) continue;
                 const T px = pvx[q], py = pvy[q], pz = pvz[q];
                 const T t = (k.min_z - pz) * (T)1.0;
@@ -1462,11 +1497,27 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                         uint32_t gl[HK_SLOTS / 2];
 #pragma unroll
                         for (int sl = 0; sl < HK_SLOTS / 2; sl++) gl[sl] = GT_REG ? gt[GT_REG ? q : 0][sl] : A.gather[sl * Ppad + tid + q * NT];
+                        // software pipeline, as in the Hooke phase: two neighbour reads in flight ahead of the test
+                        constexpr int PP_AHEAD = 2;
+                        Pt<T> nbq[PP_AHEAD];
 #pragma unroll
-                        for (int sl = 0; sl < HK_SLOTS / 2; sl++) {       // own springs come first in ascending list order
+                        for (int sl = 0; sl < PP_AHEAD; sl++) {
                             uint32_t g = gl[sl];
                             asm volatile("" : "+v"(g));
-                            const Pt<T> nb = cur[g & HK_NBR_MASK];
+                            gl[sl] = g;
+                            nbq[sl] = cur[g & HK_NBR_MASK];
+                        }
+#pragma unroll
+                        for (int sl = 0; sl < HK_SLOTS / 2; sl++) {       // own springs come first in ascending list order
+                            const uint32_t g = gl[sl];
+                            const Pt<T> nb = nbq[sl % PP_AHEAD];
+                            if (sl + PP_AHEAD < HK_SLOTS / 2) {
+                                uint32_t gn = gl[sl + PP_AHEAD];
+                                asm volatile("" : "+v"(gn));
+                                gl[sl + PP_AHEAD] = gn;
+                                nbq[sl % PP_AHEAD] = cur[gn & HK_NBR_MASK];
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
                             const uint32_t pos_ = (g >> HK_POS_SHIFT) & HK_POS_MASK;
                             T r = REST_REG ? rr[REST_REG ? q : 0][sl] : rest[pos_];
                             asm volatile("" : "+v"(r));     // or the thresholds below are hoisted out of the substep loop
@@ -1490,8 +1541,9 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                     }
                 }
                 if (__any(nact)) {
-                    for (int o = 32; o > 0; o >>= 1) { nact += __shfl_xor(nact, o); const int v_ = __shfl_xor(pmin, o); pmin = v_ < pmin ? v_ : pmin; }
-                    if (lane == 0) { atomicAdd(&misc[1], nact); atomicMin(&misc[10], pmin); }
+                    const int tot_ = __builtin_amdgcn_readlane(wave_incl_scan(nact), 63);        // DPP: no LDS round trips
+                    const int min_ = __builtin_amdgcn_readlane(wave_incl_min(pmin), 63);
+                    if (lane == 0) { atomicAdd(&misc[1], tot_); atomicMin(&misc[10], min_); }
                 }
             }
             __syncthreads();
