@@ -1606,6 +1606,10 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                         Pt<T> PA = cur[ec & 0xFFFFu], PB = cur[ec >> 16];
                         int L = Ls;
                         while (L < nLD) {
+#ifdef CLOTHHIP_SWEEP_STAMPS
+                            unsigned long long td0 = 0;
+                            if (timing) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(td0)::"memory"); }
+#endif
                             const int grp = myL - L;             // 0..GR-1: position of my level inside this pass
                             const int a = (int)(ec & 0xFFFFu), b = (int)(ec >> 16);
                             const uint32_t ca = w_cnt(PA.w), cb = w_cnt(PB.w);
@@ -1645,8 +1649,11 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                                 const T wa = ca != 0 ? (T)0 : (cb != 0 ? (T)1 : (T)0.5);
                                 const T wb = cb != 0 ? (T)0 : (ca != 0 ? (T)1 : (T)0.5);
                                 const T ea = extra * wa, eb = extra * wb;
-                                if (ca == 0) cur[a] = Pt<T>{PA.x - ux * ea, PA.y - uy * ea, PA.z - uz * ea, PA.w};
-                                if (cb == 0) cur[b] = Pt<T>{PB.x + ux * eb, PB.y + uy * eb, PB.z + uz * eb, PB.w};
+                                // branch-free: a pinned end has weight 0 and x - u*0 == x exactly (u is finite: len > 0 here), so
+                                // writing it back unchanged equals the reference's skipped assignment; the springs of a level
+                                // share no particle, so nobody else writes these two records in this pass
+                                cur[a] = Pt<T>{PA.x - ux * ea, PA.y - uy * ea, PA.z - uz * ea, PA.w};
+                                cur[b] = Pt<T>{PB.x + ux * eb, PB.y + uy * eb, PB.z + uz * eb, PB.w};
                             }
                             // same-wave LDS operations execute in program order: the reads below see the writes
                             // above without waiting for them; the barrier only pins the compiler's ordering
@@ -1663,6 +1670,14 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                             e1 = ent[pn]; r1 = rest[pn];
                             olo = (int)loffD[myL + 2 * GR]; ohi = (int)loffD[myL + 2 * GR + 1];
                             ec = ecn;
+#ifdef CLOTHHIP_SWEEP_STAMPS          // dense passes: [10] cycles of quiet passes, [11] of correcting ones, [9] 64 x #quiet passes
+                            if (timing) {
+                                unsigned long long td1;
+                                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(td1)::"memory");
+                                tph[g < GR ? 11 : 10] += td1 - td0;
+                                if (!(g < GR)) tph[9] += 64;
+                            }
+#endif
                         }
                     }
                 } else
