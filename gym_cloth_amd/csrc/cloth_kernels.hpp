@@ -304,8 +304,9 @@ __device__ __forceinline__ int strain_apply(Pt<T> *cur, uint32_t en, const Pt<T>
 // lane b holds the cell's b-th member in ascending point index; members are visited serially in that order
 // each against all lanes in parallel; the hits are summed in ascending member order. n <= 64.
 template <typename T>
-__device__ __forceinline__ void collide_cell_wave(Pt<T> *cur, uint16_t *m, const uint16_t *slot, int n,
-                                                  const DevConsts<T> &k, int lane) {
+__device__ __forceinline__ int collide_cell_wave(Pt<T> *cur, uint16_t *m, const uint16_t *slot, int n,
+                                                 const DevConsts<T> &k, int lane) {
+    int visits_ = 0;                                 // (profiling builds only read it)
     const bool in = lane < n;
     const int mine = in ? (int)m[lane] : 0x7fff;
     int rank = 0;
@@ -331,6 +332,7 @@ __device__ __forceinline__ void collide_cell_wave(Pt<T> *cur, uint16_t *m, const
     while (todo) {
         const int a = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
         todo &= todo - 1ull;
+        visits_++;
         const T xa = bcast(x, a), ya = bcast(y, a), za = bcast(z, a);
         const T dx = xa - x, dy = ya - y, dz = za - z;
         const T d2 = dx * dx + dy * dy + dz * dz;
@@ -360,6 +362,7 @@ __device__ __forceinline__ void collide_cell_wave(Pt<T> *cur, uint16_t *m, const
         todo |= ballot64(free_ && lane > a && !(d2 > thr2c));                           // a moved: later neighbours must look
     }
     if (moved) cur[i] = Pt<T>{x, y, z, me.w};
+    return visits_;
 }
 
 // 64/GSZ cells of at most GSZ (16 or 32) members each at once, one per GSZ-lane group of the wave; same exact
@@ -1389,6 +1392,10 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
             // the bpermute broadcasts cost what the pairing saves).
             {
                 const int na = __builtin_amdgcn_readfirstlane(misc[2]);
+#ifdef CLOTHHIP_CELL_COUNTERS
+                tph[9] += 64 * na; tph[10] += 64 * nocc;
+                tph[7] += 64 * (-__builtin_amdgcn_readlane(wave_incl_min(-nmax), 63));
+#endif
                 if (na) __builtin_amdgcn_s_setprio(2);     // serial per-cell sweeps: latency-critical like the strain sweep
                 int tkb = -1, tks = -1, bbase = 0, sbase = 0;       // outstanding tickets, tickets used up by earlier chunks
                 for (int c0 = 0; c0 < na; c0 += 64) {
@@ -1409,8 +1416,14 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                         const uint32_t co = (uint32_t)__builtin_amdgcn_readlane((int)co_l, b);
                         const int n = (int)(co & 0xFFFFu);
                         uint16_t *m = memb + (int)(co >> 16);
-                        if (n <= 64) collide_cell_wave<T>(cur, m, slot, n, k, lane);
-                        else if (lane == 0) collide_cell_serial<T>(cur, m, n, k);
+                        if (n <= 64) {
+                            const int nv_ = collide_cell_wave<T>(cur, m, slot, n, k, lane);
+#ifdef CLOTHHIP_CELL_COUNTERS
+                            tph[4] += 64; tph[5] += 64 * n; tph[6] += 64 * nv_;
+#else
+                            (void)nv_;
+#endif
+                        } else if (lane == 0) collide_cell_serial<T>(cur, m, n, k);
                     }
                     bbase += nbig;
 #ifdef CLOTHHIP_CELL_STAMPS
@@ -1432,6 +1445,9 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                             }
                         }
                         used += 4;
+#ifdef CLOTHHIP_CELL_COUNTERS
+                        tph[8] += 64;
+#endif
                         collide_cells_group<T, 16>(cur, memb, slot, hco, hs, k, lane);
                     }
                     sbase += nsb;
