@@ -1523,6 +1523,9 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                             gl[sl] = g;
                             nbq[sl] = cur[g & HK_NBR_MASK];
                         }
+                        // (a) branch-free: which of the six springs come within the slack band of their limit at all?
+                        uint32_t cand = 0u;
+                        T l2s[HK_SLOTS / 2];
 #pragma unroll
                         for (int sl = 0; sl < HK_SLOTS / 2; sl++) {       // own springs come first in ascending list order
                             const uint32_t g = gl[sl];
@@ -1534,24 +1537,36 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                                 nbq[sl % PP_AHEAD] = cur[gn & HK_NBR_MASK];
                             }
                             __builtin_amdgcn_sched_barrier(0);
-                            const uint32_t pos_ = (g >> HK_POS_SHIFT) & HK_POS_MASK;
-                            T r = REST_REG ? rr[REST_REG ? q : 0][sl] : rest[pos_];
+                            T r = REST_REG ? rr[REST_REG ? q : 0][sl] : rest[(g >> HK_POS_SHIFT) & HK_POS_MASK];
                             asm volatile("" : "+v"(r));     // or the thresholds below are hoisted out of the substep loop
                                                             // for all 18 springs and live in scratch
                             const T dx = nb.x - me.x, dy = nb.y - me.y, dz = nb.z - me.z;   // (ptA - ptB), as :270
                             const T len2 = dx * dx + dy * dy + dz * dz;
+                            l2s[sl] = len2;
                             const T t11 = r * k.c11, tt = r * k.tear_thresh;
                             const T tmin = t11 < tt ? t11 : tt;
-                            const bool act = (g & (HK_VALID | HK_ASB)) == (HK_VALID | HK_ASB) &&
-                                             !(cme_ != 0 && w_cnt(nb.w) != 0) &&
+                            const bool pre = ((g & (HK_VALID | HK_ASB)) == (HK_VALID | HK_ASB)) &
+                                             !((cme_ != 0) & (w_cnt(nb.w) != 0)) &
                                              (len2 > tmin * tmin * ((T)1 - filt_slack<T>()));
-                            if (act) {
-                                // inside the slack band around the limit the sweep's exact test (:270-275) decides: a spring
-                                // that sits exactly ON its limit (left there by an earlier substep's correction) is then
-                                // not flagged, and a cloth at rest skips the sweep altogether
-                                bool flag = len2 > tmin * tmin * ((T)1 + filt_slack<T>());
-                                if (!flag) { const T len = dev_sqrt<T>(len2); flag = len > t11 || len > tt; }
-                                if (flag) { atomicOr(&abits32[pos_ >> 5], 1u << (pos_ & 31)); nact++; pmin = (int)pos_ < pmin ? (int)pos_ : pmin; }
+                            cand |= pre ? (1u << sl) : 0u;
+                        }
+                        // (b) those few: inside the slack band around the limit the sweep's exact test (:270-275) decides: a
+                        // spring that sits exactly ON its limit (left there by an earlier substep's correction) is then not
+                        // flagged, and a cloth at rest skips the sweep altogether
+                        if (cand) {
+#pragma unroll
+                            for (int sl = 0; sl < HK_SLOTS / 2; sl++) {
+                                if (cand & (1u << sl)) {
+                                    const uint32_t pos_ = (gl[sl] >> HK_POS_SHIFT) & HK_POS_MASK;
+                                    T r = REST_REG ? rr[REST_REG ? q : 0][sl] : rest[pos_];
+                                    asm volatile("" : "+v"(r));
+                                    const T len2 = l2s[sl];
+                                    const T t11 = r * k.c11, tt = r * k.tear_thresh;
+                                    const T tmin = t11 < tt ? t11 : tt;
+                                    bool flag = len2 > tmin * tmin * ((T)1 + filt_slack<T>());
+                                    if (!flag) { const T len = dev_sqrt<T>(len2); flag = len > t11 || len > tt; }
+                                    if (flag) { atomicOr(&abits32[pos_ >> 5], 1u << (pos_ & 31)); nact++; pmin = (int)pos_ < pmin ? (int)pos_ : pmin; }
+                                }
                             }
                         }
                     }
