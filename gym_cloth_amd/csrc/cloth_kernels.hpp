@@ -1608,6 +1608,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                     const int res = lane >> lsh;
                     DevConsts<T> kl = k;                         // spring-test constants pinned in VGPRs
                     asm volatile("" : "+v"(kl.c11), "+v"(kl.tear_thresh));
+                    const bool tic = __builtin_amdgcn_readfirstlane(!(k.tear_thresh < k.c11) ? 1 : 0) != 0;   // (wave-uniform)
                     const int sl = lane & (lvw - 1);
                     int myL = res;                               // the level this lane currently holds
                     int Ls = 0;                                  // the sweep starts at the level of the first flagged spring:
@@ -1646,20 +1647,23 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                             const uint32_t ca = w_cnt(PA.w), cb = w_cnt(PB.w);
                             const T dx = PA.x - PB.x, dy = PA.y - PB.y, dz = PA.z - PB.z;
                             const T len2 = dx * dx + dy * dy + dz * dz;
-                            const T t11 = rc * kl.c11, tt = rc * kl.tear_thresh;
-                            bool trig, tearl;
+                            const T t11 = rc * kl.c11;
+                            // the tear test (:272, len > tear_thresh * rest): with tear_thresh >= 1.1 (`tic`, the usual case) only
+                            // a spring that also stretches can tear, so the test moves into the commit; otherwise per level
+                            bool trig, tearl = false;
                             T len;
                             if constexpr (sizeof(T) == 4) {      // one v_sqrt: cheaper than a branch around it
                                 len = dev_sqrt<T>(len2);                                        // :270
                                 const bool live = !(ca != 0 && cb != 0);                        // :268
-                                tearl = live && len > tt;                                       // :272
+                                if (!tic) tearl = live && len > rc * kl.tear_thresh;            // :272
                                 trig = live && len > t11;                                       // :275
                             } else {
-                                const T tmin = t11 < tt ? t11 : tt;
-                                trig = false; tearl = false; len = (T)0;
+                                T tmin = t11;
+                                if (!tic) { const T tt = rc * kl.tear_thresh; tmin = t11 < tt ? t11 : tt; }
+                                trig = false; len = (T)0;
                                 if (!(ca != 0 && cb != 0) && (len2 > tmin * tmin * ((T)1 - filt_slack<T>()))) {
                                     len = dev_sqrt<T>(len2);
-                                    tearl = len > tt;
+                                    if (!tic) tearl = len > rc * kl.tear_thresh;
                                     trig = len > t11;
                                 }
                             }
@@ -1675,6 +1679,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                             const bool cons = myL < L;
                             const uint32_t ecn = cons ? e1 : ec;
                             if (commit) {
+                                if (tic && len > rc * kl.tear_thresh) tear = 1;                 // :272
                                 const T ux = dev_div<T>(dx, len), uy = dev_div<T>(dy, len), uz = dev_div<T>(dz, len);   // :276-278
                                 const T extra = len - t11;                                      // :279
                                 const T wa = ca != 0 ? (T)0 : (cb != 0 ? (T)1 : (T)0.5);
@@ -1693,7 +1698,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                             __builtin_amdgcn_sched_barrier(0);
                             // the rest of the bookkeeping runs in the shadow of those reads; the stream loads for the
                             // pass after next queue behind them
-                            if (tearl && grp <= g) tear = 1;
+                            if (!tic) { if (tearl && grp <= g) tear = 1; }
                             st_levels += adv; st_trig += g < GR ? 1 : 0;
                             myL = cons ? myL + GR : myL;
                             rc = cons ? r1 : rc;

@@ -157,6 +157,39 @@ def test_other_grid_sizes_match_oracle(n_side, prec, oracle_lib):
     b.close()
 
 
+@pytest.mark.parametrize("tear_thresh", [1.02, 1.1, 1.25])
+def test_tear_thresholds_around_the_strain_limit_f64(tear_thresh, oracle_lib):
+    """cloth.pyx:272 tests every live spring for len > tear_thresh * rest at its turn of the sweep. The kernel has two
+    arrangements of that test: with tear_thresh >= 1.1 only a spring that is also corrected can tear (the test sits in the
+    commit), below 1.1 a spring can tear without stretching (tested per level). A lift-and-pull that tears under each
+    threshold must reproduce the oracle bit for bit, tear flag and the substep it appears in included."""
+    from gym_cloth_amd import ClothBatch
+    g = oracle_lib.load_golden("g_traj_lift_pull_25.npz")
+    ocfg = dict(g["cfg"], tear_thresh=tear_thresh)
+    b = ClothBatch(cfg_from_golden({"cfg": ocfg}), n_envs=2, precision="f64")
+    pos0, rest0 = b.init_grid(1)
+    b.set_state(np.stack([pos0, pos0]), np.stack([pos0, pos0]), np.zeros((2, b.P), dtype=np.uint8), rest0)
+    oc = oracle_lib.OracleCloth(ocfg)
+    oc.set_state(pos0, pos0, np.zeros(b.P, dtype=np.uint8), rest0)
+    gx, gy = float(pos0[26, 0]), float(pos0[26, 1])
+    n = b.grab_top([gx, gy])
+    assert oc.grab_top(gx, gy) == n[0] and n[0] > 0
+    first_tear = None
+    for step, delta in enumerate([(0.0, 0.0, 0.008)] * 40 + [(0.008, 0.006, 0.0)] * 60):
+        b.update(1, delta=delta)
+        oc.adjust(*delta); oc.update(1)
+        assert bool(b.tear[0]) == oc.have_tear and bool(b.tear[1]) == oc.have_tear, (tear_thresh, step)
+        if oc.have_tear and first_tear is None:
+            first_tear = step
+        if step % 10 == 9 or step == first_tear:
+            pos, prev, _ = b.get_state()
+            op, oq, _ = oc.get_state()
+            assert np.array_equal(pos[0], op) and np.array_equal(prev[0], oq), (tear_thresh, step, max_abs(pos[0], op))
+            assert np.array_equal(pos[1], op)
+    assert first_tear is not None, "the pull must tear the cloth (tear_thresh %.2f)" % tear_thresh
+    b.close()
+
+
 def test_grid_too_large_for_lds_is_rejected():
     from gym_cloth_amd import ClothBatch
     g_cfg = cfg_from_golden({"cfg": {"n_side": 64, "width": 1, "height": 1, "density": 200.0, "ks": 1e4, "damping": 2.0,
