@@ -1650,20 +1650,16 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                             const T t11 = rc * kl.c11;
                             // the tear test (:272, len > tear_thresh * rest): with tear_thresh >= 1.1 (`tic`, the usual case) only
                             // a spring that also stretches can tear, so the test moves into the commit; otherwise per level
-                            bool trig, tearl = false;
+                            bool trig;
                             T len;
                             if constexpr (sizeof(T) == 4) {      // one v_sqrt: cheaper than a branch around it
                                 len = dev_sqrt<T>(len2);                                        // :270
                                 const bool live = !(ca != 0 && cb != 0);                        // :268
-                                if (!tic) tearl = live && len > rc * kl.tear_thresh;            // :272
                                 trig = live && len > t11;                                       // :275
                             } else {
-                                T tmin = t11;
-                                if (!tic) { const T tt = rc * kl.tear_thresh; tmin = t11 < tt ? t11 : tt; }
                                 trig = false; len = (T)0;
-                                if (!(ca != 0 && cb != 0) && (len2 > tmin * tmin * ((T)1 - filt_slack<T>()))) {
+                                if (!(ca != 0 && cb != 0) && (len2 > t11 * t11 * ((T)1 - filt_slack<T>()))) {
                                     len = dev_sqrt<T>(len2);
-                                    if (!tic) tearl = len > rc * kl.tear_thresh;
                                     trig = len > t11;
                                 }
                             }
@@ -1698,7 +1694,10 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                             __builtin_amdgcn_sched_barrier(0);
                             // the rest of the bookkeeping runs in the shadow of those reads; the stream loads for the
                             // pass after next queue behind them
-                            if (!tic) { if (tearl && grp <= g) tear = 1; }
+                            if (!tic) {          // (a real branch: the empty asm keeps the compiler from flattening it into the loop)
+                                asm volatile("" ::: "memory");
+                                if (!(ca != 0 && cb != 0) && grp <= g && dev_sqrt<T>(len2) > rc * kl.tear_thresh) tear = 1;   // :272
+                            }
                             st_levels += adv; st_trig += g < GR ? 1 : 0;
                             myL = cons ? myL + GR : myL;
                             rc = cons ? r1 : rc;
