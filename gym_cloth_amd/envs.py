@@ -15,6 +15,7 @@ obs_type is forced to the '1d' observation (cloth_env.py:196-200).
 import copy
 
 import numpy as np
+import ctypes as _ctypes
 import yaml
 
 from . import seeding
@@ -26,6 +27,19 @@ _REWARD_THRESHOLDS = {           # cloth_env.py:42-50
 }
 _EPS = 1e-5                      # cloth_env.py:52
 
+
+
+def _mt_state_address(rng):
+    """Address of numpy's `mt19937_state { uint32 key[624]; int pos; }` behind a RandomState (its MT19937 bit generator exports
+    it for exactly this kind of access), or None: then get_state() / set_state() are used. Copying 2 500 bytes per env this way
+    instead of building state tuples takes the per-launch RNG hand-over of 512 envs from ~30 ms to ~1 ms."""
+    try:
+        bg = rng._bit_generator
+        if type(bg).__name__ != 'MT19937':
+            return None
+        return int(bg.ctypes.state_address)
+    except Exception:
+        return None
 
 class Box(object):
     """Minimal stand-in for gym.spaces.Box (gym is not a dependency of the hot path)."""
@@ -470,9 +484,14 @@ class ClothVecEnv(object):
                 self._drop_pending(e)
             mt = np.zeros((E, _lib.MT_WORDS), dtype=np.uint32)
             gauss = [None] * E
+            mt_addr = [_mt_state_address(self.np_randoms[e]) for e in range(E)]
+            row0, row_bytes = mt.ctypes.data, mt.strides[0]
             for e in range(E):
-                st = self.np_randoms[e].get_state()
-                mt[e, :624], mt[e, 624], gauss[e] = st[1], st[2], st[3:]
+                if mt_addr[e]:                                        # key[624] + pos, straight out of numpy's generator state
+                    _ctypes.memmove(row0 + e * row_bytes, mt_addr[e], 625 * 4)
+                else:
+                    st = self.np_randoms[e].get_state()
+                    mt[e, :624], mt[e, 624], gauss[e] = st[1], st[2], st[3:]
             mt_before = mt.copy()
         parg = None
         if pol == _lib.POLICY_ORACLE_CORNER and self._init_type == 'tier2':
@@ -543,7 +562,10 @@ class ClothVecEnv(object):
         _lap('bookkeeping')
         if use_rng:                                                   # the streams as the device left them (a reset cut by the
             for e in np.nonzero((mt != mt_before).any(axis=1))[0]:    # time slice has drawn too, before any record of it is complete)
-                self.np_randoms[e].set_state(('MT19937', mt[e, :624], int(mt[e, 624])) + tuple(gauss[e]))
+                if mt_addr[e]:                                        # (the cached gaussian of RandomState is not the device's business)
+                    _ctypes.memmove(mt_addr[e], row0 + int(e) * row_bytes, 625 * 4)
+                else:
+                    self.np_randoms[e].set_state(('MT19937', mt[e, :624], int(mt[e, 624])) + tuple(gauss[e]))
         elif dev_reset:                                               # commit the RNG draws the device consumed
             for e in np.nonzero(n_consumed)[0]:
                 chain, c = self._pending[e], int(n_consumed[e])
