@@ -216,7 +216,14 @@ template <> __device__ __forceinline__ float w_make<float>(uint32_t c) { return 
 template <> __device__ __forceinline__ double w_make<double>(uint32_t c) { return __hiloint2double(0, (int)c); }
 
 // cloth.pyx:17-18, association ((x*x + y*y) + z*z)
-template <typename T> __device__ __forceinline__ T fastnorm(T x, T y, T z) { return dev_sqrt<T>(x * x + y * y + z * z); }
+// a * b + c: for double two roundings, as the reference's C doubles compute it (the file is built with -ffp-contract=off);
+// for float ONE fused multiply-add -- the fp32 instantiation is the throughput mode, its parity a tolerance
+template <typename T> __device__ __forceinline__ T mad(T a, T b, T c);
+template <> __device__ __forceinline__ double mad<double>(double a, double b, double c) { return a * b + c; }
+template <> __device__ __forceinline__ float mad<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+// (x*x + y*y) + z*z in the reference's association
+template <typename T> __device__ __forceinline__ T sumsq(T x, T y, T z) { return mad<T>(z, z, mad<T>(y, y, x * x)); }
+template <typename T> __device__ __forceinline__ T fastnorm(T x, T y, T z) { return dev_sqrt<T>(sumsq<T>(x, y, z)); }
 
 // cloth.pyx:307-311 -> biased, clamped cell key (exact for |coordinate| < ~60 cloth widths)
 template <typename T> __device__ __forceinline__ uint32_t cell_key(const DevConsts<T> &k, T x, T y, T z) {
@@ -280,7 +287,7 @@ __device__ __forceinline__ int strain_apply(Pt<T> *cur, uint32_t en, const Pt<T>
     const int a = (int)(en & 0xFFFFu), b = (int)(en >> 16);
     const uint32_t ca = w_cnt(A.w), cb = w_cnt(B.w);
     const T dx = A.x - B.x, dy = A.y - B.y, dz = A.z - B.z;
-    const T len2 = dx * dx + dy * dy + dz * dz;
+    const T len2 = sumsq<T>(dx, dy, dz);
     const T t11 = r * k.c11, tt = r * k.tear_thresh;
     const T tmin = t11 < tt ? t11 : tt;
     // both pinned: skipped (:268); below the conservative bound: certainly neither tear nor stretch
@@ -295,8 +302,8 @@ __device__ __forceinline__ int strain_apply(Pt<T> *cur, uint32_t en, const Pt<T>
     const T wa = ca != 0 ? (T)0 : (cb != 0 ? (T)1 : (T)0.5);
     const T wb = cb != 0 ? (T)0 : (ca != 0 ? (T)1 : (T)0.5);
     const T ea = extra * wa, eb = extra * wb;
-    if (ca == 0) cur[a] = Pt<T>{A.x - ux * ea, A.y - uy * ea, A.z - uz * ea, A.w};
-    if (cb == 0) cur[b] = Pt<T>{B.x + ux * eb, B.y + uy * eb, B.z + uz * eb, B.w};
+    if (ca == 0) cur[a] = Pt<T>{mad<T>(-ux, ea, A.x), mad<T>(-uy, ea, A.y), mad<T>(-uz, ea, A.z), A.w};
+    if (cb == 0) cur[b] = Pt<T>{mad<T>(ux, eb, B.x), mad<T>(uy, eb, B.y), mad<T>(uz, eb, B.z), B.w};
     return (ca == 0 ? 1 : 0) | (cb == 0 ? 2 : 0);
 }
 
@@ -335,7 +342,7 @@ __device__ __forceinline__ int collide_cell_wave(Pt<T> *cur, uint16_t *m, const 
         visits_++;
         const T xa = bcast(x, a), ya = bcast(y, a), za = bcast(z, a);
         const T dx = xa - x, dy = ya - y, dz = za - z;
-        const T d2 = dx * dx + dy * dy + dz * dz;
+        const T d2 = sumsq<T>(dx, dy, dz);
         bool hit = in && lane != a && !(d2 > thr2);
         T fx = (T)0, fy = (T)0, fz = (T)0;
         if (hit) {
@@ -400,7 +407,7 @@ __device__ __forceinline__ void collide_cells_group(Pt<T> *cur, uint16_t *memb, 
         todo &= todo - 1u;
         const T xa = lane_pull(x, base + a), ya = lane_pull(y, base + a), za = lane_pull(z, base + a);
         const T dx = xa - x, dy = ya - y, dz = za - z;
-        const T d2 = dx * dx + dy * dy + dz * dz;
+        const T d2 = sumsq<T>(dx, dy, dz);
         bool hit = act && ins && sub != a && !(d2 > thr2);
         T fx = (T)0, fy = (T)0, fz = (T)0;
         if (hit) {
@@ -460,7 +467,7 @@ __device__ __forceinline__ void collide_cell_serial(Pt<T> *cur, uint16_t *m, int
             if (b == a) continue;
             const Pt<T> J = cur[(int)m[b]];
             const T dx = I.x - J.x, dy = I.y - J.y, dz = I.z - J.z;
-            const T d2 = dx * dx + dy * dy + dz * dz;
+            const T d2 = sumsq<T>(dx, dy, dz);
             if (d2 > thr2) continue;
             const T dist = dev_sqrt<T>(d2);
             if (dist <= k.thresh) {
@@ -1220,11 +1227,11 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                         const T l = fastnorm<T>(dx, dy, dz);                                      // :231
                         const T fm = dev_div<T>(kk * (l - r), l);                                 // :232
                         const bool valid = (g & HK_VALID) != 0u;
-                        fx = valid ? fx + fm * dx : fx; fy = valid ? fy + fm * dy : fy; fz = valid ? fz + fm * dz : fz;   // :236-237
+                        fx = valid ? mad<T>(fm, dx, fx) : fx; fy = valid ? mad<T>(fm, dy, fy) : fy; fz = valid ? mad<T>(fm, dz, fz) : fz;   // :236-237
                     }
-                    nx[q] = me.x + (k.damp * (me.x - pvx[q])) + (fx * k.dsm);                     // :249
-                    ny[q] = me.y + (k.damp * (me.y - pvy[q])) + (fy * k.dsm);
-                    nz[q] = me.z + (k.damp * (me.z - pvz[q])) + (fz * k.dsm);
+                    nx[q] = mad<T>(fx, k.dsm, mad<T>(k.damp, me.x - pvx[q], me.x));               // :249
+                    ny[q] = mad<T>(fy, k.dsm, mad<T>(k.damp, me.y - pvy[q], me.y));
+                    nz[q] = mad<T>(fz, k.dsm, mad<T>(k.damp, me.z - pvz[q], me.z));
                     if (wme[q] == 0) { pvx[q] = me.x; pvy[q] = me.y; pvz[q] = me.z; }             // :256
                 }
             }
@@ -1350,7 +1357,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                             for (int u = 0; u < CU; u++) {                              // branch-free on purpose (& not &&)
                                 const T dx = cme[q].x - o[q][u].x, dy = cme[q].y - o[q][u].y, dz = cme[q].z - o[q][u].z;
                                 const bool other = (b + u < cn[q]) & ((int)w_cnt(o[q][u].w) != tid + q * NT);
-                                hit[q] |= other & !(dx * dx + dy * dy + dz * dz > thr2);
+                                hit[q] |= other & !(sumsq<T>(dx, dy, dz) > thr2);
                             }
                     }
                 } else {
@@ -1370,7 +1377,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                                 const Pt<T> o = cur[jj[q][u]];
                                 const T dx = cme[q].x - o.x, dy = cme[q].y - o.y, dz = cme[q].z - o.z;
                                 const bool other = (b + u < cn[q]) & (jj[q][u] != tid + q * NT);
-                                hit[q] |= other & !(dx * dx + dy * dy + dz * dz > thr2);
+                                hit[q] |= other & !(sumsq<T>(dx, dy, dz) > thr2);
                             }
                     }
                 }
@@ -1481,7 +1488,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                 const T tgx = px + t * (T)(-0.0), tgy = py + t * (T)(-0.0), tgz = pz + t * (T)(-1.0);
                 const T gx = tgx + k.surf_off * (T)0.0, gy = tgy + k.surf_off * (T)0.0, gz = tgz + k.surf_off * (T)1.0;
                 const T cx = gx - px, cy = gy - py, cz = gz - pz;
-                cur[i] = Pt<T>{px + cx * k.one_m_fric, py + cy * k.one_m_fric, pz + cz * k.one_m_fric, me.w};
+                cur[i] = Pt<T>{mad<T>(cx, k.one_m_fric, px), mad<T>(cy, k.one_m_fric, py), mad<T>(cz, k.one_m_fric, pz), me.w};
             }
         }
         if (FUSED && sliced) {             // thread 0 looks at the clock here, between two barriers that every thread passes in
@@ -1541,7 +1548,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                             asm volatile("" : "+v"(r));     // or the thresholds below are hoisted out of the substep loop
                                                             // for all 18 springs and live in scratch
                             const T dx = nb.x - me.x, dy = nb.y - me.y, dz = nb.z - me.z;   // (ptA - ptB), as :270
-                            const T len2 = dx * dx + dy * dy + dz * dz;
+                            const T len2 = sumsq<T>(dx, dy, dz);
                             l2s[sl] = len2;
                             const T t11 = r * k.c11, tt = r * k.tear_thresh;
                             const T tmin = t11 < tt ? t11 : tt;
@@ -1646,7 +1653,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                             const int a = (int)(ec & 0xFFFFu), b = (int)(ec >> 16);
                             const uint32_t ca = w_cnt(PA.w), cb = w_cnt(PB.w);
                             const T dx = PA.x - PB.x, dy = PA.y - PB.y, dz = PA.z - PB.z;
-                            const T len2 = dx * dx + dy * dy + dz * dz;
+                            const T len2 = sumsq<T>(dx, dy, dz);
                             const T t11 = rc * kl.c11;
                             // the tear test (:272, len > tear_thresh * rest): with tear_thresh >= 1.1 (`tic`, the usual case) only
                             // a spring that also stretches can tear, so the test moves into the commit; otherwise per level
@@ -1684,8 +1691,8 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                                 // branch-free: a pinned end has weight 0 and x - u*0 == x exactly (u is finite: len > 0 here), so
                                 // writing it back unchanged equals the reference's skipped assignment; the springs of a level
                                 // share no particle, so nobody else writes these two records in this pass
-                                cur[a] = Pt<T>{PA.x - ux * ea, PA.y - uy * ea, PA.z - uz * ea, PA.w};
-                                cur[b] = Pt<T>{PB.x + ux * eb, PB.y + uy * eb, PB.z + uz * eb, PB.w};
+                                cur[a] = Pt<T>{mad<T>(-ux, ea, PA.x), mad<T>(-uy, ea, PA.y), mad<T>(-uz, ea, PA.z), PA.w};
+                                cur[b] = Pt<T>{mad<T>(ux, eb, PB.x), mad<T>(uy, eb, PB.y), mad<T>(uz, eb, PB.z), PB.w};
                             }
                             // same-wave LDS operations execute in program order: the reads below see the writes
                             // above without waiting for them; the barrier only pins the compiler's ordering
@@ -1758,7 +1765,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                         const Pt<T> PA = cur[pa], PB = cur[pb];
                         const uint32_t ca = w_cnt(PA.w), cb = w_cnt(PB.w);
                         const T dx = PA.x - PB.x, dy = PA.y - PB.y, dz = PA.z - PB.z;
-                        const T len2 = dx * dx + dy * dy + dz * dz;
+                        const T len2 = sumsq<T>(dx, dy, dz);
                         const T t11 = r * k.c11, tt = r * k.tear_thresh;
                         const T tmin = t11 < tt ? t11 : tt;
                         bool trig = false, tearl = false;
@@ -1778,8 +1785,8 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                             const T wa = ca != 0 ? (T)0 : (cb != 0 ? (T)1 : (T)0.5);
                             const T wb = cb != 0 ? (T)0 : (ca != 0 ? (T)1 : (T)0.5);
                             const T ea = extra * wa, eb = extra * wb;
-                            if (ca == 0) cur[pa] = Pt<T>{PA.x - ux * ea, PA.y - uy * ea, PA.z - uz * ea, PA.w};
-                            if (cb == 0) cur[pb] = Pt<T>{PB.x + ux * eb, PB.y + uy * eb, PB.z + uz * eb, PB.w};
+                            if (ca == 0) cur[pa] = Pt<T>{mad<T>(-ux, ea, PA.x), mad<T>(-uy, ea, PA.y), mad<T>(-uz, ea, PA.z), PA.w};
+                            if (cb == 0) cur[pb] = Pt<T>{mad<T>(ux, eb, PB.x), mad<T>(uy, eb, PB.y), mad<T>(uz, eb, PB.z), PB.w};
                             moved = (ca == 0 ? 1 : 0) | (cb == 0 ? 2 : 0);
                         }
                         // done: every level of the pass up to and including the first correcting one
