@@ -60,7 +60,7 @@ class ClothRenderParams(C.Structure):
                 ("background", C.c_float * 3), ("light_dir", C.c_float * 3), ("ambient", C.c_float), ("energy", C.c_float)]
 
 
-POLICY_TABLE, POLICY_ORACLE_CORNER = 0, 1
+POLICY_TABLE, POLICY_ORACLE_CORNER, POLICY_HIGHEST_POINT = 0, 1, 2
 MT_WORDS = 626                      # per-env RandomState image: key[624], pos, pad (csrc/cloth_rng.hpp)
 
 RESET_PULL_DTYPE = np.dtype([("point", "<i4"), ("need_coverage", "<i4"), ("x", "<f8"), ("y", "<f8"), ("dx", "<f8"),

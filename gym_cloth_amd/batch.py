@@ -267,6 +267,11 @@ class ClothBatch(object):
         assert num_steps.dtype == np.int32 and num_steps.shape == (self.E,) and num_steps.flags['C_CONTIGUOUS']
         assert done.dtype == np.uint8 and done.shape == (self.E,) and done.flags['C_CONTIGUOUS']
         parg = None if policy_arg is None else np.ascontiguousarray(policy_arg, dtype=np.int32)
+        if pol == _lib.POLICY_HIGHEST_POINT and (parg is None or parg.shape != (1 + T, self.E)):
+            raise ValueError("the highest-point policy needs policy_arg int32[1 + %d, %d]: construction codes, then which of "
+                             "the highest points every env pulls in every slot" % (T, self.E))
+        if pol != _lib.POLICY_HIGHEST_POINT and parg is not None and parg.shape != (self.E,):
+            raise ValueError("policy_arg must have shape (%d,)" % self.E)
         if scripts is not None:
             scripts = np.ascontiguousarray(scripts, dtype=_lib.RESET_SCRIPT_DTYPE)
             if scripts.ndim != 2 or scripts.shape[0] != self.E:

@@ -91,7 +91,8 @@ struct EpState {
     int32_t stop;          // the launch's time slice is used up: no new action or reset starts
     int32_t side;          // device-RNG resets: Cloth.init_side of the reset in progress (cloth.pyx:75)
     int32_t choice;        // tier-2 reset: the corner picked for the first pull (-25 or -1, cloth_env.py:907)
-    int32_t swap, _pad;    // oracle-corner policy: corner indices swapped (tier-2 cloth with init_side False, analytic.py:108-114)
+    int32_t swap, _pad;    // how the cloth was built, for the policies: 0 flat tiers, 1 tier 2 with init_side False (the oracle-corner
+                           // policy swaps its corner indices, analytic.py:108-114), 2 tier 2 with init_side True
     double act[4];
     ClothResetPull pull;   // device-RNG resets: the draws of the pull being executed
 };
@@ -766,7 +767,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
             eps->t_slot = 0; eps->rp = -1; eps->n_resets = 0; eps->chain_ok = 1; eps->rs_pulls = 0; eps->reset_mark = 0;
             eps->ep_steps = Fp->num_steps[e]; eps->ep_done = Fp->done[e] ? 1 : 0; eps->done_total = 0; eps->stop = 0;
             misc[7] = 0;
-            eps->swap = (Fp->policy_arg != nullptr && Fp->policy_arg[e] != 0) ? 1 : 0; eps->choice = 0;
+            eps->swap = Fp->policy_arg != nullptr ? Fp->policy_arg[e] : 0; eps->choice = 0;   // 0 flat tiers, 1 / 2 tier 2 with init_side False / True
             if (Fp->resume != nullptr && Fp->resume[e].valid) {        // continue the operation the previous time slice cut
                 const EpResume *rs_ = Fp->resume + e;
                 const EpState &o = rs_->eps;
@@ -900,7 +901,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                             eps->rp = t2_ ? 8 : 0; eps->rs_pulls = 0; eps->ep_steps = 0; eps->ep_done = 0;
                             if (rngm && !t2_) side_ = mt_double(mt) > 0.5 ? 1 : 0;               // cloth.pyx:75
                             eps->side = side_;
-                            if (t2_) eps->swap = side_ ? 0 : 1;
+                            if (t2_) eps->swap = side_ ? 2 : 1;
                             if (F.resets) {
                                 ClothResetRecord *rr_ = F.resets + ((size_t)e * F.n_scripts + n_resets);
                                 rr_->init_side = side_;
@@ -920,7 +921,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                 if (F.policy == CLOTHHIP_POLICY_ORACLE_CORNER) {
                     // examples/analytic.py:105-155 ('distance' method, delta actions): pull the inset corner that is
                     // farthest from its plane corner; candidates in the order ur, lr, ll, ul, the first maximum wins
-                    const bool sw = eps->swap != 0;                                       // tier 2, init_side False (:108-114)
+                    const bool sw = eps->swap == 1;                                       // tier 2, init_side False (:108-114)
                     double best = -1.0;
 #pragma unroll
                     for (int c = 0; c < 4; c++) {
@@ -938,6 +939,50 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                             act[2] = dx; act[3] = dy;
                         }
                     }
+                } else if (with_tier2 && F.policy == CLOTHHIP_POLICY_HIGHEST_POINT) {
+                    // examples/analytic.py:792-808: sorted(pts, key=z, reverse=True)[k] -- a stable sort, so equal heights keep
+                    // their index order -- with k (the reference: np.random.randint(top_k)) from the caller's table, pulled to
+                    // where that point sits on the flat cloth (:742-789). k + 1 rounds of a workgroup arg-max over (z, -index),
+                    // each excluding what the earlier rounds took; the per-wave results go through the member list (scratch
+                    // between substeps).
+                    struct Cand { T z; int i; int pad; };
+                    Cand *red = reinterpret_cast<Cand *>(memb);
+                    int kc = F.policy_arg[(size_t)(1 + t_slot) * F.E + e];
+                    kc = kc < 0 ? 0 : (kc > P - 1 ? P - 1 : kc);
+                    T lastz = (T)0; int lasti = -1;
+                    const auto better = [](T z1, int i1, T z0, int i0) { return i1 != 0x7fffffff && (i0 == 0x7fffffff || z1 > z0 || (z1 == z0 && i1 < i0)); };
+                    for (int round = 0; round <= kc; round++) {
+                        T bz = (T)0; int bi = 0x7fffffff;
+#pragma unroll
+                        for (int q = 0; q < PPT; q++) {
+                            const int i = tid + q * NT;
+                            if (i < P) {
+                                const T z = cur[i].z;
+                                const bool ok = lasti < 0 || z < lastz || (z == lastz && i > lasti);
+                                if (ok && better(z, i, bz, bi)) { bz = z; bi = i; }
+                            }
+                        }
+                        for (int o = 32; o > 0; o >>= 1) {
+                            const T oz = __shfl_xor(bz, o); const int oi = __shfl_xor(bi, o);
+                            if (better(oz, oi, bz, bi)) { bz = oz; bi = oi; }
+                        }
+                        if (lane == 0) { red[tid >> 6].z = bz; red[tid >> 6].i = bi; }
+                        __syncthreads();
+                        bz = red[0].z; bi = red[0].i;
+                        for (int w = 1; w < NT / 64; w++) { const T oz = red[w].z; const int oi = red[w].i; if (better(oz, oi, bz, bi)) { bz = oz; bi = oi; } }
+                        lastz = bz; lasti = bi;
+                        __syncthreads();
+                    }
+                    const int pr = lasti / A.N, pc_ = lasti - pr * A.N;
+                    const Pt<T> pp = cur[lasti];
+                    const double x = (double)pp.x, y = (double)pp.y;
+                    double tgx, tgy;
+                    if (eps->swap == 0) { tgx = F.grid_dx * pr; tgy = F.grid_dy * pc_; }                   // pt.orig_x, pt.orig_y of the flat grid (cloth.pyx:122-124)
+                    else { tgx = eps->swap == 2 ? F.grid_dy * pr : 1.0 - F.grid_dy * pr; tgy = F.grid_dx * pc_; }   // :781-788 (orig_z, orig_y)
+                    const double cx = (x - 0.5) * 2.0, cy = (y - 0.5) * 2.0;                     // analytic.py:53-54
+                    const double dx = (tgx - x) * 0.90, dy = (tgy - y) * 0.90;                    // :55-56, :64-66
+                    act[0] = F.ep.clip_act_space ? cx : x; act[1] = F.ep.clip_act_space ? cy : y; // :803-806
+                    act[2] = dx; act[3] = dy;
                 } else {
                     const double *ap = F.actions + ((size_t)t_slot * F.E + e) * 4;
                     act[0] = ap[0]; act[1] = ap[1]; act[2] = ap[2]; act[3] = ap[3];

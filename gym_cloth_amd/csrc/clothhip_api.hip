@@ -71,7 +71,7 @@ struct clothhip_handle {
     uint32_t *d_fmt = nullptr;      // [E][MT_WORDS] numpy RandomState of every env (device-drawn resets)
     uint8_t *d_fdone = nullptr;
     int f_T = 0; size_t f_nscr = 0; bool f_pending = false, f_resets = false, f_obs = false, f_robs = false, f_mt = false;
-    size_t cap_fact = 0, cap_frec = 0, cap_fobs = 0, cap_fscr = 0, cap_frst = 0, cap_frobs = 0;
+    size_t cap_fact = 0, cap_frec = 0, cap_fobs = 0, cap_fscr = 0, cap_frst = 0, cap_frobs = 0, cap_fparg = 0;
     Topology topo;
     LevelSchedule lv;
     std::vector<unsigned char> stage;   // host staging for layout conversion
@@ -708,7 +708,10 @@ extern "C" int clothhip_run_actions_begin(clothhip_handle *h, const ClothEpisode
     if (h->f_pending) return fail(CLOTHHIP_ESTATE, "a clothhip_run_actions_begin is already in flight");
     const bool resets = want_resets != 0, obs = want_obs != 0, reset_obs = want_reset_obs != 0;
     if (T_ < 1 || T_ > 4096) return fail(CLOTHHIP_EINVAL, "T must be in [1, 4096]");
-    if (policy != CLOTHHIP_POLICY_TABLE && policy != CLOTHHIP_POLICY_ORACLE_CORNER) return fail(CLOTHHIP_EINVAL, "unknown policy %d", policy);
+    if (policy != CLOTHHIP_POLICY_TABLE && policy != CLOTHHIP_POLICY_ORACLE_CORNER && policy != CLOTHHIP_POLICY_HIGHEST_POINT)
+        return fail(CLOTHHIP_EINVAL, "unknown policy %d", policy);
+    if (policy == CLOTHHIP_POLICY_HIGHEST_POINT && !policy_arg)
+        return fail(CLOTHHIP_EINVAL, "the highest-point policy needs policy_arg[1 + T][E] (construction codes + which of the highest points per slot)");
     if (policy == CLOTHHIP_POLICY_TABLE && !actions) return fail(CLOTHHIP_EINVAL, "the table policy needs actions[T][E][4]");
     if (policy == CLOTHHIP_POLICY_ORACLE_CORNER && h->N != 25)
         return fail(CLOTHHIP_ESTATE, "the oracle-corner policy is defined for 25x25 cloths only (analytic.py:106)");
@@ -735,7 +738,6 @@ extern "C" int clothhip_run_actions_begin(clothhip_handle *h, const ClothEpisode
     if (!h->d_fz) {
         HIPCHECK(hipMalloc(&h->d_fz, 1024));
         HIPCHECK(hipMalloc(&h->d_fsteps, E * 4));
-        HIPCHECK(hipMalloc(&h->d_fparg, E * 4));
         HIPCHECK(hipMalloc(&h->d_fdone, E));
     }
     if (int rc = grow(&h->d_frec, &h->cap_frec, nrec * sizeof(ClothStepRecord))) return rc;
@@ -761,7 +763,11 @@ extern "C" int clothhip_run_actions_begin(clothhip_handle *h, const ClothEpisode
         if (!h->d_fmt) HIPCHECK(hipMalloc(&h->d_fmt, E * MT_WORDS * 4));
         HIPCHECK(hipMemcpyAsync(h->d_fmt, rng_states, E * MT_WORDS * 4, hipMemcpyHostToDevice, h->stream));
     }
-    if (policy_arg) HIPCHECK(hipMemcpyAsync(h->d_fparg, policy_arg, E * 4, hipMemcpyHostToDevice, h->stream));
+    if (policy_arg) {
+        const size_t nb = (policy == CLOTHHIP_POLICY_HIGHEST_POINT ? (size_t)(1 + T_) : (size_t)1) * E * 4;
+        if (int rc = grow((void **)&h->d_fparg, &h->cap_fparg, nb)) return rc;
+        HIPCHECK(hipMemcpyAsync(h->d_fparg, policy_arg, nb, hipMemcpyHostToDevice, h->stream));
+    }
     if (scripts) HIPCHECK(hipMemcpyAsync(h->d_fscr, scripts, nscr * sizeof(ClothResetScript), hipMemcpyHostToDevice, h->stream));
     HIPCHECK(hipMemcpyAsync(h->d_fsteps, num_steps, E * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHECK(hipMemcpyAsync(h->d_fdone, done, E, hipMemcpyHostToDevice, h->stream));
@@ -779,7 +785,7 @@ extern "C" int clothhip_run_actions_begin(clothhip_handle *h, const ClothEpisode
     HIPCHECK(hipMemcpyAsync(h->d_fz, fzbuf, 1024, hipMemcpyHostToDevice, h->stream));
     HIPCHECK(hipStreamSynchronize(h->stream));          // fzbuf is on this stack frame
     HIPCHECK(hipEventRecord(h->ev0, h->stream));
-    if (tier2) {                                        // the variant that also carries the tier-2 reset code
+    if (tier2 || policy == CLOTHHIP_POLICY_HIGHEST_POINT) {   // the variant that also carries the tier-2 reset code and the cold policies
         if (h->precision == CLOTHHIP_F64) launch_run<double, 2>(h, h->d_sched, h->d_fz);
         else launch_run<float, 2>(h, h->d_sched, h->d_fz);
     } else if (h->precision == CLOTHHIP_F64) launch_run<double, 1>(h, h->d_sched, h->d_fz);

@@ -29,20 +29,35 @@ def _info_at(src, t, e):
     return out
 
 
-def collect_demos(env, policy='oracle_corner', max_episodes=10, slots_per_launch=12, path=None, time_budget_ms=0.0):
+def collect_demos(env, policy='oracle_corner', max_episodes=10, slots_per_launch=12, path=None, time_budget_ms=0.0,
+                  on_device=False):
     """Run `policy` until `max_episodes` episodes have finished (over all envs of `env`, in order of completion) and return
     them as a list of episode dicts; with `path` the list is also pickled there (analytic.py:900-901).
-    `env` must have been seeded; it is reset here."""
+    `env` must have been seeded; it is reset here. A policies.HighestPointPolicy with on_device=True is evaluated in the
+    kernel as well: its per-env pick streams are drawn here and handed to the launch slot by slot."""
     episodes = []
     E = env.E
     obs = env.reset()
-    if isinstance(policy, str):
-        if policy != 'oracle_corner':
+    from .policies import HighestPointPolicy
+    hp = policy if (on_device and isinstance(policy, HighestPointPolicy)) else None
+    if isinstance(policy, str) or hp is not None:
+        if hp is None and policy != 'oracle_corner':
             raise ValueError(policy)
         cur = [_new_episode(obs[e].astype(np.float32), e) for e in range(E)]
+        picks = [[] for _ in range(E)]                                # highest point: picks drawn but not consumed yet
         while len(episodes) < max_episodes:
-            out = env.step_many(policy='oracle_corner', n_actions=slots_per_launch, auto_reset=True, want_obs=True,
-                                time_budget_ms=time_budget_ms)
+            if hp is not None:
+                for e in range(E):
+                    while len(picks[e]) < slots_per_launch:
+                        picks[e].append(hp.draw(e))
+                tbl = np.array([[picks[e][t] for e in range(E)] for t in range(slots_per_launch)], dtype=np.int32)
+                out = env.step_many(policy='highest_point', n_actions=slots_per_launch, policy_choices=tbl, auto_reset=True,
+                                    want_obs=True, time_budget_ms=time_budget_ms)
+                for e in range(E):
+                    del picks[e][:int(out['ran'][:, e].sum())]
+            else:
+                out = env.step_many(policy='oracle_corner', n_actions=slots_per_launch, auto_reset=True, want_obs=True,
+                                    time_budget_ms=time_budget_ms)
             for t in range(slots_per_launch):
                 for e in np.nonzero(out['ran'][t])[0]:
                     k = int(out['reset_before'][t, e])

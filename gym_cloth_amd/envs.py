@@ -426,13 +426,15 @@ class ClothVecEnv(object):
         self._ep_done[ie] = False
 
     def step_many(self, actions=None, n_actions=None, policy=None, auto_reset=True, want_obs=False, reset_tail=False,
-                  actions_device_ptr=None, max_resets=None, time_budget_ms=0.0, device_rng=True):
+                  actions_device_ptr=None, max_resets=None, time_budget_ms=0.0, device_rng=True, policy_choices=None):
         """T consecutive `step(a_t, auto_reset=auto_reset)` calls for every env in ONE device launch
         (clothhip_run_actions): decoding, grab, the substep loop, metrics, the terminal test and the episode resets all
         run in the kernel, envs never wait for each other, and the host only does the reward / info bookkeeping below.
 
         actions: float64[T, E, 4], or policy='oracle_corner' (examples/analytic.py's oracle, evaluated on the device)
-        with n_actions=T. With auto_reset=False an env whose episode ends idles for the rest of the launch (`ran` False). Up to `max_resets` (default T) resets per env and launch. The resets are drawn on the device from
+        with n_actions=T, or policy='highest_point' (analytic.py:723-808 on the device) with n_actions=T and
+        policy_choices int[T, E]: which of the highest points (0 = the highest; the reference draws randint(5)) the env
+        pulls in its t-th slot. With auto_reset=False an env whose episode ends idles for the rest of the launch (`ran` False). Up to `max_resets` (default T) resets per env and launch. The resets are drawn on the device from
         each env's numpy RandomState stream (device_rng=True: the states are uploaded before and read back after the
         launch; csrc/cloth_rng.hpp reproduces numpy's MT19937 draws bit for bit; all three tiers, tier 2 rebuilding the
         env's noisy sheet and rest lengths in the kernel), or, with device_rng=False (tiers 1 and 3), pre-drawn
@@ -468,6 +470,11 @@ class ClothVecEnv(object):
         elif policy == 'oracle_corner':
             pol, T = _lib.POLICY_ORACLE_CORNER, int(n_actions)
             assert self._delta_actions and self.num_points == 625                        # analytic.py:103-106
+        elif policy == 'highest_point':                                                  # analytic.py:723-808, evaluated on the device
+            pol, T = _lib.POLICY_HIGHEST_POINT, int(n_actions)
+            policy_choices = np.asarray(policy_choices, dtype=np.int32)                  # [T, E]: 0 = the highest point, 1 = the next ...
+            if policy_choices.shape != (T, E):
+                raise ValueError("policy_choices must have shape (%d, %d)" % (T, E))
         else:
             raise ValueError(policy)
         if not self._delta_actions:
@@ -494,8 +501,10 @@ class ClothVecEnv(object):
                     mt[e, :624], mt[e, 624], gauss[e] = st[1], st[2], st[3:]
             mt_before = mt.copy()
         parg = None
-        if pol == _lib.POLICY_ORACLE_CORNER and self._init_type == 'tier2':
-            parg = (~self.init_side).astype(np.int32)                                    # analytic.py:108-114
+        if pol != _lib.POLICY_TABLE and self._init_type == 'tier2':
+            parg = np.where(self.init_side, 2, 1).astype(np.int32)                       # analytic.py:108-114, :781-788
+        if pol == _lib.POLICY_HIGHEST_POINT:
+            parg = np.concatenate([(np.zeros(E, dtype=np.int32) if parg is None else parg)[None, :], policy_choices], axis=0)
         nsteps = np.ascontiguousarray(self.num_steps, dtype=np.int32)
         done_io = np.ascontiguousarray(self._ep_done, dtype=np.uint8)
         _lap('prepare_resets')

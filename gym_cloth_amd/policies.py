@@ -56,12 +56,30 @@ class OracleCornerPolicy(object):
 
 
 class HighestPointPolicy(object):
-    """Pick one of the top-k highest points at random and pull it to where it sits on the flat cloth."""
+    """Pick one of the top-k highest points at random and pull it to where it sits on the flat cloth
+    (examples/analytic.py:723-808; the reference draws the pick from the global numpy stream, here every env has its own
+    RandomState(seed + e) so that runs are reproducible and the device evaluation, ClothVecEnv.step_many(policy=
+    'highest_point'), can be fed the same picks)."""
 
     def __init__(self, env, top_k=5, seed=0):
         self.env, self.top_k = env, top_k
         self.rngs = [np.random.RandomState(seed + e) for e in range(env.E)]
-        self.orig = env.batch.init_grid(1)[0]                            # pt.orig_x/y of tiers 1 and 3
+        self.orig = env.batch.init_grid(1)[0]                            # pt.orig_x/y of tiers 1 and 3 (cloth.pyx:122-124)
+        n = int(round(np.sqrt(env.P)))
+        r, c = np.divmod(np.arange(env.P), n)
+        self.orig_y2 = c * (1.0 / (n - 1))                               # tier 2 (cloth.pyx:109-110): orig_y, orig_z
+        self.orig_z2 = r * (1.0 / (n - 1))
+
+    def draw(self, e):
+        """The next pick of env e: which of the highest points (0 = the highest)."""
+        return int(self.rngs[e].randint(self.top_k))
+
+    def target(self, e, i):
+        """analytic.py:742-789: (orig_x, orig_y) on the flat tiers; tier 2: (orig_z, orig_y) or (1 - orig_z, orig_y)."""
+        if self.env._init_type == 'tier2':
+            z = self.orig_z2[i]
+            return (z if self.env.init_side[e] else 1.0 - z), self.orig_y2[i]
+        return self.orig[i, 0], self.orig[i, 1]
 
     def get_action(self, obs, t=0):
         E = self.env.E
@@ -69,9 +87,10 @@ class HighestPointPolicy(object):
         acts = np.zeros((E, 4))
         for e in range(E):
             order = np.argsort(-pos[e, :, 2], kind="stable")             # sorted(..., key=z, reverse=True)
-            i = int(order[self.rngs[e].randint(self.top_k)])
-            cx, cy, dx, dy = _data_delta(pos[e, i, 0], pos[e, i, 1], self.orig[i, 0], self.orig[i, 1])[:4]
-            acts[e] = (cx, cy, dx, dy)
+            i = int(order[self.draw(e)])
+            tx, ty = self.target(e, i)
+            cx, cy, dx, dy, _, x, y = _data_delta(pos[e, i, 0], pos[e, i, 1], tx, ty)
+            acts[e] = (cx, cy, dx, dy) if self.env.cfg['env']['clip_act_space'] else (x, y, dx, dy)
         return acts
 
 

@@ -182,7 +182,10 @@ typedef struct ClothEpisodeParams {
 } ClothEpisodeParams;
 
 enum { CLOTHHIP_POLICY_TABLE = 0,          /* actions[t][e][4] given by the caller (any policy run on the host, or random) */
-       CLOTHHIP_POLICY_ORACLE_CORNER = 1   /* examples/analytic.py:105-155, 'distance' method, delta actions, 25x25 only */ };
+       CLOTHHIP_POLICY_ORACLE_CORNER = 1,  /* examples/analytic.py:105-155, 'distance' method, delta actions, 25x25 only */
+       CLOTHHIP_POLICY_HIGHEST_POINT = 2   /* examples/analytic.py:723-808: the k-th highest point (stable order), pulled to where it
+                                              sits on the flat cloth; k per slot and env from policy_arg (the reference draws it
+                                              with np.random.randint(top_k = 5)) */ };
 
 /* One scripted pull of a reset (cloth_env.py:851-877 tier 1, :959-978 tier 3): the raw RNG draws; everything that
  * depends on the particle state (the picked point's position, _prevent_oob) is evaluated on the device. */
@@ -231,8 +234,10 @@ typedef struct ClothResetRecord {
 } ClothResetRecord;
 
 /* T action slots for every env. policy: CLOTHHIP_POLICY_*. actions: [T][E][4] (TABLE), a HOST pointer unless
- * actions_on_device != 0 (a device table, e.g. after an RCCL broadcast). policy_arg[E] or NULL (ORACLE_CORNER: != 0 =
- * tier-2 cloth with init_side False, corner indices swapped, analytic.py:108-114). scripts: [E][n_scripts] or NULL -- the
+ * actions_on_device != 0 (a device table, e.g. after an RCCL broadcast). policy_arg: NULL, or how every cloth was built, int32[E]: 0 = the
+ * flat tiers, 1 = tier 2 with init_side False (ORACLE_CORNER then swaps its corner indices, analytic.py:108-114), 2 = tier 2
+ * with init_side True; a tier-2 reset inside the launch updates it. HIGHEST_POINT needs it and T more rows, int32[1 + T][E]:
+ * row 1 + t = which of the highest points (0 = the highest) the env pulls in its t-th slot. scripts: [E][n_scripts] or NULL -- the
  * env's next resets in order. Script k+1 is drawn (by the host) from the RNG state script k leaves when only its
  * unconditional pulls run; if a conditional pull (tier 1's third, cloth_env.py:866) does run, it consumes further draws,
  * the later scripts of that env are void, and the env idles once its next episode ends (the host re-draws them for the

@@ -262,6 +262,37 @@ def test_demo_writer_device_equals_host_loop_f64(tmp_path):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("tier", ["tier1", "tier2"])
+def test_highest_point_policy_on_the_device_equals_the_host_policy(tier):
+    """examples/analytic.py:723-808 evaluated in the kernel (k + 1 rounds of a stable arg-max over the heights, target = the
+    point's place on the flat cloth, tier 2's (orig_z, orig_y) / (1 - orig_z, orig_y) included) against the same policy run
+    on the host through ClothVecEnv.step, fed the same picks: identical actions, rewards, dones and observations over
+    whole episodes with their resets, fp64."""
+    from gym_cloth_amd.demos import collect_demos
+    from gym_cloth_amd.envs import ClothVecEnv
+    from gym_cloth_amd.policies import HighestPointPolicy
+
+    def make():
+        v = ClothVecEnv(base_cfg(tier, 1337), n_envs=3, precision="f64", consume_domrand_draws=False)
+        v.seed([1337, 1338, 1339])
+        return v
+    a, b = make(), make()
+    dev = collect_demos(a, HighestPointPolicy(a, seed=11), max_episodes=5, slots_per_launch=5, on_device=True)
+    host = collect_demos(b, HighestPointPolicy(b, seed=11), max_episodes=5)
+    by_env = lambda eps: {e: [ep for ep in eps if ep["env"] == e] for e in range(3)}
+    d, h = by_env(dev), by_env(host)
+    compared = steps = 0
+    for e in range(3):
+        for ed, eh in zip(d[e], h[e]):
+            assert ed["act"] == eh["act"] and ed["rew"] == eh["rew"] and ed["done"] == eh["done"], (tier, e)
+            for od, oh in zip(ed["obs"], eh["obs"]):
+                assert np.array_equal(od, oh.astype(np.float32))
+            assert ed["info"] == eh["info"]
+            compared += 1; steps += len(ed["act"])
+    assert compared >= 3 and steps >= 6
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("variant", ["force_grab", "no_clip", "grid50_f32"])
 def test_step_many_equals_sequential_other_configurations(variant):
     """The episode launch against sequential step() calls in configurations the other tests do not touch: force_grab (the
