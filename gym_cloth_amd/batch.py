@@ -317,7 +317,7 @@ class ClothBatch(object):
         check(self._L.clothhip_update(self._h, int(n), _lib.dp(d)))
 
     def debug_stats(self):
-        """[E,16]: [0..3] strain sweeps run, dense sweeps, levels executed, levels that corrected (last run);
+        """[E,16]: [0..3] strain sweeps run, windows walked, passes, passes that corrected (last run);
         [4..15] per-phase shader cycles/64 when CLOTHHIP_DEBUG_PHASES has bit 32 set."""
         st = np.zeros((self.E, 16), dtype=np.int32)
         check(self._L.clothhip_debug_stats(self._h, _lib.i32p(st)))

@@ -15,9 +15,9 @@
 //                                             have a seed: to-visit set = seeds + later neighbours of members that moved;
 //                                             four small cells per wave / one wave per large cell, LDS tickets
 //   plane            cloth.pyx:345-370        per point (owner thread: it holds the previous position)
-//   strain limit     cloth.pyx:258-296        dependency-level schedule walked by ONE wave: sparse (pending-level
-//                                             tracking) or dense (8 / 4 levels speculated per pass, first correcting
-//                                             level commits)
+//   strain limit     cloth.pyx:258-296        dependency levels packed into 64-slot windows (one spring per lane, lane order ==
+//                                             level order) walked by ONE wave from the first over-stretched spring to the last
+//                                             window its corrections can reach; per pass the first correcting level commits
 // DESIGN.md section 4 has the exactness argument of every phase.
 #pragma once
 
@@ -64,7 +64,7 @@ template <typename T> struct FusedArgs {
     int32_t n_scripts, _pad;
     // copies of StepArgs' static-table pointers: the LDS re-initialisation after the in-kernel metrics loads them from
     // here (plain global loads at the point of use) instead of keeping the kernel arguments alive across the substep loop
-    const uint32_t *lv_ent; const uint16_t *lv_off, *lv_off8, *pt_lev; const T *rest; int32_t rest_stride, _pad3;
+    const uint32_t *wt_ent; const T *rest; int32_t rest_stride, _pad3;
     T *rest_rw;                       // the same table, writable: a tier-2 reset rebuilds the env's rest lengths (cloth.pyx:417)
     double grid_dx, grid_dy;          // width / (N - 1), height / (N - 1) (cloth.pyx:55-56)
     uint32_t *mt;                     // [E][MT_WORDS] numpy RandomState of every env, or nullptr (resets come from `scripts`)
@@ -114,26 +114,19 @@ template <typename T> struct StepArgs {
     T *pos;                  // [E][3][Ppad]   (HBM layout: SoA, coalesced)
     T *prev;                 // [E][3][Ppad]
     uint8_t *cnt;            // [E][Ppad]  bits0..6 multiplicity in grabbed_pts, bit7 pinned from outside
-    const T *rest;           // [E or 1][Spad] rest lengths in LEVEL order
+    const T *rest;           // [E or 1][Spad] rest lengths in window-table SLOT order (0 in empty slots)
     int32_t *tear;           // [E] sticky Cloth.cloth_have_tear
     int32_t *executed;       // [E]
-    int32_t *stats;          // [E][16] or nullptr: [0..3] sweeps run, dense sweeps, levels executed, levels that corrected;
+    int32_t *stats;          // [E][16] or nullptr: [0] sweeps run, [1] windows walked, [2] passes, [3] passes that corrected;
                              // [4..15] with PH_TIME: shader cycles/64 spent per phase (wave 0's view)
     const ClothSchedule *sched;   // [E]
     const uint32_t *gather;  // [HK_SLOTS][Ppad]
-    const uint32_t *lv_ent;  // [Spad]  ptA | ptB<<16, level order
-    const uint16_t *lv_off;  // [n_levels+40] level offsets, padded with the end offset
-    const uint16_t *lv_off8; // [n_levels8+40] the same springs cut into levels of width <= 8 (sub-levels of the levels above)
-    const uint16_t *pt_lev;  // [HK_SLOTS][Ppad] dependency level of the k-th incident spring of a point (0xFFFF none)
-    int32_t n_levels;
+    const uint32_t *wt_ent;  // [Spad] window table of the strain sweep (cloth_tables.hpp), Spad = (nW + padding windows) * 64
+    int32_t nW, wt_rshift;   // windows that hold springs; unit (log2 windows) of the entries' reach field
     int32_t N, P, Ppad, S, Spad;
     int32_t HT, ht_bits;     // spatial hash table slots (power of two > P)
-    int32_t lvw_shift;       // lanes per level in the parallel pre-pass = 1 << lvw_shift (16 or 32)
     int32_t rest_stride;     // 0: one shared table
-    int32_t dense_thresh;    // pre-pass flagged levels above which the sweep stops tracking and runs every level
-    int32_t n_levels8;       // 0: no narrow table
     int32_t cell_copy;       // 1: LDS holds a cell-ordered copy of the particle records for the collision pre-check
-    int32_t narrow_thresh;   // dense sweep: at most this many flagged levels -> narrow table (8 levels per pass)
     int32_t phase_mask;      // debug/ablation: bit0 hooke+verlet, bit1 collide, bit2 plane, bit3 strain, bit4 no-skip
     DevConsts<T> k;
     // whole episodes on the device (clothhip_run_actions): a DEVICE pointer to the episode arguments, or nullptr = one
@@ -240,22 +233,22 @@ template <typename T> __device__ __forceinline__ uint32_t cell_key(const DevCons
     return (uint32_t)kb + KEY_FLOOR;
 }
 
+// Window-table entry as the sweep wave streams it: the static word of cloth_tables.hpp + the spring's rest length.
+template <typename T> struct WEnt;
+template <> struct __attribute__((aligned(8))) WEnt<float> { uint32_t ab; float rest; };
+template <> struct __attribute__((aligned(16))) WEnt<double> { uint32_t ab; uint32_t _pad; double rest; };
+
 // LDS carve-up (dynamic shared memory), all offsets in bytes, 16-byte aligned.
-// tab: 0 = static tables stay in global memory, 1 = ent/rest/off in LDS, 2 = + per-point level table
+// tab: 0 = the window table stays in global memory (L2), 1 = table + rest lengths resident in LDS
 struct LdsLayout {
-    int cur, eps, ent, rest, off, off8, plev, flag, abits, hkey, hco, memb, slot, misc, alist, olist, cpos, total;
-    __host__ __device__ LdsLayout(int tsz, int Ppad, int Spad, int nL, int nL8, int HT, int tab, int cp) {
+    int cur, eps, wtab, hkey, hco, memb, slot, misc, alist, olist, cpos, total;
+    __host__ __device__ LdsLayout(int tsz, int Ppad, int Spad, int HT, int tab, int cp) {
         int o = 0;
         auto take = [&](int bytes) { int r = o; o += (bytes + 15) / 16 * 16; return r; };
         cur = take(4 * Ppad * tsz);
         eps = take(176);             // EpState (fused episodes)
-        ent = take(tab >= 1 ? Spad * 4 : 0);
-        rest = take(tab >= 1 ? Spad * tsz : 0);
-        off = take(tab >= 1 ? (nL + 40) * 2 : 0);       // padded: levels past the end are empty
-        off8 = take(tab >= 1 && nL8 > 0 ? (nL8 + 40) * 2 : 0);
-        plev = take(tab >= 2 ? HK_SLOTS * Ppad * 2 : 0);
-        flag = take(nL + 64);        // pending-level marks of the running sweep (all zero between sweeps)
-        abits = take((Spad / 64 + 2) * 8);   // pre-pass: one bit per spring (level order)
+        wtab = take(tab >= 1 ? Spad * (tsz == 8 ? 16 : 8) : 0);   // WEnt<T>[Spad]; everything from here on doubles as scratch of the
+                                                                  // in-kernel metrics and is rebuilt afterwards
         hkey = take(HT * 4);
         hco = take(HT * 4);          // (fill cursor << 16) | member count
         memb = take(Ppad * 2);
@@ -269,43 +262,111 @@ struct LdsLayout {
     }
 };
 
-// One spring of the strain limiter, exactly as cloth.pyx:265-296 evaluates it. Returns which endpoints were
-// moved (bit0: ptA, bit1: ptB; 0 = no correction). `tear` is OR-ed.
-template <typename T>
-__device__ __forceinline__ int strain_apply(Pt<T> *cur, uint32_t en, const Pt<T> &A, const Pt<T> &B, T r,
-                                            const DevConsts<T> &k, int &tear);
-
-template <typename T>
-__device__ __forceinline__ int strain_spring(Pt<T> *cur, uint32_t en, T r, const DevConsts<T> &k, int &tear) {
-    const Pt<T> A = cur[en & 0xFFFFu], B = cur[en >> 16];   // two 16-byte LDS reads (positions + pin state)
-    return strain_apply<T>(cur, en, A, B, r, k, tear);
-}
-
-// The spring update given its two particle records (already loaded).
-template <typename T>
-__device__ __forceinline__ int strain_apply(Pt<T> *cur, uint32_t en, const Pt<T> &A, const Pt<T> &B, T r,
-                                            const DevConsts<T> &k, int &tear) {
-    const int a = (int)(en & 0xFFFFu), b = (int)(en >> 16);
-    const uint32_t ca = w_cnt(A.w), cb = w_cnt(B.w);
-    const T dx = A.x - B.x, dy = A.y - B.y, dz = A.z - B.z;
-    const T len2 = sumsq<T>(dx, dy, dz);
-    const T t11 = r * k.c11, tt = r * k.tear_thresh;
-    const T tmin = t11 < tt ? t11 : tt;
-    // both pinned: skipped (:268); below the conservative bound: certainly neither tear nor stretch
-    if (((ca != 0) & (cb != 0)) | !(len2 > tmin * tmin * ((T)1 - filt_slack<T>()))) return 0;
-    const T len = dev_sqrt<T>(len2);                                                    // :270
-    if (len > tt) tear = 1;                                                             // :272
-    if (!(len > t11)) return 0;                                                         // :275
-    const T ux = dev_div<T>(dx, len), uy = dev_div<T>(dy, len), uz = dev_div<T>(dz, len);   // :276-278
-    const T extra = len - t11;                                                          // :279
-    // A pinned: B += dir*extra ; B pinned: A -= dir*extra ; else A -= dir*(extra*0.5), B += dir*(extra*0.5)
-    // (extra * 1.0 == extra exactly, so one weighted form covers the three reference branches, :281-296)
-    const T wa = ca != 0 ? (T)0 : (cb != 0 ? (T)1 : (T)0.5);
-    const T wb = cb != 0 ? (T)0 : (ca != 0 ? (T)1 : (T)0.5);
-    const T ea = extra * wa, eb = extra * wb;
-    if (ca == 0) cur[a] = Pt<T>{mad<T>(-ux, ea, A.x), mad<T>(-uy, ea, A.y), mad<T>(-uz, ea, A.z), A.w};
-    if (cb == 0) cur[b] = Pt<T>{mad<T>(ux, eb, B.x), mad<T>(uy, eb, B.y), mad<T>(uz, eb, B.z), B.w};
-    return (ca == 0 ? 1 : 0) | (cb == 0 ? 2 : 0);
+// Strain limit + tear (cloth.pyx:258-296) by ONE wave, exactly in the reference's order.
+//
+// The springs sit in the window table (cloth_tables.hpp): window = 64 slots = one spring per lane, consecutive dependency
+// levels in lane order, each level one "group". A pass evaluates every not yet finished group of the window against the same
+// particle state; the FIRST group (in level order) that holds an over-stretched spring commits its corrections -- the springs of
+// a level share no particle -- the groups before it are finished (they provably changed nothing), the groups behind it may have
+// read stale particles and are evaluated again by the next pass. A window without a correction costs one pass.
+// The walk starts at the window of the first spring the pre-pass flagged (nothing before it is over-stretched and nothing has
+// moved yet) and ends behind the last window that can hold work: the last flagged spring, pushed out by every correction to the
+// last window that holds a spring of one of the two moved particles (the entry's static `reach`). Everything outside
+// [w0, w_end] provably evaluates to "no correction, no tear".
+// Entry stream: lane-private, coalesced, read PF windows ahead (LDS or, for the large grids, L2).
+template <typename T, bool LDS_TAB, bool TIMED, bool STATS>
+__device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const uint32_t *g_ent, const T *g_rest, int w0, int w_end,
+                                            int nW, int rshift, const DevConsts<T> &k, int lane, int &st_windows, int &st_passes, int &st_commits,
+                                            unsigned long long *tph) {
+    constexpr int PF = LDS_TAB ? 1 : 3;
+    static_assert(PF + 1 <= WT_PAD_WINDOWS, "the table is padded by the read-ahead distance");
+    int tear = 0;
+    DevConsts<T> kl = k;                         // spring-test constants pinned in VGPRs
+    asm volatile("" : "+v"(kl.c11), "+v"(kl.tear_thresh));
+    const bool tic = __builtin_amdgcn_readfirstlane(!(k.tear_thresh < k.c11) ? 1 : 0) != 0;   // tear implies stretch (the usual case)
+    uint32_t eab[PF + 1]; T erest[PF + 1];
+    auto load = [&](int wi, uint32_t &ab_, T &r_) {
+        if (LDS_TAB) { const WEnt<T> e_ = wt[wi * 64 + lane]; ab_ = e_.ab; r_ = e_.rest; }
+        else { ab_ = g_ent[wi * 64 + lane]; r_ = g_rest[wi * 64 + lane]; }
+    };
+#pragma unroll
+    for (int j = 0; j <= PF; j++) load(w0 + j, eab[j], erest[j]);
+    for (int w = w0; w <= w_end; w++) {
+        const uint32_t ab = eab[0];
+        const T rest = erest[0];
+#pragma unroll
+        for (int j = 0; j < PF; j++) { eab[j] = eab[j + 1]; erest[j] = erest[j + 1]; }
+        load(w + PF + 1, eab[PF], erest[PF]);
+        const int a = (int)(ab & WT_IDX_MASK), b = (int)((ab >> WT_IDX_BITS) & WT_IDX_MASK);
+        const uint32_t gid = (ab >> WT_GROUP_SHIFT) & 15u;
+        Pt<T> PA = cur[a], PB = cur[b];
+        const uint32_t ca = w_cnt(PA.w), cb = w_cnt(PB.w);          // pins do not change during a sweep
+        const bool both = (ca != 0) & (cb != 0);                    // skipped by the reference (:268)
+        const T t11 = rest * kl.c11;
+        unsigned long long pend = ~0ull;                            // lanes whose group is not finished
+        if (STATS) st_windows++;
+        for (;;) {
+            unsigned long long td0 = 0;
+            if (TIMED) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(td0)::"memory"); }
+            const T dx = PA.x - PB.x, dy = PA.y - PB.y, dz = PA.z - PB.z;
+            const T len2 = sumsq<T>(dx, dy, dz);
+            bool trig;
+            T len;
+            if constexpr (sizeof(T) == 4) {      // one v_sqrt: cheaper than a branch around it
+                len = dev_sqrt<T>(len2);                                        // :270
+                trig = !both && len > t11;                                      // :275
+            } else {
+                trig = false; len = (T)0;
+                if (!both && (len2 > t11 * t11 * ((T)1 - filt_slack<T>()))) {
+                    len = dev_sqrt<T>(len2);
+                    trig = len > t11;
+                }
+            }
+            const unsigned long long tb = ballot64(trig) & pend;
+            if (STATS) st_passes++;
+            if (!tic) {          // tear_thresh < 1.1: a spring can tear without stretching, so every finished spring is tested (:272)
+                asm volatile("" ::: "memory");
+                const uint32_t gq = tb ? (uint32_t)__builtin_amdgcn_readlane((int)gid, __ffsll((long long)tb) - 1) : 16u;
+                const bool mine = ((pend >> lane) & 1ull) != 0ull && gid <= gq;
+                if (mine && !both && dev_sqrt<T>(len2) > rest * kl.tear_thresh) tear = 1;
+            }
+            if (!tb) {
+                if (TIMED) { unsigned long long td1; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(td1)::"memory"); tph[10] += td1 - td0; tph[9] += 64; }
+                break;
+            }
+            const int fl = __ffsll((long long)tb) - 1;                          // first over-stretched spring in level order
+            const uint32_t abf = (uint32_t)__builtin_amdgcn_readlane((int)ab, fl);
+            const uint32_t g = (abf >> WT_GROUP_SHIFT) & 15u;
+            const int reach = w + ((int)(abf >> WT_REACH_SHIFT) << rshift);     // (rounded up to the reach unit: at most 2^rshift - 1
+            w_end = reach > w_end ? reach : w_end;                               //  empty padding windows behind the last one get walked)
+            if (STATS) st_commits++;
+            if (trig && gid == g) {
+                if (tic && len > rest * kl.tear_thresh) tear = 1;                   // :272
+                const T ux = dev_div<T>(dx, len), uy = dev_div<T>(dy, len), uz = dev_div<T>(dz, len);   // :276-278
+                const T extra = len - t11;                                          // :279
+                // A pinned: B += dir*extra ; B pinned: A -= dir*extra ; else A -= dir*(extra*0.5), B += dir*(extra*0.5)
+                // (extra * 1.0 == extra exactly, so one weighted form covers the three reference branches, :281-296)
+                uint32_t ca_ = ca, cb_ = cb;
+                asm volatile("" : "+v"(ca_), "+v"(cb_));      // computed here, not hoisted into every window's set-up
+                const T wa = ca_ != 0 ? (T)0 : (cb_ != 0 ? (T)1 : (T)0.5);
+                const T wb = cb_ != 0 ? (T)0 : (ca_ != 0 ? (T)1 : (T)0.5);
+                const T ea = extra * wa, eb = extra * wb;
+                // branch-free: a pinned end has weight 0 and x - u*0 == x exactly (u is finite: len > 0 here), so writing it
+                // back unchanged equals the reference's skipped assignment; the springs of a level share no particle, so
+                // nobody else writes these two records in this pass
+                cur[a] = Pt<T>{mad<T>(-ux, ea, PA.x), mad<T>(-uy, ea, PA.y), mad<T>(-uz, ea, PA.z), PA.w};
+                cur[b] = Pt<T>{mad<T>(ux, eb, PB.x), mad<T>(uy, eb, PB.y), mad<T>(uz, eb, PB.z), PB.w};
+            }
+            pend = ballot64(gid > g);
+            if (TIMED) { unsigned long long td1; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(td1)::"memory"); tph[11] += td1 - td0; }
+            if (!pend) break;
+            // same-wave LDS operations execute in program order: the reads below see the writes above without waiting for
+            // them; the barrier only pins the compiler's ordering
+            __builtin_amdgcn_wave_barrier();
+            PA = cur[a]; PB = cur[b];
+        }
+    }
+    return tear;
 }
 
 // Self-collision of ONE spatial cell (cloth.pyx:313-343) by a whole wave, exact Gauss-Seidel order:
@@ -663,24 +724,22 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
         sc.break_on_tear = 1; sc.active = 1; sc._pad = 0;
         sc.dz_up = sc.dx_pull = sc.dy_pull = sc.dz_pull = 0.0;
     }
-    const int P = A.P, Ppad = A.Ppad, nL = A.n_levels, HT = A.HT;
-    const LdsLayout lay((int)sizeof(T), Ppad, A.Spad, nL, A.n_levels8, HT, TAB, A.cell_copy);
+    const int P = A.P, Ppad = A.Ppad, HT = A.HT;
+    const LdsLayout lay((int)sizeof(T), Ppad, A.Spad, HT, TAB, A.cell_copy);
     Pt<T> *cur = reinterpret_cast<Pt<T> *>(smem + lay.cur);
-    uint8_t *lvflag = smem + lay.flag;
     uint32_t *hkey = reinterpret_cast<uint32_t *>(smem + lay.hkey);
     uint32_t *hco = reinterpret_cast<uint32_t *>(smem + lay.hco);
     uint16_t *memb = reinterpret_cast<uint16_t *>(smem + lay.memb);
     uint16_t *slot = reinterpret_cast<uint16_t *>(smem + lay.slot);
-    int *misc = reinterpret_cast<int *>(smem + lay.misc);   // [0] tear, [1] #levels flagged by the pre-pass, [2] #active cells, [3] #occupied cells, [4] member cursor, [5],[6] cell tickets
+    int *misc = reinterpret_cast<int *>(smem + lay.misc);   // [0] tear, [1] #springs flagged by the pre-pass, [2] #active cells, [3] #occupied cells, [4] member cursor, [5],[6] cell tickets, [10],[11] first / last flagged slot
     uint16_t *olist = reinterpret_cast<uint16_t *>(smem + lay.olist);
     uint16_t *alist_end = olist + (Ppad - 1);            // active list grows downwards: entry k = alist_end[-k]
     Pt<T> *cpos = reinterpret_cast<Pt<T> *>(smem + lay.cpos);
     const DevConsts<T> &k = A.k;
     const T *g_rest = A.rest + (size_t)e * A.rest_stride;
-    const uint32_t *ent = TAB >= 1 ? reinterpret_cast<const uint32_t *>(smem + lay.ent) : A.lv_ent;
-    const T *rest = TAB >= 1 ? reinterpret_cast<const T *>(smem + lay.rest) : g_rest;
-    const uint16_t *loff = TAB >= 1 ? reinterpret_cast<const uint16_t *>(smem + lay.off) : A.lv_off;
-    const uint16_t *plev = TAB >= 2 ? reinterpret_cast<const uint16_t *>(smem + lay.plev) : A.pt_lev;
+    const WEnt<T> *wtab = reinterpret_cast<const WEnt<T> *>(smem + lay.wtab);    // TAB >= 1 only
+    // rest length of the spring in window-table slot i (Hooke, pre-pass; the sweep streams its own)
+    auto rest_at = [&](uint32_t i) -> T { return TAB >= 1 ? wtab[i].rest : g_rest[i]; };
     const int pm = A.phase_mask;
 
     T pvx[PPT], pvy[PPT], pvz[PPT];         // previous positions of the owned particles
@@ -709,36 +768,34 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
     }
     // everything in LDS behind the particle records: static tables, hash table, sweep flags (also re-run after the in-kernel
     // metrics, which borrow that region as scratch)
-    auto init_lds = [&](int tear_flag, const uint32_t *s_ent, const T *s_rest, const uint16_t *s_off, const uint16_t *s_off8,
-                        const uint16_t *s_plev) {
+    auto init_lds = [&](int tear_flag, const uint32_t *s_ent, const T *s_rest) {
         if (TAB >= 1) {
-            uint32_t *d0 = reinterpret_cast<uint32_t *>(smem + lay.ent);
-            T *d1 = reinterpret_cast<T *>(smem + lay.rest);
-            for (int i = tid; i < A.Spad; i += NT) { d0[i] = s_ent[i]; d1[i] = s_rest[i]; }
-            uint16_t *d2 = reinterpret_cast<uint16_t *>(smem + lay.off);
-            for (int i = tid; i < nL + 40; i += NT) d2[i] = s_off[i];
-            uint16_t *d3 = reinterpret_cast<uint16_t *>(smem + lay.off8);
-            for (int i = tid; i < (A.n_levels8 > 0 ? A.n_levels8 + 40 : 0); i += NT) d3[i] = s_off8[i];
-        }
-        if (TAB >= 2) {
-            uint16_t *d4 = reinterpret_cast<uint16_t *>(smem + lay.plev);
-            for (int i = tid; i < HK_SLOTS * Ppad; i += NT) d4[i] = s_plev[i];
+            WEnt<T> *d0 = reinterpret_cast<WEnt<T> *>(smem + lay.wtab);
+            for (int i = tid; i < A.Spad; i += NT) { WEnt<T> w_; w_.ab = s_ent[i]; w_.rest = s_rest[i]; d0[i] = w_; }
         }
         for (int h = tid; h < HT; h += NT) { hkey[h] = KEY_EMPTY; hco[h] = 0; }
-        for (int i = tid; i < nL + 64; i += NT) lvflag[i] = 0;
-        for (int i = tid; i < (A.Spad / 64 + 2) * 2; i += NT) reinterpret_cast<uint32_t *>(smem + lay.abits)[i] = 0u;
-        if (tid == 0) { misc[0] = tear_flag; misc[1] = 0; misc[2] = 0; misc[3] = 0; misc[4] = 0; misc[5] = 0; misc[6] = 0; misc[10] = 0x7fffffff; }
+        if (tid == 0) { misc[0] = tear_flag; misc[1] = 0; misc[2] = 0; misc[3] = 0; misc[4] = 0; misc[5] = 0; misc[6] = 0; misc[10] = 0x7fffffff; misc[11] = -1; }
     };
-    init_lds(A.tear[e], A.lv_ent, g_rest, A.lv_off, A.lv_off8, A.pt_lev);
+    init_lds(A.tear[e], A.wt_ent, g_rest);
     __syncthreads();
 
-    int st_sweeps = 0, st_dense = 0, st_levels = 0, st_trig = 0;      // wave 0 only (uniform)
+    int st_sweeps = 0, st_windows = 0, st_passes = 0, st_commits = 0;      // wave 0 only (uniform)
     unsigned long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0, tstart = 0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tstart)::"memory");   // whole-schedule clock of this cloth (stats[15])
 #ifdef CLOTHHIP_PHASE_STAMPS                 // profiling build (make stamps): phase mask bit 32 turns the stamps on
     const bool timing = (pm & PH_TIME) != 0;
 #else
     constexpr bool timing = false;          // the stamp accumulators would cost the hot loops two dozen SGPRs
+#endif
+#ifdef CLOTHHIP_SWEEP_STAMPS            // profiling build of the strain sweep: cycles per quiet / correcting pass
+    constexpr bool SWEEP_TIMED = true;
+#else
+    constexpr bool SWEEP_TIMED = false;
+#endif
+#ifdef CLOTHHIP_PHASE_STAMPS            // the sweep's window / pass / correction counters cost its loop three instructions per pass:
+    constexpr bool SWEEP_STATS = true;  // profiling builds only (the production build counts sweeps)
+#else
+    constexpr bool SWEEP_STATS = false;
 #endif
 #define TSTAMP(slot_)                                                          \
     if (timing) {                                                              \
@@ -844,7 +901,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                             // per point in r-major order (row 0 draws too, its noise is zeroed), and rest lengths measured on
                             // these positions (cloth.pyx:417) -- in double, as the host's clothhip_init_grid does, through a
                             // scratch copy behind the particle records
-                            double *dpos = reinterpret_cast<double *>(smem + lay.ent);
+                            double *dpos = reinterpret_cast<double *>(smem + lay.wtab);
                             if (tid == 0) {
                                 side_ = mt_double(mt) > 0.5 ? 1 : 0;                             // cloth.pyx:75
                                 const int N_ = A.N;
@@ -869,14 +926,14 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                                 if (i < P) { pvx[q] = (T)dpos[3 * i]; pvy[q] = (T)dpos[3 * i + 1]; pvz[q] = (T)dpos[3 * i + 2]; }
                             }
                             T *rw = F.rest_rw + (size_t)e * F.rest_stride;
-                            for (int p_ = tid; p_ < A.S; p_ += NT) {
-                                const uint32_t en = F.lv_ent[p_];
-                                const double *PA = dpos + 3 * (en & 0xFFFFu), *PB = dpos + 3 * (en >> 16);
+                            for (int p_ = tid; p_ < A.Spad; p_ += NT) {
+                                const uint32_t en = F.wt_ent[p_];                                 // empty slots: ptA == ptB == 0 -> 0
+                                const double *PA = dpos + 3 * (en & WT_IDX_MASK), *PB = dpos + 3 * ((en >> WT_IDX_BITS) & WT_IDX_MASK);
                                 const double ux = PA[0] - PB[0], uy = PA[1] - PB[1], uz = PA[2] - PB[2];
                                 rw[p_] = (T)sqrt(ux * ux + uy * uy + uz * uz);                    // cloth.pyx:417 via :17-18
                             }
                             __syncthreads();
-                            init_lds(0, F.lv_ent, F.rest + (size_t)e * F.rest_stride, F.lv_off, F.lv_off8, F.pt_lev);
+                            init_lds(0, F.wt_ent, F.rest + (size_t)e * F.rest_stride);
                             if (REST_REG) {
 #pragma unroll
                                 for (int q = 0; q < PPT; q++)
@@ -1266,7 +1323,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                             nbq[sl % HK_AHEAD] = cur[gn & HK_NBR_MASK];
                         }
                         __builtin_amdgcn_sched_barrier(0);  // the reads above stay above the arithmetic below
-                        const T r = REST_REG ? rr[REST_REG ? q : 0][sl] : rest[(g >> HK_POS_SHIFT) & HK_POS_MASK];
+                        const T r = REST_REG ? rr[REST_REG ? q : 0][sl] : rest_at((g >> HK_POS_SHIFT) & HK_POS_MASK);
                         const T kk = (g & HK_BEND) ? k.ks_bend : k.ks_str;
                         const T dx = nb.x - me.x, dy = nb.y - me.y, dz = nb.z - me.z;
                         const T l = fastnorm<T>(dx, dy, dz);                                      // :231
@@ -1545,18 +1602,17 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
 
         TSTAMP(7)
         // ---- strain limit + tear (cloth.pyx:258-296) ---------------------------------------------------
-        // (1) all threads: which levels hold a spring that would stretch/tear at the CURRENT positions?
-        //     A spring untouched by earlier corrections of the sweep behaves exactly as evaluated here.
-        // (2) wave 0 walks the dependency levels in order. It runs a level only if the pre-pass flagged it or
-        //     an earlier correction of this sweep moved a particle one of its springs is attached to (the
-        //     correction marks exactly those levels); everything it skips is provably a no-op.
+        // (1) all threads: which springs would stretch/tear at the CURRENT positions? Only the first and the last of them
+        //     (in window-table order) are kept: a spring untouched by earlier corrections of the sweep behaves exactly as
+        //     evaluated here, so nothing before the first needs a look, and nothing behind the last unless a correction
+        //     reaches it. No spring flagged: the sweep is skipped (a cloth at rest).
+        // (2) wave 0 walks the windows in between (strain_sweep above).
         if (pm & PH_STRAIN) {
             {
                 // Every spring is tested once, by the owner of its ptB (the particle the reference appended it for):
-                // the owner holds the spring's gather entry (neighbour = ptA, level-order position) and, with
+                // the owner holds the spring's gather entry (neighbour = ptA, table slot) and, with
                 // REST_REG, its rest length in registers, so the pre-pass needs one 16-byte LDS read per spring.
-                uint32_t *abits32 = reinterpret_cast<uint32_t *>(smem + lay.abits);
-                int nact = 0, pmin = 0x7fffffff;     // flagged springs; the first of them in level order
+                int nact = 0, pmin = 0x7fffffff, pmax = -1;     // flagged springs; the first / last of them in table order
 #pragma unroll
                 for (int q = 0; q < PPT; q++) {
                     if (tid + q * NT < P) {
@@ -1589,7 +1645,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                                 nbq[sl % PP_AHEAD] = cur[gn & HK_NBR_MASK];
                             }
                             __builtin_amdgcn_sched_barrier(0);
-                            T r = REST_REG ? rr[REST_REG ? q : 0][sl] : rest[(g >> HK_POS_SHIFT) & HK_POS_MASK];
+                            T r = REST_REG ? rr[REST_REG ? q : 0][sl] : rest_at((g >> HK_POS_SHIFT) & HK_POS_MASK);
                             asm volatile("" : "+v"(r));     // or the thresholds below are hoisted out of the substep loop
                                                             // for all 18 springs and live in scratch
                             const T dx = nb.x - me.x, dy = nb.y - me.y, dz = nb.z - me.z;   // (ptA - ptB), as :270
@@ -1610,292 +1666,41 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                             for (int sl = 0; sl < HK_SLOTS / 2; sl++) {
                                 if (cand & (1u << sl)) {
                                     const uint32_t pos_ = (gl[sl] >> HK_POS_SHIFT) & HK_POS_MASK;
-                                    T r = REST_REG ? rr[REST_REG ? q : 0][sl] : rest[pos_];
+                                    T r = REST_REG ? rr[REST_REG ? q : 0][sl] : rest_at(pos_);
                                     asm volatile("" : "+v"(r));
                                     const T len2 = l2s[sl];
                                     const T t11 = r * k.c11, tt = r * k.tear_thresh;
                                     const T tmin = t11 < tt ? t11 : tt;
                                     bool flag = len2 > tmin * tmin * ((T)1 + filt_slack<T>());
                                     if (!flag) { const T len = dev_sqrt<T>(len2); flag = len > t11 || len > tt; }
-                                    if (flag) { atomicOr(&abits32[pos_ >> 5], 1u << (pos_ & 31)); nact++; pmin = (int)pos_ < pmin ? (int)pos_ : pmin; }
+                                    if (flag) { nact++; pmin = (int)pos_ < pmin ? (int)pos_ : pmin; pmax = (int)pos_ > pmax ? (int)pos_ : pmax; }
                                 }
                             }
                         }
                     }
                 }
                 if (__any(nact)) {
-                    const int tot_ = __builtin_amdgcn_readlane(wave_incl_scan(nact), 63);        // DPP: no LDS round trips
-                    const int min_ = __builtin_amdgcn_readlane(wave_incl_min(pmin), 63);
-                    if (lane == 0) { atomicAdd(&misc[1], tot_); atomicMin(&misc[10], min_); }
+                    const int min_ = __builtin_amdgcn_readlane(wave_incl_min(pmin), 63);         // DPP: no LDS round trips
+                    const int max_ = -__builtin_amdgcn_readlane(wave_incl_min(-pmax), 63);
+                    if (lane == 0) { misc[1] = 1; atomicMin(&misc[10], min_); atomicMax(&misc[11], max_); }
                 }
             }
             __syncthreads();
             TSTAMP(8)
             if (tid < 64 && (misc[1] || (pm & PH_NOSKIP))) {
                 __builtin_amdgcn_s_setprio(3);            // the serial sweep is the critical path of the whole cloth
-                int tear = 0;
-                // dense: so many levels are flagged that tracking costs more than it saves -> run every level.
-                // sparse: a correction marks exactly the later levels that hold a spring of a moved particle.
-                const bool dense = (pm & PH_NOSKIP) || misc[1] > A.dense_thresh;
-                // marking roles: lanes 0..23 serve the first corrected spring of a pass, 24..47 the second
-                const bool mk_on = lane < 4 * HK_SLOTS;
-                const bool mk_grp = lane >= 2 * HK_SLOTS;
-                const int mk_s = lane - (mk_grp ? 2 * HK_SLOTS : 0);
-                const bool mk_isb = mk_s >= HK_SLOTS;
-                const int mk_k = mk_on ? mk_s - (mk_isb ? HK_SLOTS : 0) : 0;
-                st_sweeps++; st_dense += dense ? 1 : 0;
-                if (dense) {
-                    // Dense sweep: so many springs are over-stretched that (almost) every level has to run. The wave is
-                    // split into GR = 64/lvw lane groups and each pass evaluates GR CONSECUTIVE levels at once, one per
-                    // group, against the same particle state. The first group (in level order) that applies a
-                    // correction commits it; later groups may have read stale particles, so they are discarded and
-                    // re-evaluated by the next pass; groups before it provably changed nothing. This is exactly the
-                    // sequential sweep, ~3 levels per pass instead of 1.
-                    // A lane streams its own sub-sequence of the fixed-width level table (levels = res mod GR) from L2,
-                    // two entries ahead. Empty slots hold ptA == ptB == 0, which can never stretch (len2 == 0).
-                    // Few flagged levels: most passes find nothing to correct, so the narrow table (same springs, levels cut
-                    // to width <= 8) lets a pass look at 8 levels instead of 64/lvw.
-                    const bool narrow = A.n_levels8 > 0 && misc[1] <= A.narrow_thresh && !(pm & PH_NOSKIP);
-                    const int lsh = narrow ? 3 : A.lvw_shift, lvw = 1 << lsh, GR = 64 >> lsh;   // lvw is a power of two
-                    const int res = lane >> lsh;
-                    DevConsts<T> kl = k;                         // spring-test constants pinned in VGPRs
-                    asm volatile("" : "+v"(kl.c11), "+v"(kl.tear_thresh));
-                    const bool tic = __builtin_amdgcn_readfirstlane(!(k.tear_thresh < k.c11) ? 1 : 0) != 0;   // (wave-uniform)
-                    const int sl = lane & (lvw - 1);
-                    int myL = res;                               // the level this lane currently holds
-                    int Ls = 0;                                  // the sweep starts at the level of the first flagged spring:
-                    {                                            // every level before it is unflagged and nothing has moved yet
-                        const uint16_t *loffS = narrow ? (TAB >= 1 ? reinterpret_cast<const uint16_t *>(smem + lay.off8) : A.lv_off8) : loff;
-                        const int pfirst = misc[10];
-                        if (!(pm & PH_NOSKIP) && pfirst < A.S) {
-                            int lo_ = 0, hi_ = narrow ? A.n_levels8 : nL;
-                            while (hi_ - lo_ > 1) { const int mid_ = (lo_ + hi_) >> 1; if ((int)loffS[mid_] <= pfirst) lo_ = mid_; else hi_ = mid_; }
-                            Ls = __builtin_amdgcn_readfirstlane(lo_) & ~(GR - 1);
-                        }
-                        myL = res + Ls;
-                    }
-                    {
-                        // Lane-private stream over the compact level table (LDS, or L2 for the large grids): entry index = off[level] + slot,
-                        // a slot beyond the level's width reads the all-zero padding entry S (ptA == ptB == 0).
-                        // Every pass re-issues the loads of the NEXT entry unconditionally (same address while the lane
-                        // has not consumed), so no loaded value is touched before the following pass.
-                        const int ZE = A.S;                      // index of a zero entry (Spad > S, zero filled)
-                        const uint16_t *loffD = narrow ? (TAB >= 1 ? reinterpret_cast<const uint16_t *>(smem + lay.off8) : A.lv_off8) : loff;
-                        const int nLD = narrow ? A.n_levels8 : nL;
-                        int p0 = (int)loffD[myL] + sl; p0 = p0 < (int)loffD[myL + 1] ? p0 : ZE;
-                        int pn = (int)loffD[myL + GR] + sl; pn = pn < (int)loffD[myL + GR + 1] ? pn : ZE;
-                        uint32_t ec = ent[p0]; T rc = rest[p0];
-                        uint32_t e1 = ent[pn]; T r1 = rest[pn];
-                        int olo = (int)loffD[myL + 2 * GR], ohi = (int)loffD[myL + 2 * GR + 1];
-                        Pt<T> PA = cur[ec & 0xFFFFu], PB = cur[ec >> 16];
-                        int L = Ls;
-                        while (L < nLD) {
-#ifdef CLOTHHIP_SWEEP_STAMPS
-                            unsigned long long td0 = 0;
-                            if (timing) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(td0)::"memory"); }
-#endif
-                            const int grp = myL - L;             // 0..GR-1: position of my level inside this pass
-                            const int a = (int)(ec & 0xFFFFu), b = (int)(ec >> 16);
-                            const uint32_t ca = w_cnt(PA.w), cb = w_cnt(PB.w);
-                            const T dx = PA.x - PB.x, dy = PA.y - PB.y, dz = PA.z - PB.z;
-                            const T len2 = sumsq<T>(dx, dy, dz);
-                            const T t11 = rc * kl.c11;
-                            // the tear test (:272, len > tear_thresh * rest): with tear_thresh >= 1.1 (`tic`, the usual case) only
-                            // a spring that also stretches can tear, so the test moves into the commit; otherwise per level
-                            bool trig;
-                            T len;
-                            if constexpr (sizeof(T) == 4) {      // one v_sqrt: cheaper than a branch around it
-                                len = dev_sqrt<T>(len2);                                        // :270
-                                const bool live = !(ca != 0 && cb != 0);                        // :268
-                                trig = live && len > t11;                                       // :275
-                            } else {
-                                trig = false; len = (T)0;
-                                if (!(ca != 0 && cb != 0) && (len2 > t11 * t11 * ((T)1 - filt_slack<T>()))) {
-                                    len = dev_sqrt<T>(len2);
-                                    trig = len > t11;
-                                }
-                            }
-                            const unsigned long long tb = ballot64(trig);
-                            // groups sit in lane ranges by residue class; rotate so that bit order == level order
-                            const int rot = (L & (GR - 1)) << lsh;
-                            const unsigned long long tr = rot ? ((tb >> rot) | (tb << (64 - rot))) : tb;
-                            const int g = tr ? (__ffsll((long long)tr) - 1) >> lsh : GR;        // first correcting level of the pass
-                            const bool commit = trig && grp == g;
-                            const int adv = g < GR ? g + 1 : GR;
-                            L += adv;
-                            // lanes whose level is done move on to their next level (branch-free consume)
-                            const bool cons = myL < L;
-                            const uint32_t ecn = cons ? e1 : ec;
-                            if (commit) {
-                                if (tic && len > rc * kl.tear_thresh) tear = 1;                 // :272
-                                const T ux = dev_div<T>(dx, len), uy = dev_div<T>(dy, len), uz = dev_div<T>(dz, len);   // :276-278
-                                const T extra = len - t11;                                      // :279
-                                const T wa = ca != 0 ? (T)0 : (cb != 0 ? (T)1 : (T)0.5);
-                                const T wb = cb != 0 ? (T)0 : (ca != 0 ? (T)1 : (T)0.5);
-                                const T ea = extra * wa, eb = extra * wb;
-                                // branch-free: a pinned end has weight 0 and x - u*0 == x exactly (u is finite: len > 0 here), so
-                                // writing it back unchanged equals the reference's skipped assignment; the springs of a level
-                                // share no particle, so nobody else writes these two records in this pass
-                                cur[a] = Pt<T>{mad<T>(-ux, ea, PA.x), mad<T>(-uy, ea, PA.y), mad<T>(-uz, ea, PA.z), PA.w};
-                                cur[b] = Pt<T>{mad<T>(ux, eb, PB.x), mad<T>(uy, eb, PB.y), mad<T>(uz, eb, PB.z), PB.w};
-                            }
-                            // same-wave LDS operations execute in program order: the reads below see the writes
-                            // above without waiting for them; the barrier only pins the compiler's ordering
-                            __builtin_amdgcn_wave_barrier();
-                            PA = cur[ecn & 0xFFFFu]; PB = cur[ecn >> 16];    // next pass's particles (after this pass's writes)
-                            __builtin_amdgcn_sched_barrier(0);
-                            // the rest of the bookkeeping runs in the shadow of those reads; the stream loads for the
-                            // pass after next queue behind them
-                            if (!tic) {          // (a real branch: the empty asm keeps the compiler from flattening it into the loop)
-                                asm volatile("" ::: "memory");
-                                if (!(ca != 0 && cb != 0) && grp <= g && dev_sqrt<T>(len2) > rc * kl.tear_thresh) tear = 1;   // :272
-                            }
-                            st_levels += adv; st_trig += g < GR ? 1 : 0;
-                            myL = cons ? myL + GR : myL;
-                            rc = cons ? r1 : rc;
-                            if (cons) { int q = olo + sl; pn = q < ohi ? q : ZE; }
-                            e1 = ent[pn]; r1 = rest[pn];
-                            olo = (int)loffD[myL + 2 * GR]; ohi = (int)loffD[myL + 2 * GR + 1];
-                            ec = ecn;
-#ifdef CLOTHHIP_SWEEP_STAMPS          // dense passes: [10] cycles of quiet passes, [11] of correcting ones, [9] 64 x #quiet passes
-                            if (timing) {
-                                unsigned long long td1;
-                                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(td1)::"memory");
-                                tph[g < GR ? 11 : 10] += td1 - td0;
-                                if (!(g < GR)) tph[9] += 64;
-                            }
-#endif
-                        }
-                    }
-                } else
-                for (int L0 = 0; L0 < nL; L0 += 64) {
-                    const int Lm = L0 + lane;
-                    const bool valid = Lm < nL;
-                    const int myoff = valid ? (int)loff[Lm] : 0, myoff1 = valid ? (int)loff[Lm + 1] : 0;
-                    bool want = false;
-                    if (valid) {
-                        // any pre-pass bit in this level's spring range [myoff, myoff1)?  (width <= 64)
-                        const unsigned long long *abits = reinterpret_cast<const unsigned long long *>(smem + lay.abits);
-                        const int w0 = myoff >> 6, sh = myoff & 63, nb = myoff1 - myoff;
-                        unsigned long long bits = abits[w0] >> sh;
-                        if (sh) bits |= abits[w0 + 1] << (64 - sh);
-                        want |= (bits & (nb >= 64 ? ~0ull : ((1ull << nb) - 1ull))) != 0ull;
-                        if (lvflag[Lm]) { want = true; lvflag[Lm] = 0; }        // pending mark from an earlier correction
-                    }
-                    unsigned long long need = ballot64(want);
-                    // Up to WG = 64/lvw needed levels are evaluated per pass, one per lane group, against the same particle
-                    // state (as in the dense sweep): levels before the first correcting one are provably no-ops, that one
-                    // commits (and marks the later levels its particles touch), later ones are retried by the next pass.
-                    const int wsh = A.lvw_shift, WG = 64 >> wsh, wsub = lane & ((1 << wsh) - 1), wgrp = lane >> wsh;
-                    while (need) {
-#ifdef CLOTHHIP_SWEEP_STAMPS
-                        unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
-                        if (timing) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts0)::"memory"); }
-#endif
-                        unsigned long long nd = need;
-                        int o0 = 0, o1 = 0, myj = -1;            // my group's level: spring range and chunk-relative index
-                        unsigned long long taken = 0ull;         // the levels of this pass
-                        for (int g = 0; g < WG && nd; g++) {
-                            const int j = __ffsll((long long)nd) - 1;
-                            nd &= nd - 1ull;
-                            taken |= 1ull << j;
-                            const int a0 = __builtin_amdgcn_readlane(myoff, j), a1 = __builtin_amdgcn_readlane(myoff1, j);
-                            if (wgrp == g) { o0 = a0; o1 = a1; myj = j; }
-                        }
-                        const int idx = o0 + wsub;
-                        const bool on = myj >= 0 && idx < o1;
-                        uint32_t en = 0u; T r = (T)0;
-                        if (on) { en = ent[idx]; r = rest[idx]; }
-                        const int pa = (int)(en & 0xFFFFu), pb = (int)(en >> 16);
-                        const Pt<T> PA = cur[pa], PB = cur[pb];
-                        const uint32_t ca = w_cnt(PA.w), cb = w_cnt(PB.w);
-                        const T dx = PA.x - PB.x, dy = PA.y - PB.y, dz = PA.z - PB.z;
-                        const T len2 = sumsq<T>(dx, dy, dz);
-                        const T t11 = r * k.c11, tt = r * k.tear_thresh;
-                        const T tmin = t11 < tt ? t11 : tt;
-                        bool trig = false, tearl = false;
-                        T len = (T)0;
-                        if (on && !(ca != 0 && cb != 0) && (len2 > tmin * tmin * ((T)1 - filt_slack<T>()))) {   // :268
-                            len = dev_sqrt<T>(len2);                                            // :270
-                            tearl = len > tt;                                                   // :272
-                            trig = len > t11;                                                   // :275
-                        }
-                        const unsigned long long tb = ballot64(trig);
-                        const int gq = tb ? (__ffsll((long long)tb) - 1) >> wsh : WG;            // first correcting group
-                        if (tearl && wgrp <= gq) tear = 1;
-                        int moved = 0;
-                        if (trig && wgrp == gq) {
-                            const T ux = dev_div<T>(dx, len), uy = dev_div<T>(dy, len), uz = dev_div<T>(dz, len);   // :276-278
-                            const T extra = len - t11;                                          // :279
-                            const T wa = ca != 0 ? (T)0 : (cb != 0 ? (T)1 : (T)0.5);
-                            const T wb = cb != 0 ? (T)0 : (ca != 0 ? (T)1 : (T)0.5);
-                            const T ea = extra * wa, eb = extra * wb;
-                            if (ca == 0) cur[pa] = Pt<T>{mad<T>(-ux, ea, PA.x), mad<T>(-uy, ea, PA.y), mad<T>(-uz, ea, PA.z), PA.w};
-                            if (cb == 0) cur[pb] = Pt<T>{mad<T>(ux, eb, PB.x), mad<T>(uy, eb, PB.y), mad<T>(uz, eb, PB.z), PB.w};
-                            moved = (ca == 0 ? 1 : 0) | (cb == 0 ? 2 : 0);
-                        }
-                        // done: every level of the pass up to and including the first correcting one
-                        int jq = -1;                             // chunk-relative index of the committing level
-                        if (gq < WG) {
-                            jq = __builtin_amdgcn_readlane(myj, gq << wsh);
-                            need &= ~(taken & ((2ull << jq) - 1ull));
-                        } else need &= ~taken;
-                        st_levels += gq < WG ? gq + 1 : (int)__popcll(taken);
-                        unsigned long long mm = ballot64(moved != 0);
-                        st_trig += mm ? 1 : 0;
-#ifdef CLOTHHIP_SWEEP_STAMPS
-                        if (timing) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts1)::"memory"); tph[mm ? 11 : 10] += ts1 - ts0; }
-                        const bool did_mark = mm != 0ull;
-#endif
-                        if (mm) {
-                            // exact pending marks, lane-cooperative: two corrected springs per pass; for each, 24 lanes
-                            // read ONE entry of the incident-level table of ptA (12) / ptB (12). Marks inside the
-                            // current 64-level chunk are OR-reduced with DPP straight into `need`; marks beyond it
-                            // go to LDS flags that the later chunk consumes on entry.
-                            const int Lcur = L0 + jq;
-                            while (mm) {
-                                const int t1 = __ffsll((long long)mm) - 1;
-                                mm &= mm - 1ull;
-                                const int t2 = mm ? __ffsll((long long)mm) - 1 : t1;
-                                mm &= mm - 1ull;                 // (no-op when mm was already 0)
-                                const uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)en, t1);
-                                const uint32_t e2 = (uint32_t)__builtin_amdgcn_readlane((int)en, t2);
-                                const int m1 = __builtin_amdgcn_readlane(moved, t1), m2 = __builtin_amdgcn_readlane(moved, t2);
-                                const uint32_t es = mk_grp ? e2 : e1;
-                                const int ms = mk_grp ? m2 : m1;
-                                const int pt = mk_isb ? (int)(es >> 16) : (int)(es & 0xFFFFu);
-                                const bool use = mk_on && (t2 != t1 || !mk_grp) && ((ms >> (mk_isb ? 1 : 0)) & 1);
-                                const int lv = use ? (int)plev[mk_k * Ppad + pt] : 0xFFFF;
-                                const bool cond = lv != 0xFFFF && lv > Lcur;
-                                const int rel = lv - L0;
-                                if (cond && rel >= 64) lvflag[lv] = 1;
-                                const bool inch = cond && rel < 64;
-                                const uint32_t blo = (inch && rel < 32) ? (1u << rel) : 0u;
-                                const uint32_t bhi = (inch && rel >= 32) ? (1u << (rel - 32)) : 0u;
-                                const uint32_t slo = row_or_scan(blo), shi = row_or_scan(bhi);
-                                const uint32_t rlo = (uint32_t)(__builtin_amdgcn_readlane((int)slo, 15) | __builtin_amdgcn_readlane((int)slo, 31) |
-                                                                __builtin_amdgcn_readlane((int)slo, 47));
-                                const uint32_t rhi = (uint32_t)(__builtin_amdgcn_readlane((int)shi, 15) | __builtin_amdgcn_readlane((int)shi, 31) |
-                                                                __builtin_amdgcn_readlane((int)shi, 47));
-                                need |= ((unsigned long long)rhi << 32) | rlo;
-                            }
-                        }
-#ifdef CLOTHHIP_SWEEP_STAMPS
-                        if (timing && did_mark) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts2)::"memory"); tph[9] += ts2 - ts1; }
-#endif
-                        // the next level's lanes read what this level's lanes wrote: same wave, LDS operations execute
-                        // in program order; the barrier only pins the compiler's ordering
-                        __builtin_amdgcn_wave_barrier();
-                    }
-                }
+                const bool all_ = (pm & PH_NOSKIP) != 0;
+                const int w0 = __builtin_amdgcn_readfirstlane(all_ ? 0 : (misc[10] >> 6));
+                const int w1 = __builtin_amdgcn_readfirstlane(all_ ? A.nW - 1 : (misc[11] >> 6));
+                st_sweeps++;
+                const int tear = strain_sweep<T, (TAB >= 1), SWEEP_TIMED, SWEEP_STATS>(cur, wtab, A.wt_ent, g_rest, w0, w1, A.nW, A.wt_rshift, k, lane, st_windows,
+                                                                          st_passes, st_commits, tph);
                 if (__any(tear) && lane == 0) misc[0] = 1;
-                if (lane == 0) { misc[1] = 0; misc[10] = 0x7fffffff; }
+                if (lane == 0) { misc[1] = 0; misc[10] = 0x7fffffff; misc[11] = -1; }
                 __builtin_amdgcn_s_setprio(0);
-                // the pre-pass ORs into the bitmask: clear the words it set (they are all consumed now)
-                for (int i = lane; i < (A.Spad / 64 + 2) * 2; i += 64) reinterpret_cast<uint32_t *>(smem + lay.abits)[i] = 0u;
             }
             __syncthreads();
-#ifndef CLOTHHIP_SWEEP_STAMPS          // (that build uses slots 9-11 for the sparse sweep's marks / passes)
+#ifndef CLOTHHIP_SWEEP_STAMPS          // (that build uses slots 9-11 for the sweep's passes)
             TSTAMP(9)
 #endif
         }
@@ -1930,8 +1735,8 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
             if (op == OP_ACTION || op == OP_RESET_COND || op == OP_RESET_END) {
                 // cloth_env.py:1020-1098 on the LDS-resident state; the sort buffers borrow the LDS behind the particle records
                 auto src = [&](int i, double &x, double &y, double &z) { const Pt<T> c = cur[i]; x = (double)c.x; y = (double)c.y; z = (double)c.z; };
-                metrics_block<NT, T>(src, P, F.NS, F.NH, smem + lay.ent, tid, F.half_thickness, mo);
-                init_lds(tear_now, F.lv_ent, F.rest + (size_t)e * F.rest_stride, F.lv_off, F.lv_off8, F.pt_lev);
+                metrics_block<NT, T>(src, P, F.NS, F.NH, smem + lay.wtab, tid, F.half_thickness, mo);
+                init_lds(tear_now, F.wt_ent, F.rest + (size_t)e * F.rest_stride);
                 __syncthreads();
             }
             if (op == OP_ACTION && F.obs) {                                                       // '1d' observation, cloth_env.py:196-200
@@ -2013,7 +1818,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
         if (tid == 0) {
             A.tear[e] = misc[0]; A.executed[e] = done;
             if (A.stats) {
-                A.stats[16 * e] = st_sweeps; A.stats[16 * e + 1] = st_dense; A.stats[16 * e + 2] = st_levels; A.stats[16 * e + 3] = st_trig;
+                A.stats[16 * e] = st_sweeps; A.stats[16 * e + 1] = st_windows; A.stats[16 * e + 2] = st_passes; A.stats[16 * e + 3] = st_commits;
                 for (int q = 0; q < 12; q++) A.stats[16 * e + 4 + q] = (int)(tph[q] >> 6);
 #ifndef CLOTHHIP_PHASE_STAMPS
                 unsigned long long tend;

@@ -7,9 +7,11 @@
 //
 //   * gather table: for every point the <=12 incident springs in ascending list index, so a per-point
 //     gather adds the Hooke forces in exactly the order the reference's scatter does;
-//   * level schedule: springs grouped into dependency levels (level = 1 + max(level of the previous
-//     spring touching either endpoint)).  Springs inside a level share no endpoint; executing the levels
-//     in order reproduces the sequential sweep exactly.
+//   * window table: springs grouped into dependency levels (level = 1 + max(level of the previous
+//     spring touching either endpoint)); springs inside a level share no endpoint, and executing the
+//     levels in order reproduces the sequential sweep exactly.  Consecutive
+//     levels are packed into WINDOWS of 64 slots -- one slot per lane of the wave that walks the sweep --
+//     so that lane order == level order inside a window.
 #pragma once
 
 #include <algorithm>
@@ -23,7 +25,7 @@ enum : uint8_t { SPRING_STRUCTURAL = 0, SPRING_SHEARING = 1, SPRING_BENDING = 2 
 
 // gather-table entry layout (uint32)
 constexpr uint32_t HK_NBR_MASK = 0xFFFu;        // bits 0..11  neighbour point index (P <= 4096)
-constexpr int HK_POS_SHIFT = 12;                // bits 12..27 position of the spring in level order
+constexpr int HK_POS_SHIFT = 12;                // bits 12..27 slot of the spring in the window table
 constexpr uint32_t HK_POS_MASK = 0xFFFFu;
 constexpr uint32_t HK_ASB = 1u << 28;           // this point is the spring's ptB (owner): f += -(F)
 constexpr uint32_t HK_BEND = 1u << 29;          // BENDING spring: ks * 0.2
@@ -94,12 +96,83 @@ inline LevelSchedule build_levels(const Topology &t) {
     return L;
 }
 
+// Window table of the strain-limit sweep. Slot i = window (i >> 6), lane (i & 63). Entry (0 = empty slot, ptA == ptB == 0,
+// which can never stretch):
+//   bits  0..11  ptA           bits 12..23  ptB
+//   bits 24..27  group: which of the window's levels (<= 16, in order) the spring belongs to
+//   bits 28..31  reach: how many windows past its own the last spring incident to ptA or ptB sits, in units of
+//                2^reach_shift windows, rounded up (the maximum over the springs of the group, so that any lane of a group
+//                can speak for it); a correction of this spring cannot influence anything behind that window
+// The rest-length arrays of the device (one per env for tier 2, else one shared) are kept in slot order too.
+constexpr int WT_IDX_BITS = 12, WT_GROUP_SHIFT = 24, WT_REACH_SHIFT = 28;
+constexpr uint32_t WT_IDX_MASK = 0xFFFu;
+constexpr int WT_MAX_GROUPS = 16, WT_MAX_REACH = 15;
+constexpr int WT_PAD_WINDOWS = 4;                // empty windows behind the last one: the entry stream reads ahead
+
+struct WindowTable {
+    int nW = 0, n_slots = 0;         // windows; slots incl. the padding windows
+    int max_reach = 0, reach_shift = 0;
+    std::vector<uint32_t> ent;       // [n_slots]
+    std::vector<int32_t> slot_of;    // spring list index -> slot
+    std::vector<int32_t> spring_at;  // slot -> spring list index, -1 empty
+};
+
+inline WindowTable build_windows(const Topology &t, const LevelSchedule &L) {
+    WindowTable W;
+    W.slot_of.assign(t.S, -1);
+    std::vector<int> group_of(t.S, 0);
+    int w = 0, used = 0, groups = 0;
+    for (int l = 0; l < L.n_levels; l++) {
+        int p = L.off[l];
+        while (p < L.off[l + 1]) {                                // a level may continue in the next window: still an antichain
+            if (used == 64 || groups == WT_MAX_GROUPS) { w++; used = 0; groups = 0; }
+            const int take = std::min(L.off[l + 1] - p, 64 - used);
+            for (int q = 0; q < take; q++) {
+                const int s = L.order[p + q];
+                W.slot_of[s] = w * 64 + used + q;
+                group_of[s] = groups;
+            }
+            p += take; used += take; groups++;
+        }
+    }
+    W.nW = w + 1;
+
+    std::vector<int> last_win(t.P, 0);                            // window of the last spring incident to a point
+    for (int s = 0; s < t.S; s++) {
+        const int ws = W.slot_of[s] >> 6;
+        last_win[t.a[s]] = std::max(last_win[t.a[s]], ws);
+        last_win[t.b[s]] = std::max(last_win[t.b[s]], ws);
+    }
+    std::vector<int> greach((size_t)W.nW * WT_MAX_GROUPS, 0);     // per (window, group): the farthest reach of its springs
+    for (int s = 0; s < t.S; s++) {
+        const int ws = W.slot_of[s] >> 6;
+        const int r = std::max(last_win[t.a[s]], last_win[t.b[s]]) - ws;
+        int &g = greach[(size_t)ws * WT_MAX_GROUPS + group_of[s]];
+        g = std::max(g, r);
+        W.max_reach = std::max(W.max_reach, r);
+    }
+    while (((W.max_reach + (1 << W.reach_shift) - 1) >> W.reach_shift) > WT_MAX_REACH) W.reach_shift++;
+    // padding: the entry stream reads WT_PAD_WINDOWS ahead, and a reach rounded up to its unit may point up to 2^reach_shift - 1
+    // windows past the last one (they are empty: walking them changes nothing)
+    W.n_slots = (W.nW + WT_PAD_WINDOWS + (1 << W.reach_shift) - 1) * 64;
+    W.ent.assign(W.n_slots, 0u);
+    W.spring_at.assign(W.n_slots, -1);
+    for (int s = 0; s < t.S; s++) {
+        const int i = W.slot_of[s], ws = i >> 6;
+        const int r = (greach[(size_t)ws * WT_MAX_GROUPS + group_of[s]] + (1 << W.reach_shift) - 1) >> W.reach_shift;
+        W.ent[i] = (uint32_t)t.a[s] | ((uint32_t)t.b[s] << WT_IDX_BITS) | ((uint32_t)group_of[s] << WT_GROUP_SHIFT) |
+                   ((uint32_t)r << WT_REACH_SHIFT);
+        W.spring_at[i] = s;
+    }
+    return W;
+}
+
 // gather table [HK_SLOTS][Ppad]: slot k of point i = its k-th incident spring in ascending list index.
-inline std::vector<uint32_t> build_gather(const Topology &t, const LevelSchedule &L, int Ppad) {
+inline std::vector<uint32_t> build_gather(const Topology &t, const WindowTable &W, int Ppad) {
     std::vector<uint32_t> tab((size_t)HK_SLOTS * Ppad, 0u);
     std::vector<int> n(t.P, 0);
     for (int s = 0; s < t.S; s++) {
-        uint32_t common = ((uint32_t)L.pos_of[s] << HK_POS_SHIFT) | HK_VALID |
+        uint32_t common = ((uint32_t)W.slot_of[s] << HK_POS_SHIFT) | HK_VALID |
                           (t.type[s] == SPRING_BENDING ? HK_BEND : 0u);
         int a = t.a[s], b = t.b[s];
         tab[(size_t)n[a]++ * Ppad + a] = common | (uint32_t)b;            // point is ptA: f += F

@@ -47,18 +47,15 @@ struct clothhip_handle {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool have_timing = false, pending_exec = false;
     void *d_pos = nullptr, *d_prev = nullptr, *d_rest = nullptr;
-    void *d_flat = nullptr, *d_flat_rest = nullptr;   // flat tier-1 grid [3][Ppad] and its rest table [Spad] (level order), handle precision
+    void *d_flat = nullptr, *d_flat_rest = nullptr;   // flat tier-1 grid [3][Ppad] and its rest table [Spad] (window-table slot order), handle precision
     uint8_t *d_cnt = nullptr, *d_active = nullptr;
     int rest_stride = 0;
     int32_t *d_tear = nullptr, *d_exec = nullptr, *d_ngrab = nullptr, *d_stats = nullptr;
     ClothSchedule *d_sched = nullptr, *h_sched = nullptr;   // h_sched: pinned staging
-    uint32_t *d_gather = nullptr, *d_lv_ent = nullptr;
-    uint16_t *d_lv_off = nullptr, *d_lv_off8 = nullptr, *d_pt_lev = nullptr;
-    int n_levels8 = 0, narrow_thresh = 300, cell_copy = 0;
-    int dense_thresh = 2;         // pre-pass flagged springs above which the dense sweep (which starts at the first flagged level) beats exact
-                                  // pending-level tracking; measured best at 1-3 on the bench workload and on a well-formed action
-    int HT = 0, ht_bits = 0, lvw_shift = 4, lds_bytes = 0, phase_mask = 15, nt = 256, ppt = 3;
-    int tab = 0;            // static tables resident in LDS: 0 none, 1 springs/rest/offsets, 2 + per-point levels
+    uint32_t *d_gather = nullptr, *d_wt_ent = nullptr;
+    int cell_copy = 0;
+    int HT = 0, ht_bits = 0, lds_bytes = 0, phase_mask = 15, nt = 256, ppt = 3;
+    int tab = 0;            // the strain sweep's window table (+ rest lengths) resident in LDS: 0 no (streamed from L2), 1 yes
     bool rest_reg = false;
     double *d_levels = nullptr, *d_xy = nullptr, *d_radius = nullptr, *d_cov = nullptr, *d_vinv = nullptr;
     uint8_t *d_oob = nullptr;
@@ -73,7 +70,7 @@ struct clothhip_handle {
     int f_T = 0; size_t f_nscr = 0; bool f_pending = false, f_resets = false, f_obs = false, f_robs = false, f_mt = false;
     size_t cap_fact = 0, cap_frec = 0, cap_fobs = 0, cap_fscr = 0, cap_frst = 0, cap_frobs = 0, cap_fparg = 0;
     Topology topo;
-    LevelSchedule lv;
+    WindowTable wt;
     std::vector<unsigned char> stage;   // host staging for layout conversion
     std::vector<double> flat_rest;
 };
@@ -166,7 +163,7 @@ static void free_handle(clothhip_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_pos, h->d_prev, h->d_rest, h->d_cnt, h->d_active, h->d_tear, h->d_exec, h->d_ngrab, h->d_stats,
-                    h->d_sched, h->d_flat, h->d_flat_rest, h->d_hcnt, h->d_fz, h->d_fact, h->d_fscr, h->d_frec, h->d_frst, h->d_fobs, h->d_frobs, h->d_fsteps, h->d_fparg, h->d_fdone, h->d_fmt, h->d_resume, h->d_gather, h->d_lv_ent, h->d_lv_off, h->d_lv_off8, h->d_pt_lev, h->d_levels, h->d_xy, h->d_radius, h->d_cov, h->d_vinv, h->d_oob};
+                    h->d_sched, h->d_flat, h->d_flat_rest, h->d_hcnt, h->d_fz, h->d_fact, h->d_fscr, h->d_frec, h->d_frst, h->d_fobs, h->d_frobs, h->d_fsteps, h->d_fparg, h->d_fdone, h->d_fmt, h->d_resume, h->d_gather, h->d_wt_ent, h->d_levels, h->d_xy, h->d_radius, h->d_cov, h->d_vinv, h->d_oob};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->h_sched) (void)hipHostFree(h->h_sched);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -194,8 +191,8 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
     h->N = params->n_side; h->P = h->N * h->N; h->Ppad = (h->P + 63) / 64 * 64;
     h->tsz = precision == CLOTHHIP_F64 ? 8 : 4;
     h->topo = build_topology(h->N);
-    h->lv = build_levels(h->topo);
-    h->S = h->topo.S; h->Spad = (h->S + 64) / 64 * 64;      // > S: entry S is the all-zero padding entry of the sweeps
+    h->wt = build_windows(h->topo, build_levels(h->topo));
+    h->S = h->topo.S; h->Spad = h->wt.n_slots;               // rest-length arrays are kept in window-table slot order
     // threads per cloth x particles per thread (compile-time variants of the stepper)
     if (h->P <= 768) { h->nt = 256; h->ppt = 3; }
     else if (h->P <= 2560 && !getenv("CLOTHHIP_DEBUG_NT1024")) { h->nt = 512; h->ppt = 5; }
@@ -203,10 +200,8 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
     h->HT = 64; h->ht_bits = 0;
     while (h->HT <= h->P + h->P / 2) h->HT <<= 1;
     while ((1 << h->ht_bits) < h->HT) h->ht_bits++;
-    h->lvw_shift = h->lv.max_width <= 8 ? 3 : (h->lv.max_width <= 16 ? 4 : (h->lv.max_width <= 32 ? 5 : 6));
-    if (h->lv.max_width > 64) { delete h; return fail(CLOTHHIP_EINVAL, "level width %d > 64", h->lv.max_width); }
     if (const char *pmk = getenv("CLOTHHIP_DEBUG_PHASES")) h->phase_mask = atoi(pmk);
-    std::vector<uint32_t> gather = build_gather(h->topo, h->lv, h->Ppad);
+    std::vector<uint32_t> gather = build_gather(h->topo, h->wt, h->Ppad);
     std::vector<double> levels = build_grab_levels(params->height, params->thickness);
     h->n_grab_levels = (int)levels.size();
 
@@ -237,9 +232,7 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
     HC(hipMalloc(&h->d_sched, E * sizeof(ClothSchedule)));
     HC(hipHostMalloc((void **)&h->h_sched, E * sizeof(ClothSchedule), hipHostMallocDefault));
     HC(hipMalloc(&h->d_gather, gather.size() * 4));
-    HC(hipMalloc(&h->d_lv_ent, (size_t)h->Spad * 4));
-    HC(hipMalloc(&h->d_lv_off, (size_t)(h->lv.n_levels + 40) * 2));
-    HC(hipMalloc(&h->d_pt_lev, (size_t)HK_SLOTS * h->Ppad * 2));
+    HC(hipMalloc(&h->d_wt_ent, (size_t)h->Spad * 4));
     HC(hipMalloc(&h->d_levels, (levels.size() + 1) * 8));
     HC(hipMalloc(&h->d_xy, E * 2 * 8));
     HC(hipMalloc(&h->d_radius, E * 8));
@@ -252,36 +245,7 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
     HC(hipMalloc(&h->d_flat, (size_t)3 * h->Ppad * h->tsz));
     HC(hipMalloc(&h->d_flat_rest, (size_t)h->Spad * h->tsz));
     HC(hipMemcpy(h->d_gather, gather.data(), gather.size() * 4, hipMemcpyHostToDevice));
-    HC(hipMemset(h->d_lv_ent, 0, (size_t)h->Spad * 4));
-    HC(hipMemcpy(h->d_lv_ent, h->lv.ent.data(), (size_t)h->S * 4, hipMemcpyHostToDevice));
-    {
-        std::vector<uint16_t> off16(h->lv.off.begin(), h->lv.off.end());
-        off16.resize((size_t)h->lv.n_levels + 40, (uint16_t)h->lv.off[h->lv.n_levels]);   // levels past the end are empty
-        HC(hipMemcpy(h->d_lv_off, off16.data(), off16.size() * 2, hipMemcpyHostToDevice));
-        // narrow table: every level cut into consecutive sub-levels of at most 8 springs (still antichains, same order)
-        std::vector<uint16_t> off8;
-        for (int L = 0; L < h->lv.n_levels; L++)
-            for (int p = h->lv.off[L]; p < h->lv.off[L + 1]; p += 8) off8.push_back((uint16_t)p);
-        off8.push_back((uint16_t)h->lv.off[h->lv.n_levels]);
-        h->n_levels8 = h->lv.max_width > 8 ? (int)off8.size() - 1 : 0;     // width <= 8 already: the main table is narrow
-        off8.resize(off8.size() + 40, (uint16_t)h->lv.off[h->lv.n_levels]);
-        HC(hipMalloc(&h->d_lv_off8, off8.size() * 2));
-        HC(hipMemcpy(h->d_lv_off8, off8.data(), off8.size() * 2, hipMemcpyHostToDevice));
-    }
-    {   // dependency level of every incident spring of every point (for the exact pending-level marking)
-        std::vector<int> lvl_of_pos(h->S);
-        for (int L = 0; L < h->lv.n_levels; L++)
-            for (int p = h->lv.off[L]; p < h->lv.off[L + 1]; p++) lvl_of_pos[p] = L;
-        std::vector<uint16_t> pl((size_t)HK_SLOTS * h->Ppad, (uint16_t)0xFFFF);
-        for (int sl = 0; sl < HK_SLOTS; sl++)
-            for (int i = 0; i < h->P; i++) {
-                const uint32_t g = gather[(size_t)sl * h->Ppad + i];
-                if (g & HK_VALID) pl[(size_t)sl * h->Ppad + i] = (uint16_t)lvl_of_pos[(g >> HK_POS_SHIFT) & HK_POS_MASK];
-            }
-        HC(hipMemcpy(h->d_pt_lev, pl.data(), pl.size() * 2, hipMemcpyHostToDevice));
-    }
-    if (const char *dt = getenv("CLOTHHIP_DEBUG_DENSE")) h->dense_thresh = atoi(dt);
-    if (const char *dt = getenv("CLOTHHIP_DEBUG_NARROW")) h->narrow_thresh = atoi(dt);
+    HC(hipMemcpy(h->d_wt_ent, h->wt.ent.data(), (size_t)h->Spad * 4, hipMemcpyHostToDevice));
     HC(hipMemset(h->d_rest, 0, E * h->Spad * h->tsz));
     if (!levels.empty()) HC(hipMemcpy(h->d_levels, levels.data(), levels.size() * 8, hipMemcpyHostToDevice));
     HC(hipMemset(h->d_exec, 0, E * 4));
@@ -289,19 +253,17 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
     // as long as TWO cloths still fit per CU (512 cloths = 2 per CU on the 256 CUs of an MI355X).
     {
         const int tsz = (int)h->tsz;
-        // 256-thread variants: two cloths per CU (<= 80 KiB each); 1024-thread variants own the CU (<= 160 KiB)
+        // 256-thread variants: two cloths per CU (<= 80 KiB each); the larger ones own the CU (<= 160 KiB)
         const int budget = h->nt == 256 ? 80 * 1024 : 160 * 1024;
-        const int tmax = h->nt == 256 ? 2 : ((h->ppt == 3 || h->nt == 512) ? 1 : 0);
-        h->tab = 0;
-        for (int t = tmax; t >= 1; t--)
-            if (LdsLayout(tsz, h->Ppad, h->Spad, h->lv.n_levels, h->n_levels8, h->HT, t, 0).total <= budget) { h->tab = t; break; }
+        const int tmax = h->nt <= 512 ? 1 : 0;
+        h->tab = (tmax >= 1 && LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 1, 0).total <= budget) ? 1 : 0;
         if (const char *t = getenv("CLOTHHIP_DEBUG_TAB_LDS")) h->tab = std::min(h->tab, atoi(t));
-        h->rest_reg = (h->nt == 256 && precision == CLOTHHIP_F32 && h->tab == 2);
+        h->rest_reg = (h->nt == 256 && precision == CLOTHHIP_F32 && h->tab == 1);
         if (const char *t = getenv("CLOTHHIP_DEBUG_REST_REG")) h->rest_reg = h->rest_reg && atoi(t);
-        // the cell-ordered record copy for the collision pre-check is taken only if it costs no table tier
-        h->cell_copy = LdsLayout(tsz, h->Ppad, h->Spad, h->lv.n_levels, h->n_levels8, h->HT, h->tab, 1).total <= budget ? 1 : 0;
+        // the cell-ordered record copy for the collision pre-check is taken only if it does not cost the table its place
+        h->cell_copy = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, h->tab, 1).total <= budget ? 1 : 0;
         if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) h->cell_copy = h->cell_copy && atoi(t);
-        h->lds_bytes = LdsLayout(tsz, h->Ppad, h->Spad, h->lv.n_levels, h->n_levels8, h->HT, h->tab, h->cell_copy).total;
+        h->lds_bytes = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, h->tab, h->cell_copy).total;
         if (h->lds_bytes > 160 * 1024) { free_handle(h); return fail(CLOTHHIP_EINVAL, "n_side %d needs %d B of LDS (> 160 KiB)", h->N, h->lds_bytes); }
         const void *fn = stepper_fn(h, 0), *fnf = stepper_fn(h, 1), *fnf2 = stepper_fn(h, 2);
         if (!fn || !fnf || !fnf2) { free_handle(h); return fail(CLOTHHIP_EINVAL, "no stepper variant for n_side %d", h->N); }
@@ -412,9 +374,10 @@ extern "C" int clothhip_set_state(clothhip_handle *h, int32_t env0, int32_t n, c
         std::vector<unsigned char> buf((size_t)nt * h->Spad * h->tsz, 0);
         for (int e = 0; e < nt; e++)
             for (int p = 0; p < h->S; p++) {
-                const double v = rest[(size_t)e * h->S + h->lv.order[p]];     // list order -> level order
-                if (h->precision == CLOTHHIP_F64) ((double *)buf.data())[(size_t)e * h->Spad + p] = v;
-                else ((float *)buf.data())[(size_t)e * h->Spad + p] = (float)v;
+                const int i = h->wt.slot_of[p];                               // list order -> table slot (empty slots stay 0)
+                const double v = rest[(size_t)e * h->S + p];
+                if (h->precision == CLOTHHIP_F64) ((double *)buf.data())[(size_t)e * h->Spad + i] = v;
+                else ((float *)buf.data())[(size_t)e * h->Spad + i] = (float)v;
             }
         char *dst = (char *)h->d_rest + (rest_shared ? 0 : (size_t)env0 * h->Spad * h->tsz);
         HIPCHECK(hipMemcpy(dst, buf.data(), buf.size(), hipMemcpyHostToDevice));
@@ -455,9 +418,10 @@ extern "C" int clothhip_get_rest(clothhip_handle *h, int32_t env0, int32_t n, do
     for (int e = 0; e < n; e++) {
         const char *src = (const char *)h->d_rest + (size_t)(env0 + e) * h->rest_stride * h->tsz;   // stride 0: the shared table
         if (e == 0 || h->rest_stride) HIPCHECK(hipMemcpy(buf.data(), src, buf.size(), hipMemcpyDeviceToHost));
-        for (int p = 0; p < h->S; p++)          // level order -> list order (Spring.rest_length of cloth.springs[s])
-            rest[(size_t)e * h->S + h->lv.order[p]] = h->precision == CLOTHHIP_F64 ? ((const double *)buf.data())[p]
-                                                                                  : (double)((const float *)buf.data())[p];
+        for (int p = 0; p < h->S; p++) {        // table slot -> list order (Spring.rest_length of cloth.springs[p])
+            const int i = h->wt.slot_of[p];
+            rest[(size_t)e * h->S + p] = h->precision == CLOTHHIP_F64 ? ((const double *)buf.data())[i] : (double)((const float *)buf.data())[i];
+        }
     }
     return 0;
 }
@@ -561,10 +525,9 @@ template <typename T> static StepArgs<T> make_args(clothhip_handle *h, const Clo
     StepArgs<T> a;
     a.pos = (T *)h->d_pos; a.prev = (T *)h->d_prev; a.cnt = h->d_cnt; a.rest = (const T *)h->d_rest;
     a.tear = h->d_tear; a.executed = h->d_exec; a.stats = h->d_stats; a.sched = d_sched;
-    a.gather = h->d_gather; a.lv_ent = h->d_lv_ent; a.lv_off = h->d_lv_off; a.lv_off8 = h->d_lv_off8; a.n_levels8 = h->n_levels8; a.cell_copy = h->cell_copy; a.narrow_thresh = h->narrow_thresh; a.pt_lev = h->d_pt_lev; a.dense_thresh = h->dense_thresh;
-    a.n_levels = h->lv.n_levels;
+    a.gather = h->d_gather; a.wt_ent = h->d_wt_ent; a.nW = h->wt.nW; a.wt_rshift = h->wt.reach_shift; a.cell_copy = h->cell_copy;
     a.N = h->N; a.P = h->P; a.Ppad = h->Ppad; a.S = h->S; a.Spad = h->Spad;
-    a.HT = h->HT; a.ht_bits = h->ht_bits; a.lvw_shift = h->lvw_shift;
+    a.HT = h->HT; a.ht_bits = h->ht_bits;
     a.rest_stride = h->rest_stride; a.phase_mask = h->phase_mask;
     a.k = make_consts<T>(h->prm);
     a.fz = nullptr;
@@ -572,9 +535,13 @@ template <typename T> static StepArgs<T> make_args(clothhip_handle *h, const Clo
 }
 
 // compile-time variants: (threads per cloth, particles per thread) x tables-in-LDS level x rest-in-registers
+#ifdef CLOTHHIP_FAST_BUILD           // development builds: the 25x25 variants only (make fast)
+#define CLOTH_VARIANTS(X, T) X(T, 256, 3, 1, true) X(T, 256, 3, 1, false) X(T, 256, 3, 0, false)
+#else
 #define CLOTH_VARIANTS(X, T)                                              \
-    X(T, 256, 3, 2, true) X(T, 256, 3, 2, false) X(T, 256, 3, 1, false) X(T, 256, 3, 0, false)   \
-    X(T, 512, 5, 0, false) X(T, 512, 5, 1, false) X(T, 1024, 3, 0, false) X(T, 1024, 3, 1, false) X(T, 1024, 4, 0, false)
+    X(T, 256, 3, 1, true) X(T, 256, 3, 1, false) X(T, 256, 3, 0, false)   \
+    X(T, 512, 5, 0, false) X(T, 512, 5, 1, false) X(T, 1024, 3, 0, false) X(T, 1024, 4, 0, false)
+#endif
 
 template <typename T, int FUSED> static const void *stepper_fn_t(const clothhip_handle *h) {
 #define X(T_, NT, PPT, TAB, RR) \
@@ -665,7 +632,7 @@ template <typename T> static void fill_fused(clothhip_handle *h, FusedArgs<T> &f
     f.obs = have_obs ? (float *)h->d_fobs : nullptr;
     f.reset_obs = have_robs ? (float *)h->d_frobs : nullptr;
     f.flat = (const T *)h->d_flat;
-    f.lv_ent = h->d_lv_ent; f.lv_off = h->d_lv_off; f.lv_off8 = h->d_lv_off8; f.pt_lev = h->d_pt_lev;
+    f.wt_ent = h->d_wt_ent;
     f.rest = (const T *)h->d_rest; f.rest_rw = (T *)h->d_rest; f.rest_stride = h->rest_stride;
     f.grid_dx = h->prm.width * 1.0 / (h->N - 1); f.grid_dy = h->prm.height * 1.0 / (h->N - 1);
     f.levels = h->d_levels; f.n_glevels = h->n_grab_levels; f.E = h->E; f.n_scripts = n_scripts; f.budget_ticks = budget_ticks;
@@ -688,8 +655,8 @@ static int fused_scratch(const clothhip_handle *h, int *need_out) {
     int NS = 1; while (NS < h->P) NS <<= 1;
     const int NH = h->Ppad + 8;
     *need_out = 2 * NS * (int)h->tsz + (2 * NH + 64) * 8;
-    const LdsLayout lay((int)h->tsz, h->Ppad, h->Spad, h->lv.n_levels, h->n_levels8, h->HT, h->tab, h->cell_copy);
-    return lay.total - lay.ent;
+    const LdsLayout lay((int)h->tsz, h->Ppad, h->Spad, h->HT, h->tab, h->cell_copy);
+    return lay.total - lay.wtab;
 }
 
 extern "C" int clothhip_fused_supported(const clothhip_handle *h) {

@@ -240,19 +240,17 @@ def test_crowded_cells_selfcollision_f64(scale, lift, oracle_lib):
 
 
 @pytest.mark.parametrize("mode,env", [
-    ("sparse only", {"CLOTHHIP_DEBUG_DENSE": "100000"}),
-    ("dense, natural levels only", {"CLOTHHIP_DEBUG_DENSE": "0", "CLOTHHIP_DEBUG_NARROW": "0"}),
-    ("dense, narrow table only", {"CLOTHHIP_DEBUG_DENSE": "0", "CLOTHHIP_DEBUG_NARROW": "100000"}),
-    ("tables streamed from L2", {"CLOTHHIP_DEBUG_TAB_LDS": "0"}),
-    ("dense from L2, narrow", {"CLOTHHIP_DEBUG_TAB_LDS": "0", "CLOTHHIP_DEBUG_DENSE": "0", "CLOTHHIP_DEBUG_NARROW": "100000"}),
+    ("window table in LDS (f64: n_side 25 does not fit, so this is the default of the small grids)", {}),
+    ("window table streamed from L2", {"CLOTHHIP_DEBUG_TAB_LDS": "0"}),
+    ("every window walked, no skipping", {"CLOTHHIP_DEBUG_PHASES": "31"}),
+    ("every window, from L2", {"CLOTHHIP_DEBUG_TAB_LDS": "0", "CLOTHHIP_DEBUG_PHASES": "31"}),
     ("pre-check without the cell-ordered copy", {"CLOTHHIP_DEBUG_CELL_COPY": "0"}),
 ])
 def test_every_sweep_mode_is_exact_f64(mode, env, oracle_lib, monkeypatch):
-    """The strain sweep has several exact execution modes chosen at run time by how many levels the pre-pass flags
-    (sparse pending-level tracking / dense over the natural levels / dense over the narrow table; tables in LDS or
-    streamed from L2) and the collision pre-check has two data sources. Each mode is forced in turn (debug
-    environment variables read at clothhip_create) and must reproduce the reference's lift-and-pull trajectory,
-    whose pull phase over-stretches hundreds of springs, bit for bit."""
+    """The strain sweep walks the window table from the first flagged spring to the last window a correction can reach
+    (table in LDS or streamed from L2), or every window (debug phase bit 16); the collision pre-check has two data
+    sources. Each mode is forced in turn (debug environment variables read at clothhip_create) and must reproduce the
+    reference's lift-and-pull trajectory, whose pull phase over-stretches hundreds of springs, bit for bit."""
     from gym_cloth_amd import ClothBatch
     for k_, v_ in env.items():
         monkeypatch.setenv(k_, v_)
@@ -270,5 +268,4 @@ def test_every_sweep_mode_is_exact_f64(mode, env, oracle_lib, monkeypatch):
     st = b.debug_stats()
     b.close()
     assert not bad, (mode, bad[:4])
-    if env.get("CLOTHHIP_DEBUG_DENSE") == "100000":
-        assert st[:, 1].sum() == 0, "the sparse-only run must not have used the dense sweep"
+    assert st[:, 0].sum() > 0, "the trajectory must exercise the sweep"

@@ -56,7 +56,7 @@ if tot_sub:
         print("   %-28s %8.0f  %5.1f %%" % (n, v, 100 * v / total))
     print("   %-28s %8.0f  %5.1f %%" % ("(all cell sweeps)", per[6] + per[10] + per[11], 100 * (per[6] + per[10] + per[11]) / total))
     st = env.batch.debug_stats().astype(np.float64)
-    print("strain sweep: %.3f sweeps/substep, dense share %.3f, levels run/substep %.1f, corrected/substep %.1f" %
-          (st[:, 0].sum() / tot_sub * launches, st[:, 1].sum() / max(st[:, 0].sum(), 1), st[:, 2].sum() / tot_sub * launches,
+    print("strain sweep: %.3f sweeps/substep, windows walked/substep %.1f, passes/substep %.1f, corrected/substep %.1f" %
+          (st[:, 0].sum() / tot_sub * launches, st[:, 1].sum() / tot_sub * launches, st[:, 2].sum() / tot_sub * launches,
            st[:, 3].sum() / tot_sub * launches))
 env.close()

@@ -63,12 +63,12 @@ def main():
                 names = ["adjust", "hooke", "insert", "ranges", "fill", "precheck", "cells: wait at barrier", "reset+plane", "prepass"]
                 print("    cycles/substep (wave 0): " + "  ".join("%s %.0f" % (n, st[4 + i] * 64) for i, n in enumerate(names)))
                 if os.environ.get("CLOTHHIP_SWEEP_STAMPS_LIB"):     # library built with -DCLOTHHIP_SWEEP_STAMPS instead of CELL_STAMPS
-                    print("    sparse sweep (wave 0): marking %.0f  passes without a correction %.0f  passes with one %.0f cycles/substep" %
-                          (st[4 + 9] * 64, st[4 + 10] * 64, st[4 + 11] * 64))
+                    print("    window sweep (wave 0): passes without a correction %.0f  passes with one %.0f cycles/substep" %
+                          (st[4 + 10] * 64, st[4 + 11] * 64))
                 else:
                     print("    cells sweep (wave 0): cells over 16 members %.0f  small cells (four per pass) %.0f cycles/substep" %
                           (st[4 + 10] * 64, st[4 + 11] * 64))
-            print("%-12s mask %2d: %8.2f us/substep  (%6.2f M substeps/s at E=%d)  per substep: sweeps %.2f dense %.2f levels %.1f corrected %.1f" %
+            print("%-12s mask %2d: %8.2f us/substep  (%6.2f M substeps/s at E=%d)  per substep: sweeps %.2f windows %.1f passes %.1f corrected %.1f" %
                   (name, mask, ms * 1e3 / args.sub, args.envs * args.sub / ms / 1e3, args.envs, st[0], st[1], st[2], st[3]), flush=True)
             b.close()
     if not args.n50:

@@ -42,12 +42,12 @@ def main():
         ms = b.last_kernel_ms
         st = b.debug_stats()[0] / float(n)
         tot_ms += ms
-        print("%-13s %4d substeps %8.2f ms  %7.2f us/substep | sweeps %.2f dense %.2f levels %6.1f corrected %5.1f" %
+        print("%-13s %4d substeps %8.2f ms  %7.2f us/substep | sweeps %.2f windows %5.1f passes %6.1f corrected %5.1f" %
               (name, n, ms, ms * 1e3 / n, st[0], st[1], st[2], st[3]))
         if os.environ.get("CLOTHHIP_DEBUG_PHASES") and int(os.environ["CLOTHHIP_DEBUG_PHASES"]) & 32:
-            raw = b.debug_stats()[0].astype(float) * 64          # sweep-stamps build: dense passes (quiet / correcting)
+            raw = b.debug_stats()[0].astype(float) * 64          # sweep-stamps build: passes of the window sweep (quiet / correcting)
             nq, nc = max(raw[4 + 9] / 64, 1), max(raw[3] / 64, 1)
-            print("      dense sweep: %.1f quiet passes/substep at %.0f cycles, %.1f correcting at %.0f" %
+            print("      window sweep: %.1f quiet passes/substep at %.0f cycles, %.1f correcting at %.0f" %
                   (nq / n, raw[4 + 10] / nq, nc / n, raw[4 + 11] / nc))
     nsub = sum(p[1] for p in phases)
     print("total %d substeps %.2f ms -> %.2f us/substep -> %.2f M substeps/s at E=%d" %
