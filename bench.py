@@ -106,14 +106,14 @@ def cpu_baseline(cfg, acts0, states, budget_s=15.0):
             "single_core_value": float(ex1 / dt1) if dt1 > 0 and ex1 > 0 else None}
 
 
-def load_traffic(mode, E, n_side, precision, fuse):
-    """HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/r02_traffic.json, produced by
+def load_traffic(mode, E, n_side, precision, init):
+    """HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/r03_traffic.json, produced by
     tools/collect_profiles.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950
-    correction of MI355X_MICROARCH.md). None when no record matches this configuration."""
+    correction of MI355X_MICROARCH.md). None when no record matches this configuration (mode, envs, grid, precision, init)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r03_traffic.json")) as fh:
             for r in json.load(fh)["records"]:
-                if (r["mode"], r["envs"], r["n_side"], r["precision"]) == (mode, E, n_side, precision):
+                if (r["mode"], r["envs"], r["n_side"], r["precision"], r.get("init", "tier1")) == (mode, E, n_side, precision, init):
                     return r["hbm_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
@@ -121,7 +121,7 @@ def load_traffic(mode, E, n_side, precision, fuse):
 
 
 def run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, rank, world, local_rank, thickness=None,
-                 want_cpu=False, step_ms=170.0, slots=0, max_resets=0):
+                 want_cpu=False, step_ms=170.0, slots=0, max_resets=0, allow_tcp_fallback=False):
     """One bench configuration on this rank's GPU; returns the result record (rank 0) or None."""
     from gym_cloth_amd.dist import LocalTransport, RcclTransport, SocketTransport, StepExchange
     from gym_cloth_amd.envs import ClothVecEnv
@@ -131,8 +131,14 @@ def run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, rank
     transport_name = "none (1 GPU)"
     if world > 1:
         try:
-            transport, transport_name = RcclTransport(rank, world, env.batch), "RCCL (ctypes binding, handle stream)"
-        except Exception as exc:                             # never lose the measurement to the exchange of a few KB
+            transport, transport_name = RcclTransport(rank, world, env.batch), "RCCL (ctypes binding, handle stream, device-resident tables)"
+        except Exception as exc:
+            # a multi-GPU record that did not run over RCCL must not pass for one: the TCP transport is opt-in, and then ALL ranks
+            # must fail the same way (a rank that did join the communicator would wait in it forever otherwise)
+            if not allow_tcp_fallback:
+                print("bench: rank %d: RCCL transport failed (%s: %s); pass --allow-tcp-fallback to run over TCP sockets instead"
+                      % (rank, type(exc).__name__, exc), file=sys.stderr)
+                raise
             print("bench: rank %d: RCCL transport failed (%s: %s); using the TCP transport" % (rank, type(exc).__name__, exc),
                   file=sys.stderr)
             transport = SocketTransport(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"),
@@ -167,7 +173,8 @@ def run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, rank
         xch.barrier()                                        # RCCL all-reduce on the handle's stream + stream sync
         env.batch.sync(False)
 
-    stat = {"sub": 0, "act_sub": 0, "kms": 0.0, "launches": 0, "ran": 0, "grabbed": 0, "slots": 0, "resets": 0, "out_of_slots": 0}
+    stat = {"sub": 0, "act_sub": 0, "kms": 0.0, "launches": 0, "ran": 0, "grabbed": 0, "slots": 0, "resets": 0, "out_of_slots": 0,
+            "op_ticks": np.zeros(4), "op_subs": np.zeros(4)}
     cpu_acts = None
     cpu_states = None
     t_timed = 0.0
@@ -195,27 +202,41 @@ def run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, rank
         # every env consumes ITS OWN action stream (RandomState(2000+e)) at its own pace: per launch rank 0 builds the table
         # of each env's next `slots` actions from the per-env counters, broadcasts it, and gets the consumed counts back
         n_warm, n_timed = (warmup + fuse - 1) // fuse, max(1, steps // fuse)
-        n_stream = total + slots * (n_warm + n_timed + 1)
+        n_stream = total + slots * (n_warm + n_timed + 1) * 4
         if rank == 0:
             streams = np.stack([np.random.RandomState(2000 + e).uniform(-1, 1, size=(n_stream, 4)) for e in range(world * E)])
             cnt = np.zeros(world * E, dtype=np.int64)
+        device_xch = world > 1 and hasattr(transport, "broadcast_device")
+        warm_ms, warm_steps = 0.0, 0.0
+        op_ticks = np.zeros(4)
+        op_subs = np.zeros(4)
         for w in range(n_warm + n_timed):
             tbl = None
             if rank == 0:
                 idx = (cnt[None, :] + np.arange(slots)[:, None]) % n_stream
                 tbl = streams[np.arange(world * E)[None, :], idx]                     # [slots, world*E, 4]
-            tbl = xch.broadcast_actions(tbl, n_actions=slots)
+                tbl = np.ascontiguousarray(tbl.reshape(slots, world, E, 4).transpose(1, 0, 2, 3))   # rank-major blocks
+            # RCCL: the table is broadcast in place in device memory and the launch reads this rank's block there
+            blk, d_blk = xch.broadcast_action_blocks(tbl, slots, env.batch if device_xch else None)
             if w == n_warm:
                 if want_cpu and rank == 0:
                     cpu_states = env.batch.get_state(0, min(E, 512))
-                    cpu_acts = tbl[0][:min(E, 512)].copy()
+                    cpu_acts = blk[0][:min(E, 512)].copy() if blk is not None else None
+                # the timed launches are sized from what the warm-up measured, so that the timed region covers `steps` env steps
+                if warm_steps > 0:
+                    slice_ms = fuse * (warm_ms / warm_steps)
                 fence()
                 t0 = time.perf_counter()
-            out = env.step_many(tbl, auto_reset=True, time_budget_ms=slice_ms, max_resets=max_resets)
+            out = env.step_many(blk, n_actions=slots, actions_device_ptr=d_blk, auto_reset=True, time_budget_ms=slice_ms,
+                                max_resets=max_resets)
+            res = xch.gather_summary(env.batch)              # [world*E, 4]: slots consumed, episode over, coverage, action substeps
             n_ran = out["ran"].sum(axis=0)
-            res = xch.gather_results(n_ran, out["done"][-1], out["actual_coverage"][-1], out["executed"].sum(axis=0))
+            assert np.array_equal(res[g0:g0 + E, 0].astype(np.int64), n_ran)            # the device's summary == the records
             if rank == 0:
                 cnt += res[:, 0].astype(np.int64)
+            if w < n_warm:
+                warm_ms += env.batch.last_kernel_ms
+                warm_steps += float(res[:, 0].sum()) / (world * E)
             if w >= n_warm:
                 a_sub = int(out["executed"].sum())
                 r_sub = int(out["reset_substeps"].sum()) + int(out.get("tail_reset_substeps", np.zeros(1)).sum())
@@ -224,16 +245,27 @@ def run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, rank
                 stat["ran"] += int(n_ran.sum()); stat["grabbed"] += int((out["n_grabbed"] > 0).sum()); stat["slots"] += slots * E
                 stat["resets"] += int((out["reset_before"] > 0).sum()) + int((out.get("tail_reset_substeps", np.zeros(1)) > 0).sum())
                 stat["out_of_slots"] += int((n_ran == slots).sum())
+                op_ticks += out["op_ticks"].sum(axis=0).astype(np.float64)
+                op_subs += out["op_substeps"].sum(axis=0).astype(np.float64)
         fence()
         t_timed = time.perf_counter() - t0
+        stat["op_ticks"], stat["op_subs"] = op_ticks, op_subs
     dt = xch.max_over_ranks(t_timed)
     n_sub_all = xch.sum_over_ranks(stat["sub"])
     n_act_all = xch.sum_over_ranks(stat["act_sub"])
     n_env_steps = xch.sum_over_ranks(stat["ran"])
     rec = None
     if rank == 0:
-        b_alg = 49 * P                                        # algorithmic bytes per cloth-substep (fp32)
+        b_alg32 = 49 * P                                      # algorithmic bytes per cloth-substep (fp32 state)
+        b_alg = b_alg32 if precision == "f32" else 97 * P     # the same accounting at the f64 instantiation's state width
         ach = (stat["sub"] * b_alg / 1e9) / (stat["kms"] / 1e3) if stat["kms"] > 0 else 0.0
+        # SURVEY 8d's metric proper (reset excluded): action substeps / time spent in actions. The kernel accounts every env's
+        # launch time to {actions, reset pulls, reset settling, rest}; with n_conc cloths stepping concurrently on the GPU the
+        # rate of an actions-only workload is n_conc * sum(action substeps) / sum(env-seconds in actions).
+        tk, sb = stat["op_ticks"], stat["op_subs"]
+        n_conc = min(E, 512)                                  # resident cloths: 2 per CU (LDS-bound), 256 CUs
+        act_only = n_conc * sb[0] / (tk[0] / 1e8) if tk[0] > 0 else None
+        reset_only = n_conc * (sb[1] + sb[2]) / ((tk[1] + tk[2]) / 1e8) if (tk[1] + tk[2]) > 0 else None
         rec = {
             "value": n_sub_all / dt, "ms_per_step": dt / max(n_env_steps / (world * E), 1e-9) * 1e3, "dtype": precision,
             "config": {"workload": "%d batched %dx%d cloths per GPU, %s start, random pick-and-place actions, episodes "
@@ -246,7 +278,13 @@ def run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, rank
                        "env_steps_executed": n_env_steps, "steps_equivalent": n_env_steps / (world * E),
                        "env_steps_per_s": n_env_steps / dt,
                        "substeps_per_env_step": n_sub_all / max(n_env_steps, 1),
-                       "action_substeps_per_s": n_act_all / dt,
+                       "action_substeps_per_s": n_act_all / dt,                         # action substeps / WHOLE time: a lower bound
+                       # SURVEY 8d's definition (reset excluded), this rank: action substeps / time the envs spent in actions
+                       "action_only_substeps_per_s": act_only, "reset_only_substeps_per_s": reset_only,
+                       "reset_substep_frac": 1.0 - stat["act_sub"] / max(stat["sub"], 1),
+                       "time_frac_by_class": dict(zip(("actions", "reset_pulls", "reset_settling", "other"),
+                                                      (tk / max(tk.sum(), 1.0)).tolist())),
+                       "slice_ms": slice_ms if mode == "fused" else None,
                        "grabbed_env_frac": stat["grabbed"] / max(stat["ran"], 1),       # env-steps whose pick point hit the cloth (else 0 substeps)
                        "envs_out_of_slots": stat["out_of_slots"],                       # fused: envs that used all their action slots of a launch
                        # fraction of (env, launch) pairs in which the env was busy for the whole launch (fused: it did not run out
@@ -254,9 +292,10 @@ def run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, rank
                        "active_env_frac": 1.0 - stat["out_of_slots"] / max(E * stat["launches"], 1) if mode == "fused" else 1.0,
                        "episode_resets_in_timed_region": stat["resets"]},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": load_traffic(mode, E, n_side, precision, fuse),
+                         "frac": ach / HBM_PEAK_GBS, "traffic": load_traffic(mode, E, n_side, precision, init),
                          "kernel": "k_run_schedule", "kernel_ms_avg": stat["kms"] / max(stat["launches"], 1),
                          "launches": stat["launches"], "alg_bytes_per_substep": b_alg,
+                         "frac_on_fp32_bytes": (stat["sub"] * b_alg32 / 1e9) / (stat["kms"] / 1e3) / HBM_PEAK_GBS if stat["kms"] > 0 else 0.0,
                          "substeps_per_launch": stat["sub"] / max(stat["launches"], 1)},
         }
         if want_cpu and cpu_states is not None:
@@ -272,22 +311,118 @@ def run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, rank
 
 def self_launch(args):
     """--gpus N without a launcher environment: start one child process per GPU (fresh processes: nothing in THIS process
-    has touched the GPU, and no process is ever replaced by exec), relay rank 0's JSON line."""
+    has touched the GPU, and no process is ever replaced by exec), relay rank 0's JSON line. All children are supervised: when one
+    exits non-zero the others are terminated and its code is returned (a rank that failed to join the communicator must not leave the
+    rest waiting in it)."""
+    import secrets
     import socket
+    import tempfile
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    rdzv = os.path.join(os.environ.get("TMPDIR", "/tmp"), "clothhip_rccl_%d_%d.id" % (port, os.getpid()))
+    rdzv_dir = tempfile.mkdtemp(prefix="clothhip_rdzv_")          # private directory (0700): nobody else can plant an id file
+    rdzv = os.path.join(rdzv_dir, "rccl.id")
+    nonce = secrets.token_hex(16)
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), CLOTHHIP_RDZV_FILE=rdzv, HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   MASTER_PORT=str(port), CLOTHHIP_RDZV_FILE=rdzv, CLOTHHIP_RDZV_NONCE=nonce, HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        rc = max(rc, p.wait())
-    sys.stdout.write(out0.decode())
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad:
+            rc = bad[0]
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    try:
+        if os.path.exists(rdzv):
+            os.remove(rdzv)
+        os.rmdir(rdzv_dir)
+    except OSError:
+        pass
+    if out0 and out0[0]:
+        sys.stdout.write(out0[0].decode())
     return rc
+
+
+def dry_run(args, rank, world):
+    """--dry-run: everything of a multi-rank bench run but the GPU -- launcher environment, rendezvous file protocol (a stand-in
+    128-byte id travels exactly as the RCCL unique id does), the per-launch exchange pattern over the TCP transport and rank 0's
+    JSON line. The CPU test suite drives bench.py's own launcher through this (tests/test_dist_sockets.py)."""
+    from gym_cloth_amd import rccl
+    from gym_cloth_amd.dist import LocalTransport, SocketTransport, StepExchange
+    E = args.envs
+    if os.environ.get("CLOTH_BENCH_DRY_FAIL_RANK") == str(rank):      # test hook: this rank dies before joining
+        return 7
+    head = rccl._MAGIC + rccl._nonce(rccl.rendezvous_path(), world) + int(world).to_bytes(4, "little")
+    path = rccl.rendezvous_path()
+    if world > 1:
+        if rank == 0:
+            tmp = "%s.tmp%d" % (path, os.getpid())
+            with open(tmp, "wb") as fh:
+                fh.write(head + bytes(range(128)))
+            os.replace(tmp, path)
+        else:
+            t0 = time.time()
+            while True:
+                try:
+                    raw = open(path, "rb").read()
+                    if raw[:len(head)] == head and raw[len(head):] == bytes(range(128)):
+                        break
+                except OSError:
+                    pass
+                if time.time() - t0 > 60:
+                    print("bench: rank %d: no rendezvous file" % rank, file=sys.stderr)
+                    return 3
+                time.sleep(0.01)
+    t = SocketTransport(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")) + 17) \
+        if world > 1 else LocalTransport()
+    xch = StepExchange(E, t)
+    slots, total = 3, 0.0
+    for w in range(args.steps):
+        tbl = None
+        if rank == 0:
+            tbl = np.arange(world * slots * E * 4, dtype=np.float64).reshape(world, slots, E, 4) + w
+        blk, d_blk = xch.broadcast_action_blocks(tbl, slots)
+        assert d_blk is None and blk.shape == (slots, E, 4) and blk[0, 0, 0] == rank * slots * E * 4 + w
+        summ = np.stack([np.full(E, slots, dtype=np.float64), np.zeros(E), blk[-1, :, 0], np.full(E, 100.0 * (rank + 1))], axis=1)
+
+        class _B(object):                                     # what gather_summary reads off a ClothBatch
+            def run_summary(self_):
+                return summ
+        res = xch.gather_summary(_B())
+        assert res.shape == (world * E, 4)
+        total += float(res[:, 3].sum())
+    dt = xch.max_over_ranks(0.001 * (rank + 1))
+    n_sub = xch.sum_over_ranks(100.0 * (rank + 1) * E * args.steps)
+    xch.barrier()
+    t.close()
+    if world > 1 and rank == 0:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no GPU): launcher, rendezvous and exchange plumbing", "value": n_sub / dt,
+                          "unit": "cloth-substeps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "config": {"workload": "dry run", "transport": "TCP sockets (dry run)", "gathered_substeps": total}}))
+    return 0
 
 
 def main():
@@ -308,6 +443,9 @@ def main():
                          "work per cloth-substep for other grids / precisions)")
     ap.add_argument("--slots", type=int, default=0, help="fused mode: action slots per env and launch (0: 4 * fuse)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--allow-tcp-fallback", action="store_true",
+                    help="multi-GPU: run the exchange over TCP sockets if RCCL cannot be initialised (default: fail)")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU: exercise launcher, rendezvous and exchange plumbing only")
     ap.add_argument("--no-extra", action="store_true", help="skip the companion records (f64, step mode, tier-2, 50x50, 2048 cloths)")
     args = ap.parse_args()
 
@@ -317,10 +455,13 @@ def main():
     rank, local_rank, world = env_from_launcher()
     if args.gpus > 1 and world != args.gpus and rank == 0:
         print("bench: --gpus %d but the launcher started %d ranks; using %d" % (args.gpus, world, world), file=sys.stderr)
+    if args.dry_run:
+        sys.exit(dry_run(args, rank, world))
 
     head = run_workload(args.n_side, args.envs, args.precision, args.init, args.mode, args.steps, args.warmup, args.fuse,
                         rank, world, local_rank, thickness=args.thickness,
-                        want_cpu=(world == 1 and not args.no_cpu_baseline), step_ms=args.step_ms, slots=args.slots)
+                        want_cpu=(world == 1 and not args.no_cpu_baseline), step_ms=args.step_ms, slots=args.slots,
+                        allow_tcp_fallback=args.allow_tcp_fallback)
     extra = []
     if world == 1 and not args.no_extra:
         def companion(label, **kw):

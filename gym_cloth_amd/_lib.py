@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("CLOTHHIP_LIB") or os.path.join(_HERE, "libclothhip.so
 
 F64, F32 = 0, 1
 REST_SHARED, KEEP_TEAR = 1, 2           # clothhip_set_state flags
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 OK, EINVAL, ENODEV, EHIP, ENOMEM, ESTATE = 0, -1, -2, -3, -4, -5
 
@@ -111,6 +111,8 @@ SYMBOLS = [
                                              _vp, C.c_int32, _i32p, _u8p, _vp, C.c_int32, C.c_uint64, C.c_int32, C.c_int32,
                                              C.c_int32, C.c_double]),
     ("clothhip_run_actions_end", C.c_int, [_vp, _i32p, _u8p, _vp, _vp, _vp, _vp, _vp]),
+    ("clothhip_run_actions_op_ticks", C.c_int, [_vp, _vp]),
+    ("clothhip_run_actions_summary", C.c_int, [_vp, _dp, C.POINTER(_vp)]),
     ("clothhip_run_actions", C.c_int, [_vp, C.POINTER(ClothEpisodeParams), C.c_int32, C.c_int32, _vp, C.c_int32, _i32p, _vp,
                                        C.c_int32, _i32p, _u8p, _vp, _vp, _vp, _vp, C.c_double]),
     ("clothhip_update", C.c_int, [_vp, C.c_int32, _dp]),

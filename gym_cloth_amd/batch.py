@@ -306,6 +306,27 @@ class ClothBatch(object):
                                                vp(robs), vp(rng_states)))
         return rec, rst, obs, robs
 
+    def run_summary(self):
+        """float64[E, 4] written by the last episode launch: actions executed, episode over, coverage after the env's last
+        action / reset of the launch (NaN: none), update() calls of its actions (clothhip_run_actions_summary)."""
+        out = np.zeros((self.E, 4))
+        check(self._L.clothhip_run_actions_summary(self._h, _lib.dp(out), None))
+        return out
+
+    @property
+    def run_summary_device_ptr(self):
+        """Device address of that table (for an in-place all-gather on the handle's stream)."""
+        p = C.c_void_p()
+        check(self._L.clothhip_run_actions_summary(self._h, None, C.byref(p)))
+        return p.value
+
+    def op_ticks(self):
+        """Where the time of the last episode launch went, per env (clothhip_run_actions_op_ticks): (ticks uint64[E, 4] in 100 MHz
+        ticks, substeps uint64[E, 4]) for the classes {actions, reset pulls, reset settling, the rest}."""
+        raw = np.zeros((self.E, 8), dtype=np.uint64)
+        check(self._L.clothhip_run_actions_op_ticks(self._h, raw.ctypes.data_as(C.c_void_p)))
+        return raw[:, :4].copy(), raw[:, 4:].copy()
+
     def run_actions(self, *a, **k):
         """clothhip_run_actions: `n_actions` whole ClothEnv.step calls per env in one launch (begin + end)."""
         self.run_actions_begin(*a, **k)

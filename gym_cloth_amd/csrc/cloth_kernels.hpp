@@ -71,6 +71,10 @@ template <typename T> struct FusedArgs {
     uint64_t domrand_words;           // 32-bit words the domain-randomisation draws after a reset consume (cloth_env.py:786-789), or 0
     int32_t rng_tier, _pad2;          // with mt: 1 or 3, the reset procedure to draw (cloth_env.py:843-891, :951-982)
     EpResume *resume;                 // [E] or nullptr: operations cut by the previous launch's time slice / to be cut by this one
+    double *summary;                  // [E][4] or nullptr: per env {actions executed by this launch, episode over (0/1), coverage after its last
+                                      // action or reset of this launch (NaN: none), Cloth.update() calls of its actions}: what the multi-GPU driver gathers
+    uint64_t *op_ticks;               // [E][8] or nullptr: per env, 100 MHz ticks of this launch spent in {actions, reset pulls, reset settling, the
+                                      // rest (episode rebuild, idling out of slots)} and the Cloth.update() calls executed in each
     uint64_t budget_ticks;            // 0 = none; else no new action / reset starts once the launch has run this many 100 MHz ticks
     double two_thickness, half_thickness;
     ClothEpisodeParams ep;
@@ -91,10 +95,14 @@ struct EpState {
     int32_t stop;          // the launch's time slice is used up: no new action or reset starts
     int32_t side;          // device-RNG resets: Cloth.init_side of the reset in progress (cloth.pyx:75)
     int32_t choice;        // tier-2 reset: the corner picked for the first pull (-25 or -1, cloth_env.py:907)
-    int32_t swap, _pad;    // how the cloth was built, for the policies: 0 flat tiers, 1 tier 2 with init_side False (the oracle-corner
+    int32_t swap, n_ran;   // n_ran: actions executed by this launch (per-launch, not carried over). swap: how the cloth was built, for the policies: 0 flat tiers, 1 tier 2 with init_side False (the oracle-corner
                            // policy swaps its corner indices, analytic.py:108-114), 2 tier 2 with init_side True
     double act[4];
     ClothResetPull pull;   // device-RNG resets: the draws of the pull being executed
+    uint64_t t_mark;       // per-operation accounting of this launch (not carried across launches): last boundary,
+    uint64_t ticks[4];     //   ticks per class (0 action, 1 reset pull incl. its coverage test, 2 reset settling, 3 other),
+    uint32_t subs[4];      //   update() calls per class
+    double last_cov;       // coverage after the last action / reset of this launch (NaN: none yet)
 };
 
 // An operation cut by the end of a time slice (clothhip_run_actions with a time budget): everything needed to continue it in
@@ -246,7 +254,7 @@ struct LdsLayout {
         int o = 0;
         auto take = [&](int bytes) { int r = o; o += (bytes + 15) / 16 * 16; return r; };
         cur = take(4 * Ppad * tsz);
-        eps = take(176);             // EpState (fused episodes)
+        eps = take(240);             // EpState (fused episodes)
         wtab = take(tab >= 1 ? Spad * (tsz == 8 ? 16 : 8) : 0);   // WEnt<T>[Spad]; everything from here on doubles as scratch of the
                                                                   // in-kernel metrics and is rebuilt afterwards
         hkey = take(HT * 4);
@@ -819,11 +827,20 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
     // broadcasts), so the whole workgroup takes the same path through every barrier.
     enum { OP_SCHED = 0, OP_ACTION, OP_RESET_COND, OP_RESET_PULL, OP_RESET_SETTLE, OP_RESET_END };
     EpState *const eps = reinterpret_cast<EpState *>(smem + lay.eps);
+    // thread 0, at the end of an operation (or where a time slice cuts it): everything since the last boundary goes to its class
+    auto account = [&](int op_, int n_sub) {
+        const int cls = op_ == OP_ACTION ? 0 : ((op_ == OP_RESET_PULL || op_ == OP_RESET_COND) ? 1 : (op_ == OP_RESET_SETTLE ? 2 : 3));
+        const uint64_t now_ = __builtin_amdgcn_s_memrealtime();
+        eps->ticks[cls] += now_ - eps->t_mark; eps->t_mark = now_; eps->subs[cls] += (uint32_t)n_sub;
+    };
     if (fused) {
         if (tid == 0) {
             eps->t_slot = 0; eps->rp = -1; eps->n_resets = 0; eps->chain_ok = 1; eps->rs_pulls = 0; eps->reset_mark = 0;
             eps->ep_steps = Fp->num_steps[e]; eps->ep_done = Fp->done[e] ? 1 : 0; eps->done_total = 0; eps->stop = 0;
             misc[7] = 0;
+            eps->t_mark = __builtin_amdgcn_s_memrealtime();
+            for (int q = 0; q < 4; q++) { eps->ticks[q] = 0; eps->subs[q] = 0; }
+            eps->last_cov = __longlong_as_double(0x7ff8000000000000LL); eps->n_ran = 0;
             eps->swap = Fp->policy_arg != nullptr ? Fp->policy_arg[e] : 0; eps->choice = 0;   // 0 flat tiers, 1 / 2 tier 2 with init_side False / True
             if (Fp->resume != nullptr && Fp->resume[e].valid) {        // continue the operation the previous time slice cut
                 const EpResume *rs_ = Fp->resume + e;
@@ -1719,6 +1736,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
             if (it_next >= 0) {                          // cut by the time slice: park the run and leave
                 if (tid == 0) {
                     eps->done_total += done - (resumed_run ? resume_done : 0);
+                    account(eps->op, done - (resumed_run ? resume_done : 0));
                     EpResume *rs_ = F.resume + e;
                     rs_->valid = 1; rs_->it = it_next; rs_->done_partial = done; rs_->sc = sc; rs_->eps = *eps;
                     if (eps->rp >= 0 && F.resets != nullptr) {
@@ -1750,6 +1768,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
             if (tid == 0) {
                 if (F.budget_ticks != 0 && __builtin_amdgcn_s_memrealtime() - t_launch >= F.budget_ticks) eps->stop = 1;
                 eps->done_total += done - (resumed_run ? resume_done : 0);
+                account(op, done - (resumed_run ? resume_done : 0));
                 if (op == OP_ACTION) {
                     const int ep_steps = eps->ep_steps + 1;
                     const bool oob_ = mo[2] != 0.0;
@@ -1757,12 +1776,12 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                     const bool dn = ep_steps >= F.ep.max_actions || tear_now != 0 || oob_ || mo[0] > F.ep.coverage_done;
                     ClothStepRecord *r_ = F.records + ((size_t)t_slot * F.E + e);
                     r_->action[0] = eps->act[0]; r_->action[1] = eps->act[1]; r_->action[2] = eps->act[2]; r_->action[3] = eps->act[3];
-                    r_->coverage = mo[0]; r_->variance_inv = mo[1];
+                    r_->coverage = mo[0]; r_->variance_inv = mo[1]; eps->last_cov = mo[0];
                     r_->executed = done; r_->n_grabbed = eps->n_grab; r_->iters_pull = eps->iters_pull;
                     r_->n_below_half_thickness = (int32_t)mo[3];
                     r_->ran = eps->decode_err ? 2 : 1; r_->oob = oob_ ? 1 : 0; r_->tear = tear_now ? 1 : 0; r_->done = dn ? 1 : 0;
                     r_->reset_before = (uint8_t)eps->reset_mark;
-                    eps->reset_mark = 0; eps->ep_steps = ep_steps; eps->ep_done = dn ? 1 : 0; eps->t_slot = t_slot + 1;
+                    eps->reset_mark = 0; eps->ep_steps = ep_steps; eps->ep_done = dn ? 1 : 0; eps->t_slot = t_slot + 1; eps->n_ran += 1;
                 } else {
                     const bool rngm = F.mt != nullptr;
                     const ClothResetScript *scr = rngm ? nullptr : F.scripts + ((size_t)e * F.n_scripts + n_resets);
@@ -1783,6 +1802,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                         eps->rp = (with_tier2 && rp == 8) ? 0 : 7;
                     } else {                                                                      // OP_RESET_END
                         if (rr_) { rr_->start_coverage = mo[0]; rr_->start_variance_inv = mo[1]; rr_->tear = tear_now; }
+                        eps->last_cov = mo[0];
                         // a conditional pull that ran consumed RNG draws the later scripts were drawn without (clothhip.h)
                         if (!rngm) {
                             int n_uncond = 0;
@@ -1814,7 +1834,17 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
             const int i = tid + q * NT;
             if (i < P) { gq[i] = pvx[q]; gq[Ppad + i] = pvy[q]; gq[2 * Ppad + i] = pvz[q]; }
         }
-        if (tid == 0 && fused) { Fp->num_steps[e] = eps->ep_steps; Fp->done[e] = (uint8_t)eps->ep_done; }
+        if (tid == 0 && fused) {
+            Fp->num_steps[e] = eps->ep_steps; Fp->done[e] = (uint8_t)eps->ep_done;
+            if (Fp->summary != nullptr) {
+                double *sm_ = Fp->summary + 4 * (size_t)e;
+                sm_[0] = (double)eps->n_ran; sm_[1] = eps->ep_done ? 1.0 : 0.0; sm_[2] = eps->last_cov; sm_[3] = (double)eps->subs[0];
+            }
+            if (Fp->op_ticks != nullptr) {
+                eps->ticks[3] += __builtin_amdgcn_s_memrealtime() - eps->t_mark;     // what is left: rebuilds, idling out of action slots
+                for (int q = 0; q < 4; q++) { Fp->op_ticks[8 * e + q] = eps->ticks[q]; Fp->op_ticks[8 * e + 4 + q] = eps->subs[q]; }
+            }
+        }
         if (tid == 0) {
             A.tear[e] = misc[0]; A.executed[e] = done;
             if (A.stats) {
@@ -1930,6 +1960,16 @@ __global__ void k_reset_flat(T *pos, T *prev, uint8_t *cnt, int32_t *tear, const
     if (rest_stride)
         for (int i = threadIdx.x; i < Spad; i += blockDim.x) rest[(size_t)e * rest_stride + i] = flat_rest[i];
     if (threadIdx.x == 0) tear[e] = 0;
+}
+
+// A state change from outside the episode launches voids the operation a time slice left in flight -- for the envs it touches only:
+// mask (or the schedules' active flags) selects them, nullptr = every env.
+__global__ void k_clear_resume(EpResume *r, const uint8_t *mask, const ClothSchedule *sched, int E) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    if (mask && !mask[e]) return;
+    if (sched && !(sched[e].active && sched[e].n_total > 0)) return;
+    r[e].valid = 0;
 }
 
 __global__ void k_selftest(int op, const double *a, const double *b, double *out, long long n) {

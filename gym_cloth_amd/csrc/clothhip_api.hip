@@ -67,6 +67,8 @@ struct clothhip_handle {
     EpResume *d_resume = nullptr;   // [E] operations cut by a time slice (clothhip_run_actions), continued by the next launch
     uint32_t *d_fmt = nullptr;      // [E][MT_WORDS] numpy RandomState of every env (device-drawn resets)
     uint8_t *d_fdone = nullptr;
+    double *d_fsum = nullptr;       // [E][4] per-env summary of the last episode launch (what the multi-GPU driver all-gathers)
+    uint64_t *d_fticks = nullptr;   // [E][8] per-operation-class ticks and update() counts of the last episode launch
     int f_T = 0; size_t f_nscr = 0; bool f_pending = false, f_resets = false, f_obs = false, f_robs = false, f_mt = false;
     size_t cap_fact = 0, cap_frec = 0, cap_fobs = 0, cap_fscr = 0, cap_frst = 0, cap_frobs = 0, cap_fparg = 0;
     Topology topo;
@@ -163,7 +165,7 @@ static void free_handle(clothhip_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_pos, h->d_prev, h->d_rest, h->d_cnt, h->d_active, h->d_tear, h->d_exec, h->d_ngrab, h->d_stats,
-                    h->d_sched, h->d_flat, h->d_flat_rest, h->d_hcnt, h->d_fz, h->d_fact, h->d_fscr, h->d_frec, h->d_frst, h->d_fobs, h->d_frobs, h->d_fsteps, h->d_fparg, h->d_fdone, h->d_fmt, h->d_resume, h->d_gather, h->d_wt_ent, h->d_levels, h->d_xy, h->d_radius, h->d_cov, h->d_vinv, h->d_oob};
+                    h->d_sched, h->d_flat, h->d_flat_rest, h->d_hcnt, h->d_fz, h->d_fact, h->d_fscr, h->d_frec, h->d_frst, h->d_fobs, h->d_frobs, h->d_fsteps, h->d_fparg, h->d_fdone, h->d_fticks, h->d_fsum, h->d_fmt, h->d_resume, h->d_gather, h->d_wt_ent, h->d_levels, h->d_xy, h->d_radius, h->d_cov, h->d_vinv, h->d_oob};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->h_sched) (void)hipHostFree(h->h_sched);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -308,10 +310,17 @@ extern "C" int clothhip_num_envs(const clothhip_handle *h) { return h ? h->E : f
 extern "C" int clothhip_precision(const clothhip_handle *h) { return h ? h->precision : fail(CLOTHHIP_EINVAL, "handle is NULL"); }
 extern "C" void *clothhip_stream(clothhip_handle *h) { return h ? (void *)h->stream : nullptr; }
 
-// Any state change from outside the episode launches (uploads, resets, grabs, raw schedules) voids the operations a time
-// slice left in flight.
-static int drop_in_flight(clothhip_handle *h) {
-    if (h->d_resume) HIPCHECK(hipMemsetAsync(h->d_resume, 0, (size_t)h->E * sizeof(EpResume), h->stream));
+// Any state change from outside the episode launches (uploads, resets, grabs, raw schedules) voids the operation a time slice
+// left in flight -- for the envs that call touches, and only for them: the parked operations of the others continue in the next
+// episode launch. d_mask: device mask [E] (nullptr = all); d_sched: device schedules whose active flag selects (or nullptr).
+static int drop_in_flight(clothhip_handle *h, const uint8_t *d_mask, const ClothSchedule *d_sched) {
+    if (!h->d_resume) return 0;
+    hipLaunchKernelGGL(k_clear_resume, dim3((h->E + 255) / 256), dim3(256), 0, h->stream, h->d_resume, d_mask, d_sched, h->E);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+static int drop_in_flight_range(clothhip_handle *h, int env0, int n) {
+    if (h->d_resume && n > 0) HIPCHECK(hipMemsetAsync(h->d_resume + env0, 0, (size_t)n * sizeof(EpResume), h->stream));
     return 0;
 }
 
@@ -341,7 +350,7 @@ template <typename T> static void soa_to_aos(const T *src, double *dst, int n, i
 extern "C" int clothhip_set_state(clothhip_handle *h, int32_t env0, int32_t n, const double *pos, const double *prev,
                                   const uint8_t *pinned, const double *rest, int32_t flags) {
     if (int rc = check_range(h, env0, n)) return rc;
-    if (int rc = drop_in_flight(h)) return rc;
+    if (int rc = drop_in_flight_range(h, env0, n)) return rc;
     const bool rest_shared = (flags & CLOTHHIP_REST_SHARED) != 0;
     HIPCHECK(hipSetDevice(h->device));
     HIPCHECK(hipStreamSynchronize(h->stream));
@@ -429,8 +438,8 @@ extern "C" int clothhip_get_rest(clothhip_handle *h, int32_t env0, int32_t n, do
 extern "C" int clothhip_reset_flat(clothhip_handle *h, const uint8_t *mask) {
     if (!h) return fail(CLOTHHIP_EINVAL, "handle is NULL");
     HIPCHECK(hipSetDevice(h->device));
-    if (int rc = drop_in_flight(h)) return rc;
     if (mask) HIPCHECK(hipMemcpyAsync(h->d_active, mask, (size_t)h->E, hipMemcpyHostToDevice, h->stream));
+    if (int rc = drop_in_flight(h, mask ? h->d_active : nullptr, nullptr)) return rc;
     if (h->precision == CLOTHHIP_F64)
         hipLaunchKernelGGL(k_reset_flat<double>, dim3(h->E), dim3(256), 0, h->stream, (double *)h->d_pos, (double *)h->d_prev, h->d_cnt,
                            h->d_tear, (const double *)h->d_flat, mask ? h->d_active : nullptr, h->Ppad, (double *)h->d_rest,
@@ -468,10 +477,10 @@ static int do_grab(clothhip_handle *h, const double *xy, const double *radius, c
                    int32_t *n_grabbed, int top) {
     if (!h || !xy) return fail(CLOTHHIP_EINVAL, "NULL argument");
     HIPCHECK(hipSetDevice(h->device));
-    if (int rc = drop_in_flight(h)) return rc;
     HIPCHECK(hipMemcpyAsync(h->d_xy, xy, (size_t)h->E * 16, hipMemcpyHostToDevice, h->stream));
     if (radius) HIPCHECK(hipMemcpyAsync(h->d_radius, radius, (size_t)h->E * 8, hipMemcpyHostToDevice, h->stream));
     if (active) HIPCHECK(hipMemcpyAsync(h->d_active, active, (size_t)h->E, hipMemcpyHostToDevice, h->stream));
+    if (int rc = drop_in_flight(h, active ? h->d_active : nullptr, nullptr)) return rc;
     if (h->precision == CLOTHHIP_F64) {
         GrabArgs<double> a{(const double *)h->d_pos, h->d_cnt, h->d_xy, radius ? h->d_radius : nullptr,
                            active ? h->d_active : nullptr, h->d_ngrab, h->d_levels, h->n_grab_levels, h->P, h->Ppad, top,
@@ -569,7 +578,7 @@ template <typename T, int FUSED> static void launch_run(clothhip_handle *h, cons
 }
 
 static int run_common(clothhip_handle *h, const ClothSchedule *d_sched) {
-    if (int rc = drop_in_flight(h)) return rc;
+    if (int rc = drop_in_flight(h, nullptr, d_sched)) return rc;
     HIPCHECK(hipEventRecord(h->ev0, h->stream));
     if (h->precision == CLOTHHIP_F64) launch_run<double, 0>(h, d_sched, nullptr);
     else launch_run<float, 0>(h, d_sched, nullptr);
@@ -637,6 +646,8 @@ template <typename T> static void fill_fused(clothhip_handle *h, FusedArgs<T> &f
     f.grid_dx = h->prm.width * 1.0 / (h->N - 1); f.grid_dy = h->prm.height * 1.0 / (h->N - 1);
     f.levels = h->d_levels; f.n_glevels = h->n_grab_levels; f.E = h->E; f.n_scripts = n_scripts; f.budget_ticks = budget_ticks;
     f.resume = h->d_resume;
+    f.op_ticks = h->d_fticks;
+    f.summary = h->d_fsum;
     f.mt = have_mt ? h->d_fmt : nullptr; f.rng_tier = rng_tier; f.domrand_words = domrand_words;
     f.two_thickness = 2 * h->prm.thickness; f.half_thickness = h->prm.thickness / 2.0;
     f.ep = *ep;
@@ -706,7 +717,10 @@ extern "C" int clothhip_run_actions_begin(clothhip_handle *h, const ClothEpisode
         HIPCHECK(hipMalloc(&h->d_fz, 1024));
         HIPCHECK(hipMalloc(&h->d_fsteps, E * 4));
         HIPCHECK(hipMalloc(&h->d_fdone, E));
+        HIPCHECK(hipMalloc(&h->d_fticks, E * 64));
+        HIPCHECK(hipMalloc(&h->d_fsum, E * 32));
     }
+    HIPCHECK(hipMemsetAsync(h->d_fticks, 0, E * 64, h->stream));
     if (int rc = grow(&h->d_frec, &h->cap_frec, nrec * sizeof(ClothStepRecord))) return rc;
     const size_t nscr = E * (size_t)(n_scripts > 0 ? n_scripts : 1);
     if (int rc = grow(&h->d_fscr, &h->cap_fscr, nscr * sizeof(ClothResetScript))) return rc;
@@ -784,6 +798,28 @@ extern "C" int clothhip_run_actions_end(clothhip_handle *h, int32_t *num_steps, 
     if (rng_states) HIPCHECK(hipMemcpyAsync(rng_states, h->d_fmt, E * MT_WORDS * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(hipStreamSynchronize(h->stream));
     h->f_pending = false;
+    return 0;
+}
+
+extern "C" int clothhip_run_actions_summary(clothhip_handle *h, double *summary, void **d_summary) {
+    if (!h) return fail(CLOTHHIP_EINVAL, "handle is NULL");
+    if (!h->d_fsum) return fail(CLOTHHIP_ESTATE, "no clothhip_run_actions launch yet");
+    if (d_summary) *d_summary = h->d_fsum;
+    if (summary) {
+        HIPCHECK(hipSetDevice(h->device));
+        HIPCHECK(hipMemcpyAsync(summary, h->d_fsum, (size_t)h->E * 32, hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(hipStreamSynchronize(h->stream));
+    }
+    return 0;
+}
+
+extern "C" int clothhip_run_actions_op_ticks(clothhip_handle *h, uint64_t *ticks) {
+    if (!h || !ticks) return fail(CLOTHHIP_EINVAL, "NULL argument");
+    if (!h->d_fticks) return fail(CLOTHHIP_ESTATE, "no clothhip_run_actions launch yet");
+    if (h->f_pending) return fail(CLOTHHIP_ESTATE, "clothhip_run_actions_begin still in flight: call clothhip_run_actions_end first");
+    HIPCHECK(hipSetDevice(h->device));
+    HIPCHECK(hipMemcpyAsync(ticks, h->d_fticks, (size_t)h->E * 64, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
     return 0;
 }
 

@@ -71,6 +71,10 @@ def collect_demos(env, policy='oracle_corner', max_episodes=10, slots_per_launch
                     ep['info'].append(_info_at(out, t, e))
                     if ep['done'][-1]:
                         episodes.append(ep)
+            # a time slice can end right after a completed reset: no action of this launch carries its reset_before mark, the
+            # next launch's first action belongs to the NEW episode (analytic.py:866-882: every episode opens with reset()'s obs)
+            for e in np.nonzero(out.get('tail_reset_index', np.zeros(E, dtype=np.int64)))[0]:
+                cur[e] = _new_episode(out['reset_obs'][e, int(out['tail_reset_index'][e]) - 1].copy(), e)
     else:
         cur = [_new_episode(obs[e].copy(), e) for e in range(E)]
         steps = np.zeros(E, dtype=np.int64)

@@ -239,6 +239,36 @@ class StepExchange(object):
                         np.asarray(coverage, dtype=np.float64), np.asarray(executed, dtype=np.float64)], axis=1)
         return self.t.allgather(loc)
 
+    # ---- device-resident exchange of the episode launches (RCCL transport; the others fall back to the host calls above) ----
+    def broadcast_action_blocks(self, table_all, n_actions, batch=None):
+        """Action table of an episode launch, rank-major: rank 0 passes float64[world, n_actions, E, 4] (the others None).
+        Returns (host_block, device_ptr): with the RCCL transport the table is broadcast IN PLACE in device memory and
+        device_ptr addresses this rank's block [n_actions, E, 4] -- the launch reads it directly
+        (step_many(actions_device_ptr=...)), nothing is staged through the host on the receiving side; otherwise host_block is
+        this rank's block as an array."""
+        shape = (self.world, int(n_actions), self.E, 4)
+        if hasattr(self.t, "broadcast_device") and batch is not None:
+            nbytes = int(np.prod(shape)) * 8
+            d = self.t._buf("act_tbl", nbytes)
+            if self.rank == 0:
+                batch.device_upload(d, np.ascontiguousarray(table_all, dtype=np.float64).reshape(shape))
+            self.t.broadcast_device(d, nbytes)
+            return None, d + self.rank * (nbytes // self.world)
+        return np.ascontiguousarray(self.t.broadcast(table_all, shape, np.float64)[self.rank]), None
+
+    def gather_summary(self, batch):
+        """All-gather of the per-env summary the launch wrote on the device (ClothBatch.run_summary): float64[world*E, 4] =
+        {actions executed, episode over, coverage, action substeps}. RCCL transport: ncclAllGather straight from the handle's
+        table into a device buffer, one download of the result; otherwise through the host."""
+        if hasattr(self.t, "allgather_device"):
+            nb = self.E * 32
+            d_all = self.t._buf("sum_all", nb * self.world)
+            self.t.allgather_device(batch.run_summary_device_ptr, d_all, nb)
+            out = np.empty((self.world * self.E, 4))
+            batch.device_download(out, d_all)                 # synchronises the stream
+            return out
+        return self.t.allgather(batch.run_summary())
+
     def gather_obs(self, obs_loc):
         """All-gather of the '1d' observations float32[E, 3P] -> float32[world*E, 3P]."""
         return self.t.allgather(np.asarray(obs_loc, dtype=np.float32))

@@ -449,7 +449,8 @@ class ClothVecEnv(object):
         actions[n_e:, e] again in the next call. Results do not depend on how an env's actions are split into launches.
 
         Returns a dict of arrays [T, E] (rew, done, ran, executed, n_grabbed, reset_before, and the info keys of step())
-        plus 'obs' [E, 3P] (state after the launch), 'actions' [T, E, 4] and, with want_obs, 'obs_t' [T, E, 3P]."""
+        plus 'obs' [E, 3P] (state after the launch), 'actions' [T, E, 4], with want_obs 'obs_t' [T, E, 3P], and the launch's time
+        accounting 'op_ticks' / 'op_substeps' uint64[E, 4] (ClothBatch.op_ticks)."""
         from . import _lib
         import time as _time
         _tp = [_time.perf_counter()]
@@ -520,6 +521,7 @@ class ClothVecEnv(object):
                 self._extend_chain(e, 2 * R)
         _lap('draw_ahead(overlapped)')
         rec, rst, obs_t, robs = self.batch.run_actions_end()
+        op_ticks, op_substeps = self.batch.op_ticks()
         _lap('wait+download')
         if (rec['ran'] == 2).any():
             raise FloatingPointError("iters_pull does not terminate (non-finite action?)")
@@ -529,6 +531,8 @@ class ClothVecEnv(object):
         for k in ('executed', 'n_grabbed', 'num_steps', 'num_sim_steps', 'reset_before', 'reset_substeps'):
             out[k] = np.zeros((T, E), dtype=np.int64)
         out['actions'] = rec['action'].copy()
+        # per env: 100 MHz ticks of this launch spent in {actions, reset pulls, reset settling, the rest} and the update() calls of each
+        out['op_ticks'], out['op_substeps'] = op_ticks, op_substeps
         n_consumed = np.zeros(E, dtype=np.int64)
         for t in range(T):
             r = rec[t]
@@ -562,6 +566,7 @@ class ClothVecEnv(object):
                 rb = np.zeros(E, dtype=np.int64)
                 rb[tail] = n_consumed[tail] + 1
                 out['tail_reset_substeps'] = np.zeros(E, dtype=np.int64)
+                out['tail_reset_index'] = rb.copy()                   # 1-based index into reset_obs[e] of that reset, 0 = none
                 self._apply_reset_records(tail, rb, rst, n_consumed, out['tail_reset_substeps'], use_rng)
         # the device's view of the episode state must be the host's, except where a time slice cut a reset in the middle (the
         # device has already zeroed that env's counters; the host learns of the reset from the launch that completes it)

@@ -76,16 +76,41 @@ def rendezvous_path():
     return os.path.join(os.environ.get("TMPDIR", "/tmp"), "clothhip_rccl_%s.id" % key)
 
 
+_MAGIC = b"CLTHRCCL"
+_generation = {}                   # rendezvous path -> communicators created on it by this process so far
+
+
+def _nonce(path, world):
+    """16 bytes every rank of ONE communicator derives identically and no other communicator shares: the launcher's random
+    CLOTHHIP_RDZV_NONCE (bench.py's own launcher) or the launcher-wide key of rendezvous_path(), plus how many communicators
+    this process has already built on that path (ranks build them in the same order)."""
+    import hashlib
+    gen = _generation.get(path, 0)
+    _generation[path] = gen + 1
+    base = os.environ.get("CLOTHHIP_RDZV_NONCE") or "%s|%s|%s" % (os.environ.get("MASTER_ADDR", ""), os.environ.get("MASTER_PORT", ""),
+                                                                 os.environ.get("TORCHELASTIC_RUN_ID", ""))
+    return hashlib.sha256(("%s|%s|%d|%d" % (base, path, int(world), gen)).encode()).digest()[:16]
+
+
 def exchange_unique_id(rank, world, path=None, timeout_s=300.0):
-    """rank 0 creates the id and publishes it atomically (write + rename); the others poll for the file."""
+    """rank 0 creates the id and publishes it atomically (exclusive temp file + rename) behind a header of
+    (magic, nonce, world); the others poll for a file that carries THEIR nonce -- a file left by a crashed run or by the previous
+    communicator on the same path is ignored (and replaced by rank 0)."""
     L = load()
     path = path or rendezvous_path()
+    nonce = _nonce(path, world)
+    head = _MAGIC + nonce + int(world).to_bytes(4, "little")
     uid = _UniqueId()
     if rank == 0:
         _check(L.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        try:
+            os.remove(path)                                   # whatever an earlier run left there
+        except OSError:
+            pass
         tmp = "%s.tmp%d" % (path, os.getpid())
-        with open(tmp, "wb") as fh:
-            fh.write(bytes(uid.internal))
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+        with os.fdopen(fd, "wb") as fh:
+            fh.write(head + bytes(uid.internal))
         os.replace(tmp, path)
     else:
         t0 = time.time()
@@ -93,12 +118,13 @@ def exchange_unique_id(rank, world, path=None, timeout_s=300.0):
             try:
                 with open(path, "rb") as fh:
                     raw = fh.read()
-                if len(raw) == NCCL_UNIQUE_ID_BYTES:
+                if len(raw) == len(head) + NCCL_UNIQUE_ID_BYTES and raw[:len(head)] == head:
+                    raw = raw[len(head):]
                     break
             except OSError:
                 pass
             if time.time() - t0 > timeout_s:
-                raise RcclError("rank %d: no RCCL unique id at %s after %.0f s" % (rank, path, timeout_s))
+                raise RcclError("rank %d: no RCCL unique id for this communicator at %s after %.0f s" % (rank, path, timeout_s))
             time.sleep(0.01)
         C.memmove(C.byref(uid), raw, NCCL_UNIQUE_ID_BYTES)
     return uid, path

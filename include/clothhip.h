@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CLOTHHIP_ABI_VERSION 2
+#define CLOTHHIP_ABI_VERSION 3
 
 enum {
     CLOTHHIP_OK = 0,
@@ -275,6 +275,19 @@ int clothhip_run_actions_begin(clothhip_handle *h, const ClothEpisodeParams *ep,
                                int32_t want_resets, int32_t want_obs, int32_t want_reset_obs, double time_budget_ms);
 int clothhip_run_actions_end(clothhip_handle *h, int32_t *num_steps, uint8_t *done, ClothStepRecord *records,
                              ClothResetRecord *resets, float *obs, float *reset_obs, uint32_t *rng_states);
+/* Per-env summary of the last clothhip_run_actions launch, written by the kernel: summary[E][4] = {actions the env executed (slots with ran != 0),
+ * 1 if its episode is over, the coverage after its last action or reset of the launch (NaN: it did neither), the Cloth.update()
+ * calls of its actions}. `summary` (host, may be NULL) receives a copy; `d_summary` (may be NULL) receives the DEVICE address of the
+ * table, valid for the handle's life and ordered on the handle's stream: the multi-GPU driver all-gathers it in place
+ * (ncclAllGather) without staging through the host. Call after clothhip_run_actions_begin (the device address) or after _end (the
+ * copy). No reference counterpart. */
+int clothhip_run_actions_summary(clothhip_handle *h, double *summary, void **d_summary);
+/* Where the time of the last clothhip_run_actions launch went, per env: ticks[E][8] = 100 MHz ticks (s_memrealtime) the env's
+ * workgroup spent in {0: actions (ClothEnv.step incl. decode, grab_top, metrics), 1: scripted reset pulls (cloth_env.py:851-982) incl.
+ * the coverage test of tier 1's third pull, 2: reset settling (bare update() calls), 3: the rest (Cloth() rebuild, idling once its
+ * action slots are used up)}, then the Cloth.update() calls executed in each of the four classes. The benchmark derives the
+ * action-only rate of SURVEY 8d from it. Call after clothhip_run_actions / _end. No reference counterpart. */
+int clothhip_run_actions_op_ticks(clothhip_handle *h, uint64_t *ticks);
 /* 1 if this handle's kernel variant has the LDS room for the in-kernel metrics of clothhip_run_actions, else 0 */
 int clothhip_fused_supported(const clothhip_handle *h);
 int clothhip_run_actions(clothhip_handle *h, const ClothEpisodeParams *ep, int32_t T, int32_t policy,

@@ -99,3 +99,52 @@ def test_package_does_not_import_torch():
             "gym_cloth_amd.rccl, gym_cloth_amd.policies, gym_cloth_amd.physics; "
             "assert 'torch' not in sys.modules, 'torch was imported'" % ROOT)
     subprocess.check_call([sys.executable, "-c", code])
+
+
+def test_bench_self_launcher_two_ranks_dry_run():
+    """bench.py --gpus 2 without a launcher environment starts one fresh process per rank; --dry-run replaces the GPU work by a
+    stand-in, so this covers what a real 2-GPU run does around it: rank / world parsing from the environment the launcher
+    sets, the rendezvous file (magic + nonce + world header, private directory), the per-launch exchange pattern (rank-major
+    action blocks, summary all-gather, max / sum all-reduce) over the TCP transport, and the relay of rank 0's ONE JSON line."""
+    import json
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3", "--envs", "5"],
+                         capture_output=True, timeout=120, env={k: v for k, v in os.environ.items()
+                                                               if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert out.returncode == 0, out.stderr.decode()
+    lines = [l for l in out.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3
+    # every launch gathers 100 substeps per env of rank 0 and 200 per env of rank 1; rank 0 sums the gathered table itself
+    assert rec["config"]["gathered_substeps"] == 3 * (100.0 + 200.0) * 5
+
+
+def test_bench_self_launcher_returns_a_failing_ranks_code():
+    """A rank that dies must take the job down with a non-zero code instead of leaving the others waiting for it."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["CLOTH_BENCH_DRY_FAIL_RANK"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "2", "--envs", "4"],
+                         capture_output=True, timeout=120, env=env)
+    assert out.returncode != 0
+
+
+def test_rendezvous_file_ignores_stale_and_foreign_ids(tmp_path, monkeypatch):
+    """The unique id travels behind a (magic, nonce, world) header: a file left by an earlier communicator on the same path -- or
+    by a crashed run -- is not this communicator's and must be ignored by the polling ranks (a fast rank could pick
+    up the previous id and hang in ncclCommInitRank)."""
+    sys.path.insert(0, ROOT)
+    from gym_cloth_amd import rccl
+    path = str(tmp_path / "rccl.id")
+    monkeypatch.setenv("CLOTHHIP_RDZV_NONCE", "abc")
+    rccl._generation.pop(path, None)
+    n0 = rccl._nonce(path, 2)            # first communicator on the path
+    n1 = rccl._nonce(path, 2)            # second one: another nonce
+    assert n0 != n1 and len(n0) == 16
+    rccl._generation.pop(path, None)
+    assert rccl._nonce(path, 2) == n0    # what the other rank (same order of communicators) derives
+    assert rccl._nonce(path, 4) != n1    # world size is part of it
+    monkeypatch.setenv("CLOTHHIP_RDZV_NONCE", "xyz")
+    rccl._generation.pop(path, None)
+    assert rccl._nonce(path, 2) != n0    # another launch

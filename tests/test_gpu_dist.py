@@ -45,4 +45,28 @@ def test_rccl_single_rank_collectives(tmp_path):
     o2 = w.step_many(acts, auto_reset=False)
     assert np.array_equal(o1["rew"], o2["rew"]) and np.array_equal(o1["obs"], o2["obs"])
     v.batch.device_free(d)
+    # the bench's exchange of an episode launch: rank-major action blocks broadcast in place, the kernel's per-env summary
+    # all-gathered straight from the handle's device table
+    xv = StepExchange(4, tv)
+    blocks = np.random.RandomState(6).uniform(-1, 1, size=(1, 2, 4, 4))               # [world, slots, E, 4]
+    host_blk, d_blk = xv.broadcast_action_blocks(blocks, 2, v.batch)
+    assert host_blk is None and d_blk
+    o3 = v.step_many(n_actions=2, actions_device_ptr=d_blk, auto_reset=False)
+    o4 = w.step_many(blocks[0], auto_reset=False)
+    assert np.array_equal(o3["rew"], o4["rew"]) and np.array_equal(o3["actions"], o4["actions"])
+    summ = xv.gather_summary(v.batch)
+    assert summ.shape == (4, 4)
+    assert np.array_equal(summ[:, 0], o3["ran"].sum(axis=0)) and np.array_equal(summ[:, 1] != 0, v._ep_done)
+    assert np.array_equal(summ[:, 3], o3["executed"].sum(axis=0))
+    last = o3["actual_coverage"][-1]
+    ran_any = o3["ran"].any(axis=0)
+    assert np.array_equal(summ[ran_any, 2], last[ran_any])
+    # the same through the host transport (what world size 1 / the TCP transport use)
+    from gym_cloth_amd.dist import LocalTransport
+    xl = StepExchange(4, LocalTransport())
+    hb, db = xl.broadcast_action_blocks(blocks, 2)
+    assert db is None and np.array_equal(hb, blocks[0])
+    assert np.array_equal(xl.gather_summary(v.batch), summ, equal_nan=True)
+    tk, sb = v.batch.op_ticks()
+    assert tk.shape == (4, 4) and sb[:, 0].sum() == o3["executed"].sum() and tk[:, 0].sum() > 0
     tv.close(); t.close(); b.close(); v.close(); w.close()

@@ -201,6 +201,49 @@ def test_in_flight_operations_are_dropped_by_outside_state_changes():
     a.close(); b.close()
 
 
+def test_masked_host_reset_keeps_the_other_envs_in_flight_operations_f64():
+    """A time slice parks the running operation of every env inside the handle. A host-side reset of SOME envs
+    (ClothVecEnv.reset(mask)) voids the parked operations of those envs only: the others continue theirs in the next launch
+    exactly as if nothing had happened in between (their rewards / executed counts equal an undisturbed run's), and the reset
+    envs restart from their new episode like envs that were reset between two whole launches."""
+    E, N = 6, 3
+    acts = np.stack([np.random.RandomState(2000 + e).uniform(-0.6, 0.6, size=(N, 4)) for e in range(E)], axis=1)   # [N, E, 4]
+    mask = np.array([True, False, True, False, False, True])
+
+    def collect(out, got):
+        for e in range(E):
+            n_e = int(out["ran"][:, e].sum())
+            got[e] += [(out["rew"][t, e], bool(out["done"][t, e]), int(out["executed"][t, e])) for t in range(n_e)]
+        return out["ran"].sum(axis=0)
+
+    # undisturbed reference for the envs that are NOT reset: one launch over the whole sequence
+    ref = _bench_env(E, "f64"); ref.reset()
+    r = ref.step_many(acts, auto_reset=False)
+    # a: sliced launch (cuts every env's first action), masked host reset, then launches until every env is through
+    a = _bench_env(E, "f64"); a.reset()
+    got = [[] for _ in range(E)]
+    cnt = collect(a.step_many(acts, auto_reset=False, time_budget_ms=8.0), got)
+    assert (cnt == 0).all(), "the slice must end inside the first action"
+    a.reset(mask=mask)
+    # b: the reset envs' reference -- same RNG consumption (two host resets of those envs), nothing in flight
+    b = _bench_env(E, "f64"); b.reset(); b.reset(mask=mask)
+    rb = b.step_many(acts, auto_reset=False)
+    for _ in range(400):
+        idx = np.minimum(cnt[None, :] + np.arange(N)[:, None], N - 1)
+        tbl = acts[idx, np.arange(E)[None, :]]
+        live = (cnt < N) & ~a._ep_done                       # an env is through after N actions or at its episode's end
+        if not live.any():
+            break
+        a._ep_done = a._ep_done | ~live                      # envs that are through idle
+        cnt = cnt + collect(a.step_many(tbl, auto_reset=False, time_budget_ms=8.0), got)
+    for e in range(E):
+        src = rb if mask[e] else r
+        want = [(src["rew"][t, e], bool(src["done"][t, e]), int(src["executed"][t, e])) for t in range(N) if src["ran"][t, e]]
+        n = min(len(want), len(got[e]))
+        assert n >= 1 and got[e][:n] == want[:n], (e, bool(mask[e]), got[e][:n], want[:n])
+    ref.close(); a.close(); b.close()
+
+
 @pytest.mark.parametrize("tier,seed", [("tier1", 1337), ("tier1", 21), ("tier3", 1339), ("tier2", 1337), ("tier2", 1338)])
 def test_device_drawn_reset_equals_host_reset_f64(tier, seed, oracle_lib):
     """The reset the kernel draws from the env's numpy stream (MT19937 on the device, csrc/cloth_rng.hpp) equals
@@ -257,6 +300,33 @@ def test_demo_writer_device_equals_host_loop_f64(tmp_path):
             for od, oh in zip(ed["obs"], eh["obs"]):
                 assert np.array_equal(od, oh.astype(np.float32))
             assert ed["info"] == eh["info"]
+            compared += 1
+    assert compared >= 3
+    a.close(); b.close()
+
+
+def test_demo_writer_with_time_slices_equals_unsliced_f64():
+    """collect_demos over time-sliced launches: a slice may end right after a completed reset, so that no action of that launch
+    carries the reset mark; the writer must still open a new episode there. The episodes equal those of unsliced launches."""
+    from gym_cloth_amd.demos import collect_demos
+    from gym_cloth_amd.envs import ClothVecEnv
+
+    def make():
+        v = ClothVecEnv(base_cfg("tier1", 1337), n_envs=3, precision="f64", consume_domrand_draws=False)
+        v.seed([1337, 1338, 1339])
+        return v
+    a, b = make(), make()
+    whole = collect_demos(a, "oracle_corner", max_episodes=6, slots_per_launch=6)
+    sliced = collect_demos(b, "oracle_corner", max_episodes=6, slots_per_launch=6, time_budget_ms=20.0)
+    by_env = lambda eps: {e: [ep for ep in eps if ep["env"] == e] for e in range(3)}
+    w, s_ = by_env(whole), by_env(sliced)
+    compared = 0
+    for e in range(3):
+        for ew, es in zip(w[e], s_[e]):
+            assert ew["act"] == es["act"] and ew["rew"] == es["rew"] and ew["done"] == es["done"], e
+            assert len(es["obs"]) == len(es["act"]) + 1
+            for ow, os_ in zip(ew["obs"], es["obs"]):
+                assert np.array_equal(ow, os_)
             compared += 1
     assert compared >= 3
     a.close(); b.close()
