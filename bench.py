@@ -309,6 +309,29 @@ def run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, rank
     return rec
 
 
+def render_bench(E, local_rank, size=224, reps=3):
+    """Companion record for the headless rasteriser: RGB (+ depth) images per second of E crumpled 25x25 cloths
+    at size x size, wall time of ClothBatch.render incl. the download of the images (what an image-observation env pays)."""
+    from gym_cloth_amd.envs import ClothVecEnv
+    env = ClothVecEnv(bench_cfg(25, 0.02), n_envs=E, device=local_rank, precision="f32", consume_domrand_draws=False)
+    for e in range(E):
+        env.np_randoms[e] = np.random.RandomState(1000 + e)
+    env.reset()                                               # the reset pulls leave every cloth folded somewhere
+    rec = {}
+    for label, kw in (("rgb", dict(want_rgb=True, want_depth=False)), ("rgbd", dict(want_rgb=True, want_depth=True))):
+        env.batch.render(width=size, height=size, **kw)      # warm-up (allocations)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            env.batch.render(width=size, height=size, **kw)
+        dt = (time.perf_counter() - t0) / reps
+        rec[label + "_images_per_s"] = E / dt
+        rec[label + "_ms_per_batch"] = dt * 1e3
+    env.close()
+    rec.update({"value": rec["rgb_images_per_s"], "unit": "images/s", "dtype": "f32",
+                "config": {"workload": "%d cloths of 25x25 (tier-1 post-reset states), %dx%d RGB images, k_render + download" % (E, size, size)}})
+    return rec
+
+
 def self_launch(args):
     """--gpus N without a launcher environment: start one child process per GPU (fresh processes: nothing in THIS process
     has touched the GPU, and no process is ever replaced by exec), relay rank 0's JSON line. All children are supervised: when one
@@ -492,6 +515,14 @@ def main():
             companion("BASELINE configs[4]: 50x50 x 1024 cloths, thickness 0.0095", n_side=50, E=1024,
                       precision=args.precision, init="tier1", mode="fused", steps=5, warmup=0, fuse_max=5, step_ms=2400.0,
                       want_cpu=not args.no_cpu_baseline, **k5)
+        if args.n_side == 25:
+            t0 = time.perf_counter()
+            try:
+                r = render_bench(args.envs, local_rank)
+            except Exception as exc:
+                r = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            r["label"], r["wall_s"] = "headless rasteriser (SURVEY 8f-f4): image observations of the whole batch", time.perf_counter() - t0
+            extra.append(r)
     if rank == 0:
         out = {
             "metric": "cloth substeps/sec (25x25 grid, batched envs)" if args.n_side == 25 else

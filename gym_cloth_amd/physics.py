@@ -57,6 +57,14 @@ class Point(object):
         return "({:.3f}, {:.3f}, {:.3f})".format(self.x, self.y, self.z)     # point.pyx:53-55
 
 
+class Spring(object):
+    """cloth.pyx:411-417 (read-only view: the device holds the rest lengths)."""
+    __slots__ = ("ptA", "ptB", "type", "rest_length")
+
+    def __init__(self, ptA, ptB, springtype, rest_length):
+        self.ptA, self.ptB, self.type, self.rest_length = ptA, ptB, springtype, rest_length
+
+
 class _Mirror(object):
     __slots__ = ("pos", "prev", "pinned")
 
@@ -163,6 +171,48 @@ class Cloth(object):
     def pinnedpts_arr(self):
         h = self._host()
         return h.pos[h.pinned.astype(bool)].copy()
+
+    # the debugging colour set (cloth.pyx:147-164: chosen from the INITIAL positions by the cfg's color_pts rule)
+    def _color_mask(self):
+        if getattr(self, "_cmask", None) is None:
+            rule = self.params['cloth'].get('color_pts', 'None')
+            x, y = self._orig[:, 0], self._orig[:, 1]
+            if rule == 'None':
+                m = np.zeros(len(x), dtype=bool)
+            elif rule == 'circle0':
+                m = np.abs((x - 1.0) ** 2 + (y - 1.0) ** 2 - 0.05 ** 2) < 0.10
+            elif rule == 'diag0':
+                m = np.abs(x - y) < 0.05
+            elif rule == 'diag1':
+                m = np.abs((1.0 - x) - y) < 0.05
+            else:
+                raise ValueError(rule)                                                   # cloth.pyx:161
+            self._cmask = m
+        return self._cmask
+
+    @property
+    def color_pts(self):
+        """cloth.pyx:164: a set of Points."""
+        return set(p for p, c in zip(self._pts, self._color_mask()) if c)
+
+    @property
+    def noncolorpts_arr(self):
+        return self._host().pos[~self._color_mask()].copy()                              # cloth.pyx:398-400
+
+    @property
+    def colorpts_arr(self):
+        return self._host().pos[self._color_mask()].copy()                               # cloth.pyx:402-404 (index order here)
+
+    @property
+    def springs(self):
+        """cloth.pyx:134-146 / :411-417: the spring list in reference order, each with ptA, ptB, type, rest_length."""
+        if getattr(self, "_springs", None) is None:
+            a, b, t = self.batch.topology()
+            rest = self.batch.get_rest(self.env, 1)[0]
+            names = ("STRUCTURAL", "SHEARING", "BENDING")
+            self._springs = [Spring(self._pts[int(a[s])], self._pts[int(b[s])], names[int(t[s])], float(rest[s]))
+                             for s in range(len(a))]
+        return self._springs
 
     def stop_render(self):
         pass

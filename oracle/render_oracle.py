@@ -15,6 +15,20 @@ def _q8(v):
     return (v * F(255.0) + F(0.5)).astype(np.uint32)          # truncation, as the (uint32_t) cast
 
 
+def faces(n_side):
+    """The triangle list of the cloth mesh, in the order and with the winding the reference exports to Blender
+    (gym_cloth/envs/cloth_env.py:224-229): per grid cell pp = r*N + c the two triangles [pp, pp+N, pp+1], [pp+1, pp+N, pp+N+1];
+    vertex i = particle i. render() below rasterises exactly this list (tests pin it to the reference's captured export)."""
+    N = int(n_side)
+    out = []
+    for r in range(N - 1):
+        for c in range(N - 1):
+            pp = r * N + c
+            out.append((pp, pp + N, pp + 1))
+            out.append((pp + 1, pp + N, pp + N + 1))
+    return out
+
+
 def render(pos, n_side, width, height, cam_pos, world_to_cam, lens_mm, sensor_mm, front, back, background, light_dir, ambient,
            energy, swap=False):
     """pos [P, 3] (any float type; converted to float32 as the kernel does) -> (rgb uint8 [H, W, 3], depth float32 [H, W])."""
@@ -33,6 +47,7 @@ def render(pos, n_side, width, height, cam_pos, world_to_cam, lens_mm, sensor_mm
     ds = np.where(d > F(1e-6), d, F(1e-6))
     vx = (fx * xc) / ds + cx
     vy = cy - (fy * yc) / ds
+    tri = faces(N)
     # vertex normals: incident faces in the kernel's order
     nrm = np.zeros((P, 3), dtype=F)
     for i in range(P):
@@ -43,7 +58,7 @@ def render(pos, n_side, width, height, cam_pos, world_to_cam, lens_mm, sensor_mm
                 if qr < 0 or qc < 0 or qr >= N - 1 or qc >= N - 1:
                     continue
                 pp = qr * N + qc
-                for f in ((pp, pp + N, pp + 1), (pp + 1, pp + N, pp + N + 1)):
+                for f in (tri[2 * (qr * (N - 1) + qc)], tri[2 * (qr * (N - 1) + qc) + 1]):
                     if i not in f:
                         continue
                     a, b, cc = f
@@ -59,10 +74,7 @@ def render(pos, n_side, width, height, cam_pos, world_to_cam, lens_mm, sensor_mm
     bgkey = np.uint64((int(_q8(bg[0])) << 16) | (int(_q8(bg[1])) << 8) | int(_q8(bg[2])))      # depth key 0: behind everything
     zb = np.full((H, W), bgkey, dtype=np.uint64)
     for t in range(2 * (N - 1) * (N - 1)):
-        q = t >> 1
-        qr, qc = divmod(q, N - 1)
-        pp = qr * N + qc
-        a, b, c = ((pp + 1, pp + N, pp + N + 1) if (t & 1) else (pp, pp + N, pp + 1))
+        a, b, c = tri[t]
         x0, y0, x1, y1, x2, y2 = vx[a], vy[a], vx[b], vy[b], vx[c], vy[c]
         if not (d[a] > F(1e-6) and d[b] > F(1e-6) and d[c] > F(1e-6)):
             continue

@@ -601,6 +601,177 @@ def env_fixture(tier, seed, episode, name):
     return env
 
 
+
+def _load_analytic():
+    spec = importlib.util.spec_from_file_location("ref_analytic", os.path.join(REF, "examples", "analytic.py"))
+    mod = importlib.util.module_from_spec(spec)
+    with contextlib.redirect_stdout(io.StringIO()):
+        spec.loader.exec_module(mod)
+    return mod
+
+
+def episodes_fixture(tier, seed, n_episodes, max_actions_total, name):
+    """The reference's data-collection loop (examples/analytic.py:866-882: reset, step until done, reset again ...) with RANDOM
+    clip-space actions from RandomState(seed + 5000) -- whole episodes incl. the reset that follows an episode's end, so that a
+    replay through the fused episode launch (which draws that reset from the env's RandomState on the device) is pinned to the
+    reference directly, not to this repository's own sequential path."""
+    t0 = time.time()
+    env, cfg = make_env(tier, seed)
+    np.random.seed(seed)
+    rs = np.random.RandomState(seed + 5000)
+    acts, rews, dones, infos, n_updates, reset_before = [], [], [], [], [], []
+    reset_cov, reset_obs = [], []
+    n_ep = 0
+    obs = env.reset()
+    reset_cov.append(float(env._start_coverage)); reset_obs.append(np.asarray(obs, dtype=np.float64))
+    pending_reset = 1
+    while n_ep < n_episodes and len(acts) < max_actions_total:
+        a = rs.uniform(-1, 1, size=4)
+        it0 = env.cloth.iter
+        obs, rew, done, info = env.step(a)
+        acts.append(a); rews.append(float(rew)); dones.append(bool(done)); n_updates.append(env.cloth.iter - it0)
+        infos.append({k: (float(v) if not isinstance(v, (bool, np.bool_)) else bool(v)) for k, v in info.items()})
+        reset_before.append(pending_reset); pending_reset = 0
+        if done:
+            n_ep += 1
+            if n_ep < n_episodes and len(acts) < max_actions_total:
+                obs = env.reset()
+                reset_cov.append(float(env._start_coverage)); reset_obs.append(np.asarray(obs, dtype=np.float64))
+                pending_reset = 1
+    pos, prev, pin = snap(env.cloth)
+    out = dict(cfg=physics_cfg_json(cfg), tier=tier, seed=np.int64(seed), act=np.array(acts), rew=np.array(rews),
+               done=np.array(dones, dtype=np.uint8), n_updates=np.array(n_updates, dtype=np.int64), info=json.dumps(infos),
+               reset_before=np.array(reset_before, dtype=np.uint8), reset_start_coverage=np.array(reset_cov),
+               reset_obs=np.stack(reset_obs), final_pos=pos, final_prev=prev, final_pinned=pin)
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **out)
+    print("wrote %s (%.1f KB; %d actions in %d episodes, %d resets) in %.0fs" %
+          (name, os.path.getsize(path) / 1024.0, len(acts), n_ep, len(reset_cov), time.time() - t0))
+
+
+def highest_point_fixture(name):
+    """examples/analytic.py's HighestPointPolicy.get_action (:792-808) under np.random.seed(k), k = 0..7 (so that every rank of its
+    randint(5) pick occurs), on a post-reset and on a post-action (folded, points in the air settled) state, tiers 1 and 2 with
+    both tier-2 sides. Stored: the state, the seeds and the actions."""
+    mod = _load_analytic()
+    out, t0 = {}, time.time()
+    cases = [("tier1", 1337), ("tier2", 1337), ("tier2", 1338)]
+    sides = []
+    for ci, (tier, seed) in enumerate(cases):
+        env, cfg = make_env(tier, seed)
+        np.random.seed(seed)
+        obs = env.reset()
+        pol = mod.HighestPointPolicy()
+        pol.set_env_cfg(env, cfg)
+        sides.append(int(bool(env.cloth.init_side)))
+        for si in range(2):
+            if si == 1:                                   # one real action first: a folded / crumpled state
+                with contextlib.redirect_stdout(io.StringIO()):
+                    np.random.seed(99)
+                    a = pol.get_action(obs, t=0)
+                obs, _, _, _ = env.step(a)
+            pos, prev, pin = snap(env.cloth)
+            acts = []
+            for k in range(8):
+                np.random.seed(k)
+                with contextlib.redirect_stdout(io.StringIO()):
+                    acts.append([float(v) for v in pol.get_action(obs, t=si)])
+            np.random.seed(0)
+            picks = [int(np.random.RandomState(k).randint(5)) for k in range(8)]     # what np.random.seed(k); randint(5) draws
+            out["c%d_s%d_pos" % (ci, si)] = pos
+            out["c%d_s%d_act" % (ci, si)] = np.array(acts)
+            out["c%d_s%d_pick" % (ci, si)] = np.array(picks, dtype=np.int64)
+    out["tiers"] = np.array([c[0] for c in cases]); out["seeds"] = np.array([c[1] for c in cases], dtype=np.int64)
+    out["init_side"] = np.array(sides, dtype=np.uint8)
+    out["cfg"] = physics_cfg_json(cfg)
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **out)
+    print("wrote %s (%.1f KB) in %.0fs" % (name, os.path.getsize(path) / 1024.0, time.time() - t0))
+
+
+def coverage_reward_fixture(name):
+    """reward_type 'coverage' (cloth_env.py:656-662: the non-delta reward) over a short tier-1 episode of random actions."""
+    import yaml
+    t0 = time.time()
+    cfg = load_cfg(25, tier="tier1")
+    cfg["seed"] = 1337
+    cfg["env"]["reward_type"] = "coverage"
+    path_cfg = os.path.join(SCRATCH, "cfg_covrew.yaml")
+    with open(path_cfg, "w") as fh:
+        yaml.safe_dump(cfg, fh)
+    with contextlib.redirect_stdout(io.StringIO()):
+        from gym_cloth.envs import ClothEnv
+    env = ClothEnv(path_cfg)
+    logging.getLogger().setLevel(logging.WARNING); env.logger.setLevel(logging.WARNING)
+    env.seed(1337); env._wd = env._hd = 224
+    np.random.seed(1337)
+    env.reset()
+    rs = np.random.RandomState(77)
+    acts, rews, dones, covs = [], [], [], []
+    done = False
+    while not done and len(acts) < 4:
+        a = rs.uniform(-0.8, 0.8, size=4)
+        _, rew, done, info = env.step(a)
+        acts.append(a); rews.append(float(rew)); dones.append(bool(done)); covs.append(float(info["actual_coverage"]))
+    np.savez_compressed(os.path.join(HERE, name), cfg=physics_cfg_json(cfg), act=np.array(acts), rew=np.array(rews),
+                        done=np.array(dones, dtype=np.uint8), coverage=np.array(covs))
+    print("wrote %s (%d actions) in %.0fs" % (name, len(acts), time.time() - t0))
+
+
+def mesh_fixture(name):
+    """What the reference hands to Blender for an image observation (cloth_env.py:212-276): the triangle mesh built from the
+    particles (vertex order, faces, winding) and the command line (init_side, tier, image size), captured with trimesh.Trimesh and
+    subprocess.call replaced by recorders; plus the numeric scene constants of the Blender script (camera pose and lens, the two
+    cloth colours) read out of gym_cloth/blender/get_image_rep_279.py at generation time. Two states: post-reset, post-action."""
+    import re
+    import subprocess as sp
+    import trimesh
+    t0 = time.time()
+    env, cfg = make_env("tier1", 1337)
+    np.random.seed(1337)
+    env.reset()
+    rec = {}
+
+    class _TM(object):
+        def __init__(self, vertices, faces):
+            rec["v"], rec["f"] = np.array(vertices, dtype=np.float64), np.array(faces, dtype=np.int64)
+
+        def export(self, path):
+            pass
+    trimesh.Trimesh = _TM
+    import gym_cloth.envs.cloth_env as ce
+    real_call = sp.call
+    ce.subprocess.call = lambda argv, *a, **k: rec.__setitem__("argv", list(argv)) or 0
+    ce.time.sleep = lambda *_: None
+    out = {}
+    try:
+        for si in range(2):
+            if si == 1:
+                env.step(np.array([-0.2, 0.1, 0.6, 0.5]))
+            try:
+                env.get_blender_rep("False")
+            except Exception:                              # no image comes back: everything of interest happened before
+                pass
+            out["s%d_vertices" % si], out["s%d_faces" % si] = rec["v"], rec["f"]
+            out["s%d_pos" % si] = snap(env.cloth)[0]
+            argv = rec["argv"]
+            k = argv.index("--")
+            out["s%d_argv" % si] = np.array([str(a) for a in argv[k + 2:k + 6]])        # height, width, init_side, init type
+    finally:
+        ce.subprocess.call = real_call
+    src = open(os.path.join(REF, "gym_cloth", "blender", "get_image_rep_279.py")).read()
+    num = lambda pat: float(re.search(pat, src).group(1))
+    out["camera_location"] = np.array([num(r"location\[0\] = ([0-9.]+)\s*\+ cp\[0\]"), num(r"location\[1\] = ([0-9.]+)\s*\+ cp\[1\]"),
+                                       num(r"location\[2\] = ([0-9.]+)\s*\+ cp\[2\]")])
+    out["camera_lens_mm"] = np.float64(num(r"data\.lens = ([0-9.]+)"))
+    out["camera_sensor_mm"] = np.float64(num(r"data\.sensor_width = ([0-9.]+)"))
+    m = re.search(r"else:\s*\n\s*b = np\.array\(\[([0-9., ]+)\]\)\s*\n\s*f = np\.array\(\[([0-9., ]+)\]\)", src)
+    out["color_back"] = np.array([float(v) for v in m.group(1).split(",")])
+    out["color_front"] = np.array([float(v) for v in m.group(2).split(",")])
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print("wrote %s (%d faces) in %.0fs" % (name, len(out["s0_faces"]), time.time() - t0))
+
+
 def metrics_fixture(states):
     """positions -> (coverage via scipy ConvexHull.volume, variance_inv, out_of_bounds) as the env computes them
     (cloth_env.py:1020-1098)."""
@@ -663,6 +834,16 @@ def main():
     if want("env3"):
         env_fixture("tier3", 1337, False, "g_env_tier3_1337.npz")
         env_fixture("tier3", 1339, False, "g_env_tier3_1339.npz")
+    if want("episodes1"):
+        episodes_fixture("tier1", 1337, 3, 12, "g_episodes_tier1_1337.npz")
+    if want("episodes3"):
+        episodes_fixture("tier3", 1339, 2, 8, "g_episodes_tier3_1339.npz")
+    if want("highest"):
+        highest_point_fixture("g_highest_point.npz")
+    if want("covrew"):
+        coverage_reward_fixture("g_coverage_reward.npz")
+    if want("mesh"):
+        mesh_fixture("g_mesh_export.npz")
 
 
 if __name__ == "__main__":

@@ -16,7 +16,7 @@ def _ocfg(cfg):
             "grip_radius": cfg["env"]["grip_radius"]}
 
 
-@pytest.mark.parametrize("tier,n_side,E,steps", [("tier2", 25, 16, 2), ("tier3", 25, 16, 2), ("tier1", 50, 6, 1)])
+@pytest.mark.parametrize("tier,n_side,E,steps", [("tier2", 25, 64, 2), ("tier3", 25, 16, 2), ("tier1", 50, 6, 1)])
 def test_env_steps_match_oracle_f64(tier, n_side, E, steps, oracle_lib):
     """bench.py's workload shape (reset drawn from RandomState(1000+e), random actions from RandomState(2000+e)) for the
     tiers and grid the headline run does not cover: after every env step every env is bit-identical to the oracle
@@ -95,3 +95,65 @@ def test_f32_outcome_distribution_vs_f64():
     assert np.median(dcov) < 0.02 and np.percentile(dcov, 90) < 0.1
     for v in envs.values():
         v.close()
+
+
+def test_f32_free_running_episode_outcomes_vs_f64():
+    """Long horizon, free running (SURVEY 7-H2 iii): 128 independently seeded envs run ONE WHOLE EPISODE each (up to max_actions = 10
+    random actions, never re-synchronised) in fp32 and in fp64 from the same seeds and action streams. Individual trajectories
+    decorrelate after the first action or two -- what must agree is the DISTRIBUTION of outcomes: episode length, how episodes end
+    (out of bounds / tear / coverage reached / action budget), final coverage. The first action, which both precisions start from
+    (nearly) the same state, must also agree env by env. With CLOTH_OUTCOME_REPORT=<path> the measured figures are written there
+    (profiles/r03_f32_outcomes.json is that file from the round's GPU run)."""
+    import json
+    import os
+    import bench
+    from gym_cloth_amd.envs import ClothVecEnv
+    E, T = 128, 10
+    cfg = bench.bench_cfg(25, 0.02)
+    acts = np.ascontiguousarray(np.stack([np.random.RandomState(2000 + e).uniform(-1, 1, size=(T, 4)) for e in range(E)], axis=1))
+    res = {}
+    for prec in ("f64", "f32"):
+        v = ClothVecEnv(cfg, n_envs=E, precision=prec, consume_domrand_draws=False)
+        for e in range(E):
+            v.np_randoms[e] = np.random.RandomState(1000 + e)
+        v.reset()
+        out = v.step_many(acts, auto_reset=False)
+        ran = out["ran"]
+        n = ran.sum(axis=0)                                        # episode length in actions
+        last = np.maximum(n - 1, 0)
+        idx = (last, np.arange(E))
+        cov = out["actual_coverage"][idx]
+        reason = np.where(out["have_tear"][idx], 1, np.where(out["out_of_bounds"][idx], 2, np.where(cov > 0.92, 3, 4)))
+        res[prec] = dict(n=n, cov=cov, reason=reason, first_done=out["done"][0].copy(), first_exec=out["executed"][0].copy(),
+                         first_cov=out["actual_coverage"][0].copy(), first_grab=(out["n_grabbed"][0] > 0).copy(),
+                         rew_sum=(out["rew"] * ran).sum(axis=0))
+        v.close()
+    a, b = res["f64"], res["f32"]
+    names = {1: "tear", 2: "out_of_bounds", 3: "coverage_reached", 4: "action_budget"}
+    freq = lambda r: {names[k]: float((r["reason"] == k).mean()) for k in names}
+    first_agree = float(((a["first_done"] == b["first_done"]) & (a["first_grab"] == b["first_grab"])).mean())
+    first_same_n = float((a["first_exec"] == b["first_exec"]).mean())
+    first_dcov = np.abs(a["first_cov"] - b["first_cov"])
+    rep = {"envs": E, "max_actions": T,
+           "first_action": {"outcome_agreement": first_agree, "same_substep_count": first_same_n,
+                            "abs_dcoverage_median": float(np.median(first_dcov)), "abs_dcoverage_p90": float(np.percentile(first_dcov, 90))},
+           "episode": {"same_length_frac": float((a["n"] == b["n"]).mean()), "same_end_reason_frac": float((a["reason"] == b["reason"]).mean()),
+                       "mean_length": {"f64": float(a["n"].mean()), "f32": float(b["n"].mean())},
+                       "end_reason_freq": {"f64": freq(a), "f32": freq(b)},
+                       "final_coverage_mean": {"f64": float(a["cov"].mean()), "f32": float(b["cov"].mean())},
+                       "final_coverage_quartiles": {"f64": np.percentile(a["cov"], [25, 50, 75]).tolist(),
+                                                    "f32": np.percentile(b["cov"], [25, 50, 75]).tolist()},
+                       "return_mean": {"f64": float(a["rew_sum"].mean()), "f32": float(b["rew_sum"].mean())},
+                       "abs_dfinal_coverage_median_per_env": float(np.median(np.abs(a["cov"] - b["cov"])))}}
+    print("\n" + json.dumps(rep, indent=1))
+    path = os.environ.get("CLOTH_OUTCOME_REPORT")
+    if path:
+        with open(path, "w") as fh:
+            json.dump(rep, fh, indent=1)
+    assert first_agree >= 0.90 and first_same_n >= 0.85 and np.median(first_dcov) < 0.02
+    assert abs(a["n"].mean() - b["n"].mean()) < 0.5                                   # episode length distribution
+    fa, fb = freq(a), freq(b)
+    assert max(abs(fa[k] - fb[k]) for k in fa) < 0.10                                 # how episodes end
+    assert abs(a["cov"].mean() - b["cov"].mean()) < 0.03                              # where they end
+    qa, qb = np.percentile(a["cov"], [25, 50, 75]), np.percentile(b["cov"], [25, 50, 75])
+    assert np.abs(qa - qb).max() < 0.06

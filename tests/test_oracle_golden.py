@@ -134,3 +134,26 @@ def test_initial_grid_matches_reference(name, oracle_lib):
     tier = {"tier1": 1, "tier2": 2, "tier3": 3}[str(g["tier"])]
     c.init_grid(tier, init_side, rng.rand(c.P) if tier == 2 else None)
     assert np.array_equal(c.get_state()[0], g["init_pos"]) and np.array_equal(c.rest, g["rest"])
+
+
+def test_render_mesh_and_scene_constants_match_the_reference_export(oracle_lib):
+    """What the reference hands to Blender for an image observation (cloth_env.py:212-276), captured by make_golden.py with
+    trimesh / subprocess replaced by recorders: vertex i = particle i, the face list with its winding, the command line; and the
+    numeric scene constants of get_image_rep_279.py. The rasteriser's oracle walks exactly that face list (render_oracle.faces)
+    and the package's default scene equals those constants -- this is the reference-derived pin of SURVEY 8f-f4 (the pixels
+    themselves are Blender's and are not reproduced)."""
+    from oracle import render_oracle
+    from gym_cloth_amd.batch import ClothBatch
+    g = oracle_lib.load_golden("g_mesh_export.npz")
+    for s in ("s0", "s1"):
+        assert np.array_equal(g[s + "_vertices"], g[s + "_pos"])                 # vertices are the particles in index order
+        assert np.array_equal(np.array(render_oracle.faces(25)), g[s + "_faces"])
+        assert [str(v) for v in g[s + "_argv"]] == ["224", "224", "1", "tier1"]     # height, width, init_side (+1: True), tier
+    # on the flat post-reset cloth every exported triangle faces the camera above it (+z): the FRONT colour is what it sees
+    v, f = g["s0_vertices"], g["s0_faces"]
+    nz = np.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]])[:, 2]
+    assert (nz > 0).mean() > 0.8                       # (the reset pulls have folded a part of it over)
+    d = ClothBatch.RENDER_DEFAULTS
+    assert tuple(d["cam_pos"]) == tuple(g["camera_location"]) and d["lens_mm"] == float(g["camera_lens_mm"])
+    assert d["sensor_mm"] == float(g["camera_sensor_mm"])
+    assert np.allclose(d["front"], g["color_front"], atol=0) and np.allclose(d["back"], g["color_back"], atol=0)
