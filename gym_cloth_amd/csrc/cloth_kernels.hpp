@@ -282,7 +282,7 @@ struct LdsLayout {
 // last window that holds a spring of one of the two moved particles (the entry's static `reach`). Everything outside
 // [w0, w_end] provably evaluates to "no correction, no tear".
 // Entry stream: lane-private, coalesced, read PF windows ahead (LDS or, for the large grids, L2).
-template <typename T, bool LDS_TAB, bool TIMED, bool STATS>
+template <typename T, bool LDS_TAB, bool TIMED, bool STATS, bool TIC>
 __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const uint32_t *g_ent, const T *g_rest, int w0, int w_end,
                                             int nW, int rshift, const DevConsts<T> &k, int lane, int &st_windows, int &st_passes, int &st_commits,
                                             unsigned long long *tph) {
@@ -291,7 +291,8 @@ __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const
     int tear = 0;
     DevConsts<T> kl = k;                         // spring-test constants pinned in VGPRs
     asm volatile("" : "+v"(kl.c11), "+v"(kl.tear_thresh));
-    const bool tic = __builtin_amdgcn_readfirstlane(!(k.tear_thresh < k.c11) ? 1 : 0) != 0;   // tear implies stretch (the usual case)
+    constexpr bool tic = TIC;                    // tear_thresh >= 1.1: tear implies stretch (the usual case; the caller tests it once)
+    const T INF_ = sizeof(T) == 4 ? (T)__builtin_huge_valf() : (T)__builtin_huge_val();
     uint32_t eab[PF + 1]; T erest[PF + 1];
     auto load = [&](int wi, uint32_t &ab_, T &r_) {
         if (LDS_TAB) { const WEnt<T> e_ = wt[wi * 64 + lane]; ab_ = e_.ab; r_ = e_.rest; }
@@ -299,7 +300,13 @@ __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const
     };
 #pragma unroll
     for (int j = 0; j <= PF; j++) load(w0 + j, eab[j], erest[j]);
-    for (int w = w0; w <= w_end; w++) {
+    // Both loops are single-exit do-whiles with wave-uniform conditions (ballots), so they compile to plain scalar branches; the
+    // particle state carried from pass to pass is the six coordinates only (12-byte LDS reads / writes: the pin word never changes
+    // during a sweep and is read once per window).
+    struct __attribute__((aligned(16))) P3 { T x, y, z; };
+    int w = w0;
+    if (w > w_end) return tear;
+    do {
         const uint32_t ab = eab[0];
         const T rest = erest[0];
 #pragma unroll
@@ -307,27 +314,35 @@ __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const
         load(w + PF + 1, eab[PF], erest[PF]);
         const int a = (int)(ab & WT_IDX_MASK), b = (int)((ab >> WT_IDX_BITS) & WT_IDX_MASK);
         const uint32_t gid = (ab >> WT_GROUP_SHIFT) & 15u;
-        Pt<T> PA = cur[a], PB = cur[b];
-        const uint32_t ca = w_cnt(PA.w), cb = w_cnt(PB.w);          // pins do not change during a sweep
-        const bool both = (ca != 0) & (cb != 0);                    // skipped by the reference (:268)
+        P3 *const pa = reinterpret_cast<P3 *>(cur + a), *const pb = reinterpret_cast<P3 *>(cur + b);
+        T ax, ay, az, bx, by, bz;
+        uint32_t ca, cb;
+        {
+            const Pt<T> PA = cur[a], PB = cur[b];
+            ax = PA.x; ay = PA.y; az = PA.z; bx = PB.x; by = PB.y; bz = PB.z;
+            ca = w_cnt(PA.w); cb = w_cnt(PB.w);                     // pins do not change during a sweep
+        }
         const T t11 = rest * kl.c11;
+        // both ends pinned: skipped by the reference (:268) -- by a limit no length exceeds: ONE compare per pass then
+        const T tlim = ((ca != 0) & (cb != 0)) ? INF_ : t11;
         unsigned long long pend = ~0ull;                            // lanes whose group is not finished
         if (STATS) st_windows++;
-        for (;;) {
+        bool more;
+        do {
             unsigned long long td0 = 0;
             if (TIMED) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(td0)::"memory"); }
-            const T dx = PA.x - PB.x, dy = PA.y - PB.y, dz = PA.z - PB.z;
+            const T dx = ax - bx, dy = ay - by, dz = az - bz;
             const T len2 = sumsq<T>(dx, dy, dz);
             bool trig;
             T len;
             if constexpr (sizeof(T) == 4) {      // one v_sqrt: cheaper than a branch around it
                 len = dev_sqrt<T>(len2);                                        // :270
-                trig = !both && len > t11;                                      // :275
+                trig = len > tlim;                                              // :275
             } else {
                 trig = false; len = (T)0;
-                if (!both && (len2 > t11 * t11 * ((T)1 - filt_slack<T>()))) {
+                if (len2 > tlim * tlim * ((T)1 - filt_slack<T>())) {
                     len = dev_sqrt<T>(len2);
-                    trig = len > t11;
+                    trig = len > tlim;
                 }
             }
             const unsigned long long tb = ballot64(trig) & pend;
@@ -336,44 +351,45 @@ __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const
                 asm volatile("" ::: "memory");
                 const uint32_t gq = tb ? (uint32_t)__builtin_amdgcn_readlane((int)gid, __ffsll((long long)tb) - 1) : 16u;
                 const bool mine = ((pend >> lane) & 1ull) != 0ull && gid <= gq;
-                if (mine && !both && dev_sqrt<T>(len2) > rest * kl.tear_thresh) tear = 1;
+                if (mine && !((ca != 0) & (cb != 0)) && dev_sqrt<T>(len2) > rest * kl.tear_thresh) tear = 1;
             }
-            if (!tb) {
-                if (TIMED) { unsigned long long td1; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(td1)::"memory"); tph[10] += td1 - td0; tph[9] += 64; }
-                break;
-            }
-            const int fl = __ffsll((long long)tb) - 1;                          // first over-stretched spring in level order
-            const uint32_t abf = (uint32_t)__builtin_amdgcn_readlane((int)ab, fl);
-            const uint32_t g = (abf >> WT_GROUP_SHIFT) & 15u;
-            const int reach = w + ((int)(abf >> WT_REACH_SHIFT) << rshift);     // (rounded up to the reach unit: at most 2^rshift - 1
-            w_end = reach > w_end ? reach : w_end;                               //  empty padding windows behind the last one get walked)
-            if (STATS) st_commits++;
-            if (trig && gid == g) {
-                if (tic && len > rest * kl.tear_thresh) tear = 1;                   // :272
-                const T ux = dev_div<T>(dx, len), uy = dev_div<T>(dy, len), uz = dev_div<T>(dz, len);   // :276-278
-                const T extra = len - t11;                                          // :279
-                // A pinned: B += dir*extra ; B pinned: A -= dir*extra ; else A -= dir*(extra*0.5), B += dir*(extra*0.5)
-                // (extra * 1.0 == extra exactly, so one weighted form covers the three reference branches, :281-296)
-                uint32_t ca_ = ca, cb_ = cb;
-                asm volatile("" : "+v"(ca_), "+v"(cb_));      // computed here, not hoisted into every window's set-up
-                const T wa = ca_ != 0 ? (T)0 : (cb_ != 0 ? (T)1 : (T)0.5);
-                const T wb = cb_ != 0 ? (T)0 : (ca_ != 0 ? (T)1 : (T)0.5);
-                const T ea = extra * wa, eb = extra * wb;
-                // branch-free: a pinned end has weight 0 and x - u*0 == x exactly (u is finite: len > 0 here), so writing it
-                // back unchanged equals the reference's skipped assignment; the springs of a level share no particle, so
-                // nobody else writes these two records in this pass
-                cur[a] = Pt<T>{mad<T>(-ux, ea, PA.x), mad<T>(-uy, ea, PA.y), mad<T>(-uz, ea, PA.z), PA.w};
-                cur[b] = Pt<T>{mad<T>(ux, eb, PB.x), mad<T>(uy, eb, PB.y), mad<T>(uz, eb, PB.z), PB.w};
-            }
-            pend = ballot64(gid > g);
-            if (TIMED) { unsigned long long td1; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(td1)::"memory"); tph[11] += td1 - td0; }
-            if (!pend) break;
-            // same-wave LDS operations execute in program order: the reads below see the writes above without waiting for
-            // them; the barrier only pins the compiler's ordering
-            __builtin_amdgcn_wave_barrier();
-            PA = cur[a]; PB = cur[b];
-        }
-    }
+            more = false;
+            if (tb) {
+                const int fl = __ffsll((long long)tb) - 1;                      // first over-stretched spring in level order
+                const uint32_t abf = (uint32_t)__builtin_amdgcn_readlane((int)ab, fl);
+                const uint32_t g = (abf >> WT_GROUP_SHIFT) & 15u;
+                const int reach = w + ((int)(abf >> WT_REACH_SHIFT) << rshift); // (rounded up to the reach unit: at most 2^rshift - 1
+                w_end = reach > w_end ? reach : w_end;                           //  empty padding windows behind the last one get walked)
+                if (STATS) st_commits++;
+                if (trig && gid == g) {
+                    if (tic && len > rest * kl.tear_thresh) tear = 1;               // :272
+                    const T ux = dev_div<T>(dx, len), uy = dev_div<T>(dy, len), uz = dev_div<T>(dz, len);   // :276-278
+                    const T extra = len - t11;                                      // :279
+                    // A pinned: B += dir*extra ; B pinned: A -= dir*extra ; else A -= dir*(extra*0.5), B += dir*(extra*0.5)
+                    // (extra * 1.0 == extra exactly, so one weighted form covers the three reference branches, :281-296)
+                    const T wa = ca != 0 ? (T)0 : (cb != 0 ? (T)1 : (T)0.5);
+                    const T wb = cb != 0 ? (T)0 : (ca != 0 ? (T)1 : (T)0.5);
+                    const T ea = extra * wa, eb = extra * wb;
+                    // branch-free: a pinned end has weight 0 and x - u*0 == x exactly (u is finite: len > 0 here), so writing it
+                    // back unchanged equals the reference's skipped assignment; the springs of a level share no particle, so
+                    // nobody else writes these two records in this pass
+                    *pa = P3{mad<T>(-ux, ea, ax), mad<T>(-uy, ea, ay), mad<T>(-uz, ea, az)};
+                    *pb = P3{mad<T>(ux, eb, bx), mad<T>(uy, eb, by), mad<T>(uz, eb, bz)};
+                }
+                pend = ballot64(gid > g);
+                more = pend != 0ull;
+                if (TIMED) { unsigned long long td1; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(td1)::"memory"); tph[11] += td1 - td0; }
+                if (more) {
+                    // same-wave LDS operations execute in program order: the reads below see the writes above without waiting
+                    // for them; the barrier only pins the compiler's ordering
+                    __builtin_amdgcn_wave_barrier();
+                    const P3 na = *pa, nb = *pb;
+                    ax = na.x; ay = na.y; az = na.z; bx = nb.x; by = nb.y; bz = nb.z;
+                }
+            } else if (TIMED) { unsigned long long td1; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(td1)::"memory"); tph[10] += td1 - td0; tph[9] += 64; }
+        } while (more);
+        w++;
+    } while (w <= w_end);
     return tear;
 }
 
@@ -1710,8 +1726,12 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                 const int w0 = __builtin_amdgcn_readfirstlane(all_ ? 0 : (misc[10] >> 6));
                 const int w1 = __builtin_amdgcn_readfirstlane(all_ ? A.nW - 1 : (misc[11] >> 6));
                 st_sweeps++;
-                const int tear = strain_sweep<T, (TAB >= 1), SWEEP_TIMED, SWEEP_STATS>(cur, wtab, A.wt_ent, g_rest, w0, w1, A.nW, A.wt_rshift, k, lane, st_windows,
-                                                                          st_passes, st_commits, tph);
+                // tear_thresh >= 1.1 (every shipped configuration): only a stretching spring can tear, the test sits in the commit
+                const bool tic = __builtin_amdgcn_readfirstlane(!(k.tear_thresh < k.c11) ? 1 : 0) != 0;
+                const int tear = tic ? strain_sweep<T, (TAB >= 1), SWEEP_TIMED, SWEEP_STATS, true>(cur, wtab, A.wt_ent, g_rest, w0, w1, A.nW, A.wt_rshift, k,
+                                                                                                 lane, st_windows, st_passes, st_commits, tph)
+                                     : strain_sweep<T, (TAB >= 1), SWEEP_TIMED, SWEEP_STATS, false>(cur, wtab, A.wt_ent, g_rest, w0, w1, A.nW, A.wt_rshift, k,
+                                                                                                  lane, st_windows, st_passes, st_commits, tph);
                 if (__any(tear) && lane == 0) misc[0] = 1;
                 if (lane == 0) { misc[1] = 0; misc[10] = 0x7fffffff; misc[11] = -1; }
                 __builtin_amdgcn_s_setprio(0);
