@@ -207,7 +207,6 @@ def run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, rank
             streams = np.stack([np.random.RandomState(2000 + e).uniform(-1, 1, size=(n_stream, 4)) for e in range(world * E)])
             cnt = np.zeros(world * E, dtype=np.int64)
         device_xch = world > 1 and hasattr(transport, "broadcast_device")
-        warm_ms, warm_steps = 0.0, 0.0
         op_ticks = np.zeros(4)
         op_subs = np.zeros(4)
         for w in range(n_warm + n_timed):
@@ -222,9 +221,6 @@ def run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, rank
                 if want_cpu and rank == 0:
                     cpu_states = env.batch.get_state(0, min(E, 512))
                     cpu_acts = blk[0][:min(E, 512)].copy() if blk is not None else None
-                # the timed launches are sized from what the warm-up measured, so that the timed region covers `steps` env steps
-                if warm_steps > 0:
-                    slice_ms = fuse * (warm_ms / warm_steps)
                 fence()
                 t0 = time.perf_counter()
             out = env.step_many(blk, n_actions=slots, actions_device_ptr=d_blk, auto_reset=True, time_budget_ms=slice_ms,
@@ -234,9 +230,6 @@ def run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, rank
             assert np.array_equal(res[g0:g0 + E, 0].astype(np.int64), n_ran)            # the device's summary == the records
             if rank == 0:
                 cnt += res[:, 0].astype(np.int64)
-            if w < n_warm:
-                warm_ms += env.batch.last_kernel_ms
-                warm_steps += float(res[:, 0].sum()) / (world * E)
             if w >= n_warm:
                 a_sub = int(out["executed"].sum())
                 r_sub = int(out["reset_substeps"].sum()) + int(out.get("tail_reset_substeps", np.zeros(1)).sum())
@@ -307,6 +300,17 @@ def run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, rank
     xch.t.close()
     env.close()
     return rec
+
+
+def nominal_step_ms(default=88.0):
+    """How long one env step of the headline workload takes with the committed kernel: ms_per_step of profiles/r03_bench.json.
+    The fused launches are time slices of fuse x this, so that `--steps` env steps fall into the timed region."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_bench.json")) as fh:
+            d = json.load(fh)
+        return float((d.get("bench") or d.get("bench_traced"))["ms_per_step"])
+    except (OSError, ValueError, KeyError, TypeError):
+        return default
 
 
 def render_bench(E, local_rank, size=224, reps=3):
@@ -461,9 +465,10 @@ def main():
                     help="start state of every env (reset draws come from RandomState(1000+e))")
     ap.add_argument("--mode", default="fused", choices=["fused", "step"])
     ap.add_argument("--fuse", type=int, default=10, help="fused mode: nominal steps per launch; the timed region is steps // fuse launches")
-    ap.add_argument("--step-ms", type=float, default=170.0,
-                    help="fused mode: nominal duration of one step; a launch is a time slice of fuse * step_ms (scaled with the "
-                         "work per cloth-substep for other grids / precisions)")
+    ap.add_argument("--step-ms", type=float, default=None,
+                    help="fused mode: nominal duration of one env step; a launch is a time slice of fuse * step_ms, the same for the "
+                         "warm-up and the timed launches (default: ms_per_step of the committed headline run, profiles/r03_bench.json, so "
+                         "that the timed region covers --steps env steps; scaled for other grids / precisions)")
     ap.add_argument("--slots", type=int, default=0, help="fused mode: action slots per env and launch (0: 4 * fuse)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--allow-tcp-fallback", action="store_true",
@@ -472,6 +477,8 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the companion records (f64, step mode, tier-2, 50x50, 2048 cloths)")
     args = ap.parse_args()
 
+    if args.step_ms is None:
+        args.step_ms = nominal_step_ms()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
     from gym_cloth_amd.dist import env_from_launcher
@@ -499,7 +506,7 @@ def main():
         other = "f64" if args.precision == "f32" else "f32"
         companion("same workload, %s instantiation%s" % (other, " (bit-exact vs the reference)" if other == "f64" else ""),
                   n_side=args.n_side, E=args.envs, precision=other, init=args.init, mode=args.mode, steps=10, warmup=5,
-                  fuse_max=10, step_ms=args.step_ms * (1.5 if other == "f64" else 0.7), **k5)
+                  fuse_max=10, step_ms=args.step_ms * (1.8 if other == "f64" else 0.6), **k5)
         companion("same workload, the other execution mode", n_side=args.n_side, E=args.envs, precision=args.precision,
                   init=args.init, mode="step" if args.mode == "fused" else "fused", steps=10, warmup=5, fuse_max=10,
                   step_ms=args.step_ms, **k5)

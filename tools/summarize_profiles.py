@@ -50,36 +50,64 @@ def main():
     # PMC passes: sum per counter over the stepper dispatches, plus per-dispatch HBM traffic
     pmc = {"note": "rocprofv3 --pmc, one run per counter group (never combined with tracing); sums over the "
                    "k_run_schedule dispatches of the profiled command", "counters": {}, "per_dispatch": {}}
-    for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+
+    def per_dispatch(d):
+        c_ = db_of(d)
+        res = {}
+        if c_ is None:
+            return res
+        for name, in c_.execute("select distinct counter_name from counters_collection").fetchall():
+            res[name] = [r[0] for r in c_.execute("select sum(value) from counters_collection where counter_name=? and "
+                                                  "kernel_name like '%k_run_schedule%' group by dispatch_id order by dispatch_id", (name,))]
+        return res
+    for d in sorted(glob.glob(os.path.join(src, "pmc_*")) + glob.glob(os.path.join(src, "sq_*"))):
         if not os.path.isdir(d):
             continue
-        c = db_of(d)
-        if c is None:
-            continue
-        for name, in c.execute("select distinct counter_name from counters_collection").fetchall():
-            vals = [r[0] for r in c.execute("select sum(value) from counters_collection where counter_name=? and "
-                                            "kernel_name like '%k_run_schedule%' group by dispatch_id order by dispatch_id", (name,))]
+        for name, vals in per_dispatch(d).items():
             pmc["counters"][name] = float(sum(vals))
             if name in ("FETCH_SIZE", "WRITE_SIZE"):
                 pmc["per_dispatch"][name + "_KB"] = [round(v, 1) for v in vals]
+            if name == "TCC_EA0_RDREQ_sum":
+                pmc["per_dispatch"]["TCC_EA0_RDREQ_x64B_KB"] = [round(v * 64.0 / 1024.0, 1) for v in vals]
+    for d in sorted(glob.glob(os.path.join(src, "pmcrep*_FETCH_SIZE"))):            # repeated passes: is the fetch burst of one dispatch real?
+        v = per_dispatch(d).get("FETCH_SIZE")
+        if v:
+            pmc["per_dispatch"].setdefault("FETCH_SIZE_KB_repeats", []).append([round(x, 1) for x in v])
     json.dump(pmc, open(dst + "_pmc_summary.json", "w"), indent=1)
     # per-launch HBM traffic of the dominant kernel for bench.py's roofline.traffic: the timed launches are the last ones of
-    # the profiled command; FETCH_SIZE is doubled (gfx950: it tallies 128-byte requests at 64 bytes, MI355X_MICROARCH.md)
-    tb = out.get("bench_traced") or {}
-    nl = int(tb.get("roofline", {}).get("launches", 0) or 0)
-    fk, wk = pmc["per_dispatch"].get("FETCH_SIZE_KB"), pmc["per_dispatch"].get("WRITE_SIZE_KB")
-    if nl and fk and wk and len(fk) >= nl and len(wk) >= nl:
-        fetch = sum(fk[-nl:]) / nl * 1024.0
+    # the profiled command; FETCH_SIZE is doubled (gfx950: it tallies 128-byte requests at 64 bytes, MI355X_MICROARCH.md).
+    # One record per configuration bench.py reports a roofline for (keyed on mode, envs, grid, precision, init).
+    records = []
+
+    def traffic_record(prefix, out_json, command):
+        p_ = os.path.join(src, out_json)
+        if not os.path.exists(p_):
+            return
+        txt = [l for l in open(p_).read().splitlines() if l.startswith("{")]
+        if not txt:
+            return
+        tb = json.loads(txt[-1])
+        nl = int(tb.get("roofline", {}).get("launches", 0) or 0)
+        fk = per_dispatch(os.path.join(src, prefix + "FETCH_SIZE")).get("FETCH_SIZE")
+        wk = per_dispatch(os.path.join(src, prefix + "WRITE_SIZE")).get("WRITE_SIZE")
+        if not (nl and fk and wk and len(fk) >= nl and len(wk) >= nl):
+            return
+        fetch = sorted(fk[-nl:])[len(fk[-nl:]) // 2] * 1024.0 if nl > 2 else min(fk[-nl:]) * 1024.0   # (a burst dispatch is not the typical launch)
         write = sum(wk[-nl:]) / nl * 1024.0
         cfg = tb["config"]
-        rec = {"mode": "fused" if cfg["mode"].startswith("fused") else "step", "envs": cfg["envs_per_gpu"], "n_side": cfg["n_side"],
-               "precision": tb["dtype"], "fuse": None, "fetch_size_bytes_per_launch_raw": fetch, "write_size_bytes_per_launch": write,
-               "hbm_bytes_per_launch": 2.0 * fetch + write,
-               "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) -- python3 bench.py --no-extra --no-cpu-baseline",
-               "algorithmic_bytes_per_launch": tb["roofline"]["substeps_per_launch"] * tb["roofline"]["alg_bytes_per_substep"]}
-        json.dump({"records": [rec]}, open(os.path.join(os.path.dirname(dst) or ".", os.path.basename(dst).split("_")[0] + "_traffic.json"), "w"), indent=1)
+        records.append({"mode": "fused" if cfg["mode"].startswith("fused") else "step", "envs": cfg["envs_per_gpu"], "n_side": cfg["n_side"],
+                        "precision": tb["dtype"], "init": cfg["init"], "slice_ms": cfg.get("slice_ms"),
+                        "fetch_size_bytes_per_launch_raw": fetch, "fetch_size_kb_of_the_timed_launches": [round(x, 1) for x in fk[-nl:]],
+                        "write_size_bytes_per_launch": write, "hbm_bytes_per_launch": 2.0 * fetch + write, "command": command,
+                        "algorithmic_bytes_per_launch": tb["roofline"]["substeps_per_launch"] * tb["roofline"]["alg_bytes_per_substep"]})
+    traffic_record("pmc_", "pmc_FETCH_SIZE.out", "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) -- python3 bench.py --no-extra --no-cpu-baseline")
+    traffic_record("t2pmc_", "t2pmc_FETCH_SIZE.out", "... -- python3 bench.py --no-extra --no-cpu-baseline --init tier2 --steps 10")
+    traffic_record("n50pmc_", "n50pmc_FETCH_SIZE.out", "... -- python3 bench.py --no-extra --no-cpu-baseline --n-side 50 --envs 1024 --steps 5 --warmup 0 --fuse 5 --step-ms 2400")
+    if records:
+        json.dump({"records": records}, open(os.path.join(os.path.dirname(dst) or ".", os.path.basename(dst).split("_")[0] + "_traffic.json"), "w"), indent=1)
     for nm, to in (("phase_f32.txt", "_phase_profile_f32.txt"), ("phase_f64.txt", "_phase_profile_f64.txt"),
-                   ("fused_balance.txt", "_fused_balance.txt"), ("fused_phases.txt", "_fused_phases.txt")):
+                   ("fused_balance.txt", "_fused_balance.txt"), ("fused_phases.txt", "_fused_phases.txt"),
+                   ("fused_phases_f64.txt", "_fused_phases_f64.txt"), ("sweepstamps_f32.txt", "_sweepstamps_f32.txt")):
         p = os.path.join(src, nm)
         if os.path.exists(p):
             shutil.copy(p, dst + to)
