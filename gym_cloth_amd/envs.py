@@ -434,7 +434,8 @@ class ClothVecEnv(object):
         actions: float64[T, E, 4], or policy='oracle_corner' (examples/analytic.py's oracle, evaluated on the device)
         with n_actions=T, or policy='highest_point' (analytic.py:723-808 on the device) with n_actions=T and
         policy_choices int[T, E]: which of the highest points (0 = the highest; the reference draws randint(5)) the env
-        pulls in its t-th slot. With auto_reset=False an env whose episode ends idles for the rest of the launch (`ran` False). Up to `max_resets` (default T) resets per env and launch. The resets are drawn on the device from
+        pulls in its t-th slot. With auto_reset=False an env whose episode ends idles for the rest of the launch (`ran` False). Up to `max_resets` (default min(T, 255), the
+        launch's limit) resets per env and launch; an env that has used them idles until the launch ends. The resets are drawn on the device from
         each env's numpy RandomState stream (device_rng=True: the states are uploaded before and read back after the
         launch; csrc/cloth_rng.hpp reproduces numpy's MT19937 draws bit for bit; all three tiers, tier 2 rebuilding the
         env's noisy sheet and rest lengths in the kernel), or, with device_rng=False (tiers 1 and 3), pre-drawn
@@ -481,7 +482,9 @@ class ClothVecEnv(object):
         if not self._delta_actions:
             raise NotImplementedError("non-delta actions are decoded on the host only (cos/sin, cloth_env.py:452-453)")
         dev_reset = auto_reset and (self._init_type in ('tier1', 'tier3') or (self._init_type == 'tier2' and device_rng))
-        R = T if max_resets is None else int(max_resets)
+        R = min(T, 255) if max_resets is None else int(max_resets)      # clothhip_run_actions: n_scripts in [1, 255]
+        if dev_reset and not 1 <= R <= 255:
+            raise ValueError("max_resets must be in [1, 255] (got %d)" % R)
         use_rng = dev_reset and device_rng
         scripts = self._prepare_scripts(R) if (dev_reset and not use_rng) else None
         mt = gauss = None

@@ -69,10 +69,17 @@ def main():
                 pmc["per_dispatch"][name + "_KB"] = [round(v, 1) for v in vals]
             if name == "TCC_EA0_RDREQ_sum":
                 pmc["per_dispatch"]["TCC_EA0_RDREQ_x64B_KB"] = [round(v * 64.0 / 1024.0, 1) for v in vals]
-    for d in sorted(glob.glob(os.path.join(src, "pmcrep*_FETCH_SIZE"))):            # repeated passes: is the fetch burst of one dispatch real?
-        v = per_dispatch(d).get("FETCH_SIZE")
-        if v:
-            pmc["per_dispatch"].setdefault("FETCH_SIZE_KB_repeats", []).append([round(x, 1) for x in v])
+    # repeated passes: is the burst one dispatch shows now and then real? (it moves between dispatches and counters from pass to pass)
+    for cname in ("FETCH_SIZE", "WRITE_SIZE"):
+        for d in sorted(glob.glob(os.path.join(src, "pmcrep*_" + cname))):
+            v = per_dispatch(d).get(cname)
+            if v:
+                pmc["per_dispatch"].setdefault(cname + "_KB_repeats", []).append([round(x, 1) for x in v])
+    for d in sorted(glob.glob(os.path.join(src, "pmcx*_WRITE_SIZE_TCC_EA0_WRREQ_sum"))):      # both counters in ONE pass
+        r = per_dispatch(d)
+        if r.get("WRITE_SIZE") and r.get("TCC_EA0_WRREQ_sum"):
+            pmc["per_dispatch"].setdefault("same_pass_WRITE_SIZE_KB_and_WRREQ", []).append(
+                {"WRITE_SIZE_KB": [round(x, 1) for x in r["WRITE_SIZE"]], "TCC_EA0_WRREQ_sum": [round(x, 1) for x in r["TCC_EA0_WRREQ_sum"]]})
     json.dump(pmc, open(dst + "_pmc_summary.json", "w"), indent=1)
     # per-launch HBM traffic of the dominant kernel for bench.py's roofline.traffic: the timed launches are the last ones of
     # the profiled command; FETCH_SIZE is doubled (gfx950: it tallies 128-byte requests at 64 bytes, MI355X_MICROARCH.md).
@@ -92,13 +99,26 @@ def main():
         wk = per_dispatch(os.path.join(src, prefix + "WRITE_SIZE")).get("WRITE_SIZE")
         if not (nl and fk and wk and len(fk) >= nl and len(wk) >= nl):
             return
-        fetch = sorted(fk[-nl:])[len(fk[-nl:]) // 2] * 1024.0 if nl > 2 else min(fk[-nl:]) * 1024.0   # (a burst dispatch is not the typical launch)
-        write = sum(wk[-nl:]) / nl * 1024.0
+        # the timed launches of every pass of the counter, pooled; the per-launch figure is their (lower) median and a dispatch
+        # at more than twice the median is listed as an outlier (one dispatch of some passes shows a 10-14x burst in ONE counter,
+        # a different dispatch and counter each time, with unchanged duration: profiles/README.md)
+        def pooled(cname, first):
+            vals = list(first[-nl:])
+            if prefix == "pmc_":
+                for d in sorted(glob.glob(os.path.join(src, "pmcrep*_" + cname)) + glob.glob(os.path.join(src, "pmcx*_" + cname + "_*"))):
+                    v = per_dispatch(d).get(cname)
+                    if v and len(v) >= nl:
+                        vals += v[-nl:]
+            med = sorted(vals)[(len(vals) - 1) // 2]
+            return med * 1024.0, [round(x, 1) for x in vals], [round(x, 1) for x in vals if x > 2.0 * med]
+        fetch, f_all, f_out = pooled("FETCH_SIZE", fk)
+        write, w_all, w_out = pooled("WRITE_SIZE", wk)
         cfg = tb["config"]
         records.append({"mode": "fused" if cfg["mode"].startswith("fused") else "step", "envs": cfg["envs_per_gpu"], "n_side": cfg["n_side"],
                         "precision": tb["dtype"], "init": cfg["init"], "slice_ms": cfg.get("slice_ms"),
-                        "fetch_size_bytes_per_launch_raw": fetch, "fetch_size_kb_of_the_timed_launches": [round(x, 1) for x in fk[-nl:]],
-                        "write_size_bytes_per_launch": write, "hbm_bytes_per_launch": 2.0 * fetch + write, "command": command,
+                        "fetch_size_bytes_per_launch_raw": fetch, "fetch_size_kb_of_the_timed_launches": f_all, "fetch_outliers_kb": f_out,
+                        "write_size_bytes_per_launch": write, "write_size_kb_of_the_timed_launches": w_all, "write_outliers_kb": w_out,
+                        "estimator": "lower median over the timed launches of all passes of the counter", "hbm_bytes_per_launch": 2.0 * fetch + write, "command": command,
                         "algorithmic_bytes_per_launch": tb["roofline"]["substeps_per_launch"] * tb["roofline"]["alg_bytes_per_substep"]})
     traffic_record("pmc_", "pmc_FETCH_SIZE.out", "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) -- python3 bench.py --no-extra --no-cpu-baseline")
     traffic_record("t2pmc_", "t2pmc_FETCH_SIZE.out", "... -- python3 bench.py --no-extra --no-cpu-baseline --init tier2 --steps 10")
