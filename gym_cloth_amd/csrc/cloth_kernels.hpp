@@ -130,6 +130,7 @@ template <typename T> struct StepArgs {
     const ClothSchedule *sched;   // [E]
     const uint32_t *gather;  // [HK_SLOTS][Ppad]
     const uint32_t *wt_ent;  // [Spad] window table of the strain sweep (cloth_tables.hpp), Spad = (nW + padding windows) * 64
+    const unsigned long long *wt_dep;   // [Spad] per slot: the lanes of its window the spring transitively depends on
     int32_t nW, wt_rshift;   // windows that hold springs; unit (log2 windows) of the entries' reach field
     int32_t N, P, Ppad, S, Spad;
     int32_t HT, ht_bits;     // spatial hash table slots (power of two > P)
@@ -283,21 +284,26 @@ struct LdsLayout {
 // [w0, w_end] provably evaluates to "no correction, no tear".
 // Entry stream: lane-private, coalesced, read PF windows ahead (LDS or, for the large grids, L2).
 template <typename T, bool LDS_TAB, bool TIMED, bool STATS, bool TIC>
-__device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const uint32_t *g_ent, const T *g_rest, int w0, int w_end,
+__device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const uint32_t *g_ent, const T *g_rest,
+                                            const unsigned long long *g_dep, int w0, int w_end,
                                             int nW, int rshift, const DevConsts<T> &k, int lane, int &st_windows, int &st_passes, int &st_commits,
                                             unsigned long long *tph) {
-    constexpr int PF = LDS_TAB ? 1 : 3;
-    static_assert(PF + 1 <= WT_PAD_WINDOWS, "the table is padded by the read-ahead distance");
+    constexpr int PF = LDS_TAB ? 1 : 3;          // entry stream: windows read ahead
+    constexpr int PD = sizeof(T) == 4 ? 3 : 2;   // dependency words (always from L2 / L1: one table for all cloths)
+    static_assert(PF + 1 <= WT_PAD_WINDOWS && PD + 1 <= WT_PAD_WINDOWS, "the table is padded by the read-ahead distance");
     int tear = 0;
     DevConsts<T> kl = k;                         // spring-test constants pinned in VGPRs
     asm volatile("" : "+v"(kl.c11), "+v"(kl.tear_thresh));
     constexpr bool tic = TIC;                    // tear_thresh >= 1.1: tear implies stretch (the usual case; the caller tests it once)
     const T INF_ = sizeof(T) == 4 ? (T)__builtin_huge_valf() : (T)__builtin_huge_val();
     uint32_t eab[PF + 1]; T erest[PF + 1];
+    unsigned long long edep[PD + 1];
     auto load = [&](int wi, uint32_t &ab_, T &r_) {
         if (LDS_TAB) { const WEnt<T> e_ = wt[wi * 64 + lane]; ab_ = e_.ab; r_ = e_.rest; }
         else { ab_ = g_ent[wi * 64 + lane]; r_ = g_rest[wi * 64 + lane]; }
     };
+#pragma unroll
+    for (int j = 0; j <= PD; j++) edep[j] = g_dep[(w0 + j) * 64 + lane];
 #pragma unroll
     for (int j = 0; j <= PF; j++) load(w0 + j, eab[j], erest[j]);
     // Both loops are single-exit do-whiles with wave-uniform conditions (ballots), so they compile to plain scalar branches; the
@@ -306,26 +312,39 @@ __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const
     struct __attribute__((aligned(16))) P3 { T x, y, z; };
     int w = w0;
     if (w > w_end) return tear;
+    // fp32: the particle records of the NEXT window are read while this window's passes run; they are good unless this window
+    // corrected something (then they are read again): most windows of a walk correct nothing. (fp64: the sixteen registers
+    // this costs are spilled, measured -2 %; there the records are read when the window starts.)
+    constexpr bool NEXT_AHEAD = sizeof(T) == 4;
+    Pt<T> NA, NB;
+    {
+        const uint32_t ab0 = eab[0];
+        NA = cur[ab0 & WT_IDX_MASK]; NB = cur[(ab0 >> WT_IDX_BITS) & WT_IDX_MASK];
+    }
     do {
         const uint32_t ab = eab[0];
         const T rest = erest[0];
+        const unsigned long long dep = edep[0];
 #pragma unroll
         for (int j = 0; j < PF; j++) { eab[j] = eab[j + 1]; erest[j] = erest[j + 1]; }
+#pragma unroll
+        for (int j = 0; j < PD; j++) edep[j] = edep[j + 1];
         load(w + PF + 1, eab[PF], erest[PF]);
+        edep[PD] = g_dep[(w + PD + 1) * 64 + lane];
         const int a = (int)(ab & WT_IDX_MASK), b = (int)((ab >> WT_IDX_BITS) & WT_IDX_MASK);
-        const uint32_t gid = (ab >> WT_GROUP_SHIFT) & 15u;
         P3 *const pa = reinterpret_cast<P3 *>(cur + a), *const pb = reinterpret_cast<P3 *>(cur + b);
         T ax, ay, az, bx, by, bz;
         uint32_t ca, cb;
-        {
-            const Pt<T> PA = cur[a], PB = cur[b];
-            ax = PA.x; ay = PA.y; az = PA.z; bx = PB.x; by = PB.y; bz = PB.z;
-            ca = w_cnt(PA.w); cb = w_cnt(PB.w);                     // pins do not change during a sweep
-        }
+        ax = NA.x; ay = NA.y; az = NA.z; bx = NB.x; by = NB.y; bz = NB.z;
+        ca = w_cnt(NA.w); cb = w_cnt(NB.w);                         // pins do not change during a sweep
+        const int an = (int)(eab[0] & WT_IDX_MASK), bn = (int)((eab[0] >> WT_IDX_BITS) & WT_IDX_MASK);
+        if (NEXT_AHEAD) { NA = cur[an]; NB = cur[bn]; }
+        bool dirty = !NEXT_AHEAD;
         const T t11 = rest * kl.c11;
         // both ends pinned: skipped by the reference (:268) -- by a limit no length exceeds: ONE compare per pass then
         const T tlim = ((ca != 0) & (cb != 0)) ? INF_ : t11;
-        unsigned long long pend = ~0ull;                            // lanes whose group is not finished
+        const uint32_t dlo = (uint32_t)dep, dhi = (uint32_t)(dep >> 32);
+        bool pl = true;                                             // this lane's spring is not finished
         if (STATS) st_windows++;
         bool more;
         do {
@@ -345,23 +364,27 @@ __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const
                     trig = len > tlim;
                 }
             }
-            const unsigned long long tb = ballot64(trig) & pend;
+            // the over-stretched unfinished springs of the window, as this state shows them
+            const unsigned long long tb = ballot64(trig & pl);
             if (STATS) st_passes++;
+            // A spring is VALID when none of its (transitive) predecessors in the window is over-stretched now: then every
+            // predecessor that shares a particle with it leaves the particle alone, and the spring sees what the sequential sweep
+            // shows it. All valid springs are finished by this pass (the over-stretched ones corrected, all at once: two valid
+            // over-stretched springs share no particle, or the later one would not be valid); the others are evaluated again.
+            // The first over-stretched spring in table order is always valid.
+            const bool bad = ((dlo & (uint32_t)tb) | (dhi & (uint32_t)(tb >> 32))) != 0u;
             if (!tic) {          // tear_thresh < 1.1: a spring can tear without stretching, so every finished spring is tested (:272)
-                asm volatile("" ::: "memory");
-                const uint32_t gq = tb ? (uint32_t)__builtin_amdgcn_readlane((int)gid, __ffsll((long long)tb) - 1) : 16u;
-                const bool mine = ((pend >> lane) & 1ull) != 0ull && gid <= gq;
+                const bool mine = pl & !bad;
                 if (mine && !((ca != 0) & (cb != 0)) && dev_sqrt<T>(len2) > rest * kl.tear_thresh) tear = 1;
             }
             more = false;
             if (tb) {
-                const int fl = __ffsll((long long)tb) - 1;                      // first over-stretched spring in level order
-                const uint32_t abf = (uint32_t)__builtin_amdgcn_readlane((int)ab, fl);
-                const uint32_t g = (abf >> WT_GROUP_SHIFT) & 15u;
-                const int reach = w + ((int)(abf >> WT_REACH_SHIFT) << rshift); // (rounded up to the reach unit: at most 2^rshift - 1
-                w_end = reach > w_end ? reach : w_end;                           //  empty padding windows behind the last one get walked)
+                // every correction of the window may move particles whose springs sit as far as the window's reach
+                const int reach = w + ((int)((uint32_t)__builtin_amdgcn_readfirstlane((int)ab) >> WT_REACH_SHIFT) << rshift);
+                w_end = reach > w_end ? reach : w_end;
+                dirty = true;
                 if (STATS) st_commits++;
-                if (trig && gid == g) {
+                if (trig & pl & !bad) {
                     if (tic && len > rest * kl.tear_thresh) tear = 1;               // :272
                     const T ux = dev_div<T>(dx, len), uy = dev_div<T>(dy, len), uz = dev_div<T>(dz, len);   // :276-278
                     const T extra = len - t11;                                      // :279
@@ -371,13 +394,13 @@ __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const
                     const T wb = cb != 0 ? (T)0 : (ca != 0 ? (T)1 : (T)0.5);
                     const T ea = extra * wa, eb = extra * wb;
                     // branch-free: a pinned end has weight 0 and x - u*0 == x exactly (u is finite: len > 0 here), so writing it
-                    // back unchanged equals the reference's skipped assignment; the springs of a level share no particle, so
-                    // nobody else writes these two records in this pass
+                    // back unchanged equals the reference's skipped assignment; the springs corrected together share no
+                    // particle, so nobody else writes these two records in this pass
                     *pa = P3{mad<T>(-ux, ea, ax), mad<T>(-uy, ea, ay), mad<T>(-uz, ea, az)};
                     *pb = P3{mad<T>(ux, eb, bx), mad<T>(uy, eb, by), mad<T>(uz, eb, bz)};
                 }
-                pend = ballot64(gid > g);
-                more = pend != 0ull;
+                pl = pl & bad;
+                more = ballot64(pl) != 0ull;
                 if (TIMED) { unsigned long long td1; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(td1)::"memory"); tph[11] += td1 - td0; }
                 if (more) {
                     // same-wave LDS operations execute in program order: the reads below see the writes above without waiting
@@ -389,6 +412,7 @@ __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const
             } else if (TIMED) { unsigned long long td1; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(td1)::"memory"); tph[10] += td1 - td0; tph[9] += 64; }
         } while (more);
         w++;
+        if (dirty) { NA = cur[an]; NB = cur[bn]; }
     } while (w <= w_end);
     return tear;
 }
@@ -1728,9 +1752,9 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                 st_sweeps++;
                 // tear_thresh >= 1.1 (every shipped configuration): only a stretching spring can tear, the test sits in the commit
                 const bool tic = __builtin_amdgcn_readfirstlane(!(k.tear_thresh < k.c11) ? 1 : 0) != 0;
-                const int tear = tic ? strain_sweep<T, (TAB >= 1), SWEEP_TIMED, SWEEP_STATS, true>(cur, wtab, A.wt_ent, g_rest, w0, w1, A.nW, A.wt_rshift, k,
+                const int tear = tic ? strain_sweep<T, (TAB >= 1), SWEEP_TIMED, SWEEP_STATS, true>(cur, wtab, A.wt_ent, g_rest, A.wt_dep, w0, w1, A.nW, A.wt_rshift, k,
                                                                                                  lane, st_windows, st_passes, st_commits, tph)
-                                     : strain_sweep<T, (TAB >= 1), SWEEP_TIMED, SWEEP_STATS, false>(cur, wtab, A.wt_ent, g_rest, w0, w1, A.nW, A.wt_rshift, k,
+                                     : strain_sweep<T, (TAB >= 1), SWEEP_TIMED, SWEEP_STATS, false>(cur, wtab, A.wt_ent, g_rest, A.wt_dep, w0, w1, A.nW, A.wt_rshift, k,
                                                                                                   lane, st_windows, st_passes, st_commits, tph);
                 if (__any(tear) && lane == 0) misc[0] = 1;
                 if (lane == 0) { misc[1] = 0; misc[10] = 0x7fffffff; misc[11] = -1; }

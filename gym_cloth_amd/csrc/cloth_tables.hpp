@@ -113,6 +113,7 @@ struct WindowTable {
     int nW = 0, n_slots = 0;         // windows; slots incl. the padding windows
     int max_reach = 0, reach_shift = 0;
     std::vector<uint32_t> ent;       // [n_slots]
+    std::vector<uint64_t> dep;       // [n_slots] lanes of the SAME window (all earlier ones) the slot's spring transitively depends on
     std::vector<int32_t> slot_of;    // spring list index -> slot
     std::vector<int32_t> spring_at;  // slot -> spring list index, -1 empty
 };
@@ -143,12 +144,11 @@ inline WindowTable build_windows(const Topology &t, const LevelSchedule &L) {
         last_win[t.a[s]] = std::max(last_win[t.a[s]], ws);
         last_win[t.b[s]] = std::max(last_win[t.b[s]], ws);
     }
-    std::vector<int> greach((size_t)W.nW * WT_MAX_GROUPS, 0);     // per (window, group): the farthest reach of its springs
-    for (int s = 0; s < t.S; s++) {
+    std::vector<int> wreach((size_t)W.nW, 0);                     // per window: the farthest reach of its springs (a pass may commit
+    for (int s = 0; s < t.S; s++) {                               // springs of several groups at once)
         const int ws = W.slot_of[s] >> 6;
         const int r = std::max(last_win[t.a[s]], last_win[t.b[s]]) - ws;
-        int &g = greach[(size_t)ws * WT_MAX_GROUPS + group_of[s]];
-        g = std::max(g, r);
+        wreach[ws] = std::max(wreach[ws], r);
         W.max_reach = std::max(W.max_reach, r);
     }
     while (((W.max_reach + (1 << W.reach_shift) - 1) >> W.reach_shift) > WT_MAX_REACH) W.reach_shift++;
@@ -159,10 +159,33 @@ inline WindowTable build_windows(const Topology &t, const LevelSchedule &L) {
     W.spring_at.assign(W.n_slots, -1);
     for (int s = 0; s < t.S; s++) {
         const int i = W.slot_of[s], ws = i >> 6;
-        const int r = (greach[(size_t)ws * WT_MAX_GROUPS + group_of[s]] + (1 << W.reach_shift) - 1) >> W.reach_shift;
+        const int r = (wreach[ws] + (1 << W.reach_shift) - 1) >> W.reach_shift;
         W.ent[i] = (uint32_t)t.a[s] | ((uint32_t)t.b[s] << WT_IDX_BITS) | ((uint32_t)group_of[s] << WT_GROUP_SHIFT) |
                    ((uint32_t)r << WT_REACH_SHIFT);
         W.spring_at[i] = s;
+    }
+    // Dependencies inside a window: lane l depends on every earlier lane that shares a particle with it, transitively. A pass of
+    // the sweep commits every over-stretched spring none of whose (transitive) predecessors is over-stretched itself: those
+    // springs see exactly the state the sequential sweep shows them; everything behind an over-stretched spring is evaluated
+    // again by the next pass.
+    W.dep.assign(W.n_slots, 0ull);
+    {
+        std::vector<uint64_t> touch(t.P, 0ull);
+        std::vector<int> touched;
+        for (int ws = 0; ws < W.nW; ws++) {
+            touched.clear();
+            for (int l = 0; l < 64; l++) {
+                const int s = W.spring_at[ws * 64 + l];
+                if (s < 0) continue;
+                const uint64_t direct = touch[t.a[s]] | touch[t.b[s]];
+                uint64_t all = direct;
+                for (uint64_t m = direct; m; m &= m - 1) all |= W.dep[ws * 64 + __builtin_ctzll(m)];
+                W.dep[ws * 64 + l] = all;
+                touch[t.a[s]] |= 1ull << l; touch[t.b[s]] |= 1ull << l;
+                touched.push_back(t.a[s]); touched.push_back(t.b[s]);
+            }
+            for (int p : touched) touch[p] = 0ull;
+        }
     }
     return W;
 }
