@@ -372,7 +372,8 @@ __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const
             // shows it. All valid springs are finished by this pass (the over-stretched ones corrected, all at once: two valid
             // over-stretched springs share no particle, or the later one would not be valid); the others are evaluated again.
             // The first over-stretched spring in table order is always valid.
-            const bool bad = ((dlo & (uint32_t)tb) | (dhi & (uint32_t)(tb >> 32))) != 0u;
+            bool bad = false;
+            if (tb) bad = ((dlo & (uint32_t)tb) | (dhi & (uint32_t)(tb >> 32))) != 0u;      // (a quiet pass skips this)
             if (!tic) {          // tear_thresh < 1.1: a spring can tear without stretching, so every finished spring is tested (:272)
                 const bool mine = pl & !bad;
                 if (mine && !((ca != 0) & (cb != 0)) && dev_sqrt<T>(len2) > rest * kl.tear_thresh) tear = 1;

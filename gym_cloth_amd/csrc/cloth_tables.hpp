@@ -11,7 +11,8 @@
 //     spring touching either endpoint)); springs inside a level share no endpoint, and executing the
 //     levels in order reproduces the sequential sweep exactly.  Consecutive
 //     levels are packed into WINDOWS of 64 slots -- one slot per lane of the wave that walks the sweep --
-//     so that lane order == level order inside a window.
+//     so that lane order == level order inside a window; per slot the set of earlier lanes of its window the spring
+//     depends on (shares a particle with, transitively) lets one pass of the sweep finish several levels at once.
 #pragma once
 
 #include <algorithm>
@@ -99,10 +100,12 @@ inline LevelSchedule build_levels(const Topology &t) {
 // Window table of the strain-limit sweep. Slot i = window (i >> 6), lane (i & 63). Entry (0 = empty slot, ptA == ptB == 0,
 // which can never stretch):
 //   bits  0..11  ptA           bits 12..23  ptB
-//   bits 24..27  group: which of the window's levels (<= 16, in order) the spring belongs to
-//   bits 28..31  reach: how many windows past its own the last spring incident to ptA or ptB sits, in units of
-//                2^reach_shift windows, rounded up (the maximum over the springs of the group, so that any lane of a group
-//                can speak for it); a correction of this spring cannot influence anything behind that window
+//   bits 24..27  which of the window's levels (in order, saturating at 15) the spring belongs to (informative)
+//   bits 28..31  reach: how many windows past its own the last spring incident to a particle of THIS WINDOW's springs sits, in
+//                units of 2^reach_shift windows, rounded up (the same value in every entry of a window: a pass may correct
+//                springs of several levels at once); no correction made in this window can influence anything behind that window
+// Beside it, per slot, `dep`: the lanes of the same window whose springs this one depends on -- every earlier lane that shares a
+// particle with it, transitively closed.
 // The rest-length arrays of the device (one per env for tier 2, else one shared) are kept in slot order too.
 constexpr int WT_IDX_BITS = 12, WT_GROUP_SHIFT = 24, WT_REACH_SHIFT = 28;
 constexpr uint32_t WT_IDX_MASK = 0xFFFu;
@@ -126,7 +129,7 @@ inline WindowTable build_windows(const Topology &t, const LevelSchedule &L) {
     for (int l = 0; l < L.n_levels; l++) {
         int p = L.off[l];
         while (p < L.off[l + 1]) {                                // a level may continue in the next window: still an antichain
-            if (used == 64 || groups == WT_MAX_GROUPS) { w++; used = 0; groups = 0; }
+            if (used == 64) { w++; used = 0; groups = 0; }
             const int take = std::min(L.off[l + 1] - p, 64 - used);
             for (int q = 0; q < take; q++) {
                 const int s = L.order[p + q];
@@ -160,7 +163,7 @@ inline WindowTable build_windows(const Topology &t, const LevelSchedule &L) {
     for (int s = 0; s < t.S; s++) {
         const int i = W.slot_of[s], ws = i >> 6;
         const int r = (wreach[ws] + (1 << W.reach_shift) - 1) >> W.reach_shift;
-        W.ent[i] = (uint32_t)t.a[s] | ((uint32_t)t.b[s] << WT_IDX_BITS) | ((uint32_t)group_of[s] << WT_GROUP_SHIFT) |
+        W.ent[i] = (uint32_t)t.a[s] | ((uint32_t)t.b[s] << WT_IDX_BITS) | ((uint32_t)std::min(group_of[s], WT_MAX_GROUPS - 1) << WT_GROUP_SHIFT) |
                    ((uint32_t)r << WT_REACH_SHIFT);
         W.spring_at[i] = s;
     }

@@ -140,6 +140,21 @@ extern "C" int clothhip_spring_topology(const ClothParams *p, int32_t *a, int32_
     return 0;
 }
 
+extern "C" int clothhip_selftest_windows(const ClothParams *p, int32_t *n_windows, int32_t *n_slots, int32_t *reach_shift,
+                                         int32_t *spring_at, uint32_t *ent, uint64_t *dep, int32_t capacity) {
+    if (int rc = check_params(p)) return rc;
+    const Topology t = build_topology(p->n_side);
+    const WindowTable W = build_windows(t, build_levels(t));
+    if (n_windows) *n_windows = W.nW;
+    if (n_slots) *n_slots = W.n_slots;
+    if (reach_shift) *reach_shift = W.reach_shift;
+    if ((spring_at || ent || dep) && capacity < W.n_slots) return fail(CLOTHHIP_EINVAL, "capacity below the table's slot count");
+    if (spring_at) memcpy(spring_at, W.spring_at.data(), sizeof(int32_t) * W.n_slots);
+    if (ent) memcpy(ent, W.ent.data(), sizeof(uint32_t) * W.n_slots);
+    if (dep) memcpy(dep, W.dep.data(), sizeof(uint64_t) * W.n_slots);
+    return 0;
+}
+
 template <typename T> static DevConsts<T> make_consts(const ClothParams &p) {
     const int N = p.n_side;
     const double dx = p.width * 1.0 / (N - 1), dy = p.height * 1.0 / (N - 1);

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CLOTHHIP_ABI_VERSION 3
+#define CLOTHHIP_ABI_VERSION 4
 
 enum {
     CLOTHHIP_OK = 0,
@@ -369,6 +369,14 @@ int clothhip_debug_stats(clothhip_handle *h, int32_t *stats);
 /* Arithmetic self-test used by the parity tests: evaluates out[i] = op(a[i], b[i]) in double ON THE
  * DEVICE with the same compiler flags as the stepper (op 0: a/b, 1: sqrt(a), 2: a*b+c unfused = (a*b)+b,
  * 3: floor(a/b)).  Lets tests assert IEEE-correct rounding of the device's sqrt/div bit-for-bit. */
+/* (new, host only) The static tables of the strain sweep for a grid, for the CPU test that pins the sweep's pass rule to the
+ * sequential loop of cloth.pyx:258-296: `spring_at[slot]` = reference list index of the spring in window-table slot `slot`
+ * (-1: empty), `ent[slot]` = packed entry (ptA | ptB << 12 | level-in-window << 24 | reach << 28), `dep[slot]` = the lanes of
+ * the slot's 64-slot window whose springs it transitively depends on. Arrays hold `capacity` slots; returns CLOTHHIP_EINVAL
+ * when that is too small (n_slots is set either way). Any array may be NULL. */
+int clothhip_selftest_windows(const ClothParams *params, int32_t *n_windows, int32_t *n_slots, int32_t *reach_shift,
+                              int32_t *spring_at, uint32_t *ent, uint64_t *dep, int32_t capacity);
+
 /* Host-side self-test of csrc/cloth_rng.hpp (the same functions the kernel runs): n draws of kind 0 next32, 1 rand(),
  * 2 uniform(a, b), 3 randint((uint32)a), 4 _randval_minabs(a, b, minabs = c) into out[n]; kind 5 skips (uint64)a words.
  * state[625] = key[624], pos: numpy RandomState.get_state()[1:3], advanced in place. No device needed. */

@@ -8,7 +8,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 T="timeout 900"
 HEAD="--no-extra --no-cpu-baseline"        # the headline configuration only (512 cloths, fp32, fused time slices)
-# STAGES="trace traffic writerep sq phases action n50" selects stages (default: all)
+# STAGES="trace traffic writerep sq phases action n50 ablation" selects stages (default: all)
 want() { [[ -z "${STAGES:-}" || " $STAGES " == *" $1 "* ]]; }
 if want trace; then
 # 1. kernel trace + stats of the headline bench command
@@ -64,5 +64,10 @@ fi
 if want n50; then
 # 6. rocprofv3 trace of the 50x50 companion (configs[4]) alone
 $T rocprofv3 --kernel-trace --stats -d "$OUT/trace50" -o run -- python3 bench.py $HEAD --n-side 50 --envs 1024 --steps 5 --warmup 0 --fuse 5 --step-ms 2400 > "$OUT/bench50_traced.json" 2> "$OUT/trace50.log"
+fi
+if want ablation; then
+# 7. phase ablation on harvested reference states (settled / rest / pull / lift): all phases, without the strain limit, without
+#    strain limit and self-collision, Hooke + Verlet only -- what the exact-order sweeps cost, and what is left without them
+$T python3 tools/microbench.py --masks 15,7,5,1 > "$OUT/ablation.txt" 2>&1
 fi
 find "$OUT" -name "*.db" | head -60

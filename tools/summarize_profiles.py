@@ -127,7 +127,8 @@ def main():
         json.dump({"records": records}, open(os.path.join(os.path.dirname(dst) or ".", os.path.basename(dst).split("_")[0] + "_traffic.json"), "w"), indent=1)
     for nm, to in (("phase_f32.txt", "_phase_profile_f32.txt"), ("phase_f64.txt", "_phase_profile_f64.txt"),
                    ("fused_balance.txt", "_fused_balance.txt"), ("fused_phases.txt", "_fused_phases.txt"),
-                   ("fused_phases_f64.txt", "_fused_phases_f64.txt"), ("sweepstamps_f32.txt", "_sweepstamps_f32.txt")):
+                   ("fused_phases_f64.txt", "_fused_phases_f64.txt"), ("sweepstamps_f32.txt", "_sweepstamps_f32.txt"),
+                   ("ablation.txt", "_phase_ablation.txt")):
         p = os.path.join(src, nm)
         if os.path.exists(p):
             shutil.copy(p, dst + to)
