@@ -77,8 +77,8 @@ def main():
             if exo[k] != ex[e] or not (np.array_equal(pos1[e], op) and np.array_equal(prev1[e], oq)):
                 bad.append((e, int(ex[e]), int(exo[k]), float(np.abs(pos1[e] - op).max())))
         st = env.batch.debug_stats()
-        print("step %d: %d envs active, %d substeps, oracle %.1f s on %d threads | dense sweeps %d, sparse %d | mismatches %d %s" %
-              (t, len(idx), int(ex.sum()), dt, threads, int(st[idx, 1].sum()), int((st[idx, 0] - st[idx, 1]).sum()), len(bad), bad[:3]),
+        print("step %d: %d envs active, %d substeps, oracle %.1f s on %d threads | strain sweeps %d | mismatches %d %s" %
+              (t, len(idx), int(ex.sum()), dt, threads, int(st[idx, 0].sum()), len(bad), bad[:3]),
               flush=True)
         bad_total += len(bad)
     print("SOAK", "OK" if bad_total == 0 else "FAILED (%d)" % bad_total)
