@@ -336,6 +336,32 @@ def render_bench(E, local_rank, size=224, reps=3):
     return rec
 
 
+def demo_bench(E, local_rank, episodes=4000):
+    """Companion record for the demonstration writer: the reference's own use of the path, `examples/analytic.py
+    oracle --tier=1` (analytic.py:825-910) -- whole episodes with the oracle-corner policy, here evaluated in the kernel, until
+    `episodes` episodes have finished over E envs; wall time incl. cutting the records into the reference's episode dicts.
+    Episodes are taken in order of completion and the launch that completes the last one is run to its end, so the rate is a slight
+    under-statement. (The reference notes ~250 minutes for 400 such episodes on one core, Blender observations included:
+    BASELINE.md section 1; its physics alone is 70-95 s per 10-action episode.)"""
+    from gym_cloth_amd.demos import collect_demos
+    from gym_cloth_amd.envs import ClothVecEnv
+    env = ClothVecEnv(bench_cfg(25, 0.02), n_envs=E, device=local_rank, precision="f32")
+    env.seed(1337)
+    t0 = time.perf_counter()
+    eps = collect_demos(env, "oracle_corner", max_episodes=episodes, time_budget_ms=400.0)
+    dt = time.perf_counter() - t0
+    n_act = sum(len(ep["act"]) for ep in eps)
+    n_sub = sum(int(ep["info"][-1]["num_sim_steps"]) for ep in eps)
+    cov = float(np.mean([ep["info"][-1]["actual_coverage"] for ep in eps]))
+    env.close()
+    return {"value": len(eps) / dt, "unit": "episodes/s", "dtype": "f32", "episodes": len(eps), "wall_s_collect": dt,
+            "actions_per_episode": n_act / max(len(eps), 1), "action_substeps_of_the_kept_episodes": n_sub,
+            "mean_final_coverage": cov,
+            "config": {"workload": "%d finished tier-1 episodes of the in-kernel oracle-corner policy over %d envs "
+                                   "(resets, policy, steps, metrics on the device; records cut into episode dicts on the host)"
+                                   % (len(eps), E)}}
+
+
 def self_launch(args):
     """--gpus N without a launcher environment: start one child process per GPU (fresh processes: nothing in THIS process
     has touched the GPU, and no process is ever replaced by exec), relay rank 0's JSON line. All children are supervised: when one
@@ -529,6 +555,13 @@ def main():
             except Exception as exc:
                 r = {"error": "%s: %s" % (type(exc).__name__, exc)}
             r["label"], r["wall_s"] = "headless rasteriser (SURVEY 8f-f4): image observations of the whole batch", time.perf_counter() - t0
+            extra.append(r)
+            t0 = time.perf_counter()
+            try:
+                r = demo_bench(args.envs, local_rank)
+            except Exception as exc:
+                r = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            r["label"], r["wall_s"] = "demonstration writer (SURVEY 8f-f2): 4000 oracle-corner episodes, policy in the kernel", time.perf_counter() - t0
             extra.append(r)
     if rank == 0:
         out = {
