@@ -302,10 +302,10 @@ __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const
     unsigned long long edep[PD + 1];
     auto load = [&](int wi, uint32_t &ab_, T &r_) {
         if (LDS_TAB) { const WEnt<T> e_ = wt[wi * 64 + lane]; ab_ = e_.ab; r_ = e_.rest; }
-        else { ab_ = g_ent[wi * 64 + lane]; r_ = g_rest[wi * 64 + lane]; }
+        else { const uint32_t ix = (uint32_t)(wi * 64 + lane); ab_ = g_ent[ix]; r_ = g_rest[ix]; }    // (unsigned: scalar base + 32-bit offset addressing)
     };
 #pragma unroll
-    for (int j = 0; j <= PD; j++) edep[j] = g_dep[(w0 + j) * 64 + lane];
+    for (int j = 0; j <= PD; j++) edep[j] = g_dep[(uint32_t)((w0 + j) * 64 + lane)];
 #pragma unroll
     for (int j = 0; j <= PF; j++) load(w0 + j, eab[j], erest[j]);
     // Both loops are single-exit do-whiles with wave-uniform conditions (ballots), so they compile to plain scalar branches; the
@@ -332,7 +332,7 @@ __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const
 #pragma unroll
         for (int j = 0; j < PD; j++) edep[j] = edep[j + 1];
         load(w + PF + 1, eab[PF], erest[PF]);
-        edep[PD] = g_dep[(w + PD + 1) * 64 + lane];
+        edep[PD] = g_dep[(uint32_t)((w + PD + 1) * 64 + lane)];
         const int a = (int)(ab & WT_IDX_MASK), b = (int)((ab >> WT_IDX_BITS) & WT_IDX_MASK);
         P3 *const pa = reinterpret_cast<P3 *>(cur + a), *const pb = reinterpret_cast<P3 *>(cur + b);
         T ax, ay, az, bx, by, bz;
@@ -752,9 +752,6 @@ __device__ __forceinline__ void metrics_block(const Src &src, int P, int NS, int
 //   FUSED: 0 = one externally decoded schedule per env (clothhip_run); 1 = whole episodes per launch (clothhip_run_actions)
 //          with the resets of the flat tiers 1 and 3; 2 = also tier-2 resets. (The tier-2 reset code is cold, but its presence
 //          costs the substep loop registers: -7 % on the headline workload, so it is compiled in only where it is asked for.)
-#ifndef CLOTHHIP_LEAN_WAVES
-#define CLOTHHIP_LEAN_WAVES 3
-#endif
 // LEAN variant (TAB == 0 with REST_REG, fp32): the 12-slot gather stencil of a particle is recomputed from its grid position
 // instead of being held in 36 registers, and rest lengths come from a three-value palette instead of 36 more: the stepper then
 // fits 168 VGPRs and three cloths share a CU. Position k of the stencil = the k-th incident spring in ascending list index when
@@ -778,7 +775,7 @@ __host__ __device__ inline uint32_t lean_valid_mask(int r, int c, int N) {
 }
 
 template <typename T, int NT, int PPT, int TAB, bool REST_REG, int FUSED>
-__global__ __launch_bounds__(NT, ((TAB == 0 && REST_REG && sizeof(T) == 4) ? CLOTHHIP_LEAN_WAVES : (NT <= 512 ? 2 : NT / 256))) void k_run_schedule(StepArgs<T> A) {
+__global__ __launch_bounds__(NT, ((TAB == 0 && REST_REG && sizeof(T) == 4) ? 3 : (NT <= 512 ? 2 : NT / 256))) void k_run_schedule(StepArgs<T> A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int e = blockIdx.x;
     const int tid = threadIdx.x;
@@ -821,11 +818,7 @@ __global__ __launch_bounds__(NT, ((TAB == 0 && REST_REG && sizeof(T) == 4) ? CLO
     T pvx[PPT], pvy[PPT], pvz[PPT];         // previous positions of the owned particles
     // their incident-spring gather entries (static): in registers for fp32; the fp64 instantiation has no room
     // (they ended up in scratch, reloaded one by one) and re-reads the L2-resident table, 12 loads in flight
-#ifdef CLOTHHIP_LEAN_TAB1
-    constexpr bool LEAN = REST_REG && sizeof(T) == 4;
-#else
     constexpr bool LEAN = TAB == 0 && REST_REG && sizeof(T) == 4;
-#endif
     constexpr bool GT_REG = sizeof(T) == 4 && !LEAN;
     constexpr bool REST_R = REST_REG && !LEAN;
     uint32_t gt[GT_REG ? PPT : 1][HK_SLOTS];
@@ -1398,9 +1391,11 @@ __global__ __launch_bounds__(NT, ((TAB == 0 && REST_REG && sizeof(T) == 4) ? CLO
                     wme[q] = w_cnt(me.w);
                     T fx = (T)0 + (T)0, fy = (T)0 + (T)0, fz = (T)0 + k.mg;
                     uint32_t gl[HK_SLOTS];
+                    int iq_ = tid + q * NT; uint32_t vq_ = vm[LEAN ? q : 0];
+                    if (LEAN) asm volatile("" : "+v"(iq_), "+v"(vq_));     // opaque: the stencil is recomputed every substep, not hoisted and held
 #pragma unroll
                     for (int sl = 0; sl < HK_SLOTS; sl++)
-                        gl[sl] = LEAN ? lean_entry(tid + q * NT, vm[LEAN ? q : 0], sl) : (GT_REG ? gt[GT_REG ? q : 0][sl] : A.gather[sl * Ppad + tid + q * NT]);
+                        gl[sl] = LEAN ? lean_entry(iq_, vq_, sl) : (GT_REG ? gt[GT_REG ? q : 0][sl] : A.gather[sl * Ppad + tid + q * NT]);
                     // software pipeline: the neighbour records of the next springs are in flight while spring sl is
                     // evaluated (left to itself the scheduler, which minimises live registers at this kernel's pressure, issues
                     // each 16-byte read right before its use and waits out the whole LDS latency 12 times per particle)
@@ -1769,9 +1764,11 @@ __global__ __launch_bounds__(NT, ((TAB == 0 && REST_REG && sizeof(T) == 4) ? CLO
                         const Pt<T> me = cur[tid + q * NT];
                         const uint32_t cme_ = w_cnt(me.w);
                         uint32_t gl[HK_SLOTS / 2];
+                        int iq_ = tid + q * NT; uint32_t vq_ = vm[LEAN ? q : 0];
+                        if (LEAN) asm volatile("" : "+v"(iq_), "+v"(vq_));
 #pragma unroll
                         for (int sl = 0; sl < HK_SLOTS / 2; sl++)
-                            gl[sl] = LEAN ? lean_entry(tid + q * NT, vm[LEAN ? q : 0], sl) : (GT_REG ? gt[GT_REG ? q : 0][sl] : A.gather[sl * Ppad + tid + q * NT]);
+                            gl[sl] = LEAN ? lean_entry(iq_, vq_, sl) : (GT_REG ? gt[GT_REG ? q : 0][sl] : A.gather[sl * Ppad + tid + q * NT]);
                         // software pipeline, as in the Hooke phase: two neighbour reads in flight ahead of the test
                         constexpr int PP_AHEAD = 2;
                         Pt<T> nbq[PP_AHEAD];

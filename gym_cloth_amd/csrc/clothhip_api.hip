@@ -63,6 +63,7 @@ struct clothhip_handle {
     // may have changed) and the regular gather stencil (checked once); otherwise the (0, false) variant runs on the same layout.
     bool lean = false, lean_dirty = true, lean_ok = false, lean_stencil_ok = false;
     float pal[3] = {0, 0, 0};
+    struct Layout { int tab; bool rest_reg; int cell_copy; int lds_bytes; } lay_std = {0, false, 0, 0}, lay_lean = {0, true, 0, 0};
     double *d_levels = nullptr, *d_xy = nullptr, *d_radius = nullptr, *d_cov = nullptr, *d_vinv = nullptr;
     uint8_t *d_oob = nullptr;
     int32_t *d_hcnt = nullptr;      // per env: #points with z < thickness/2 (height reward, cloth_env.py:1047-1073)
@@ -285,10 +286,17 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
         if (const char *t = getenv("CLOTHHIP_DEBUG_TAB_LDS")) h->tab = std::min(h->tab, atoi(t));
         h->rest_reg = (h->nt == 256 && precision == CLOTHHIP_F32 && h->tab == 1);
         if (const char *t = getenv("CLOTHHIP_DEBUG_REST_REG")) h->rest_reg = h->rest_reg && atoi(t);
-        h->lean = h->nt == 256 && precision == CLOTHHIP_F32 && h->E >= 1024;
-        if (const char *t = getenv("CLOTHHIP_DEBUG_LEAN")) h->lean = h->nt == 256 && precision == CLOTHHIP_F32 && atoi(t) == 1;
+        // LEAN variant: three cloths per CU instead of two, each stepping at 84 % of the standard variant's rate (measured). A
+        // launch runs its cloths in generations of what is resident, so it pays when ceil(E / 2 CUs) / ceil(E / 3 CUs) > 1.19.
+        {
+            hipDeviceProp_t dp;
+            int cus = 256;
+            if (hipGetDeviceProperties(&dp, device) == hipSuccess && dp.multiProcessorCount > 0) cus = dp.multiProcessorCount;
+            const int g2 = (h->E + 2 * cus - 1) / (2 * cus), g3 = (h->E + 3 * cus - 1) / (3 * cus);
+            h->lean = h->nt == 256 && precision == CLOTHHIP_F32 && (double)g2 > 1.19 * (double)g3;
+        }
+        if (const char *t = getenv("CLOTHHIP_DEBUG_LEAN")) h->lean = h->nt == 256 && precision == CLOTHHIP_F32 && atoi(t) != 0;
         if (h->lean) {
-            h->tab = 0; h->rest_reg = false;
             // the arithmetic stencil of the LEAN kernel against the gather table built from the reference's spring list
             h->lean_stencil_ok = true;
             for (int i = 0; i < h->P && h->lean_stencil_ok; i++) {
@@ -308,17 +316,32 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
                 }
                 if (slot < HK_SLOTS && h->lean_stencil_ok && (gather[(size_t)slot * h->Ppad + i] & HK_VALID)) h->lean_stencil_ok = false;
             }
+            if (!h->lean_stencil_ok) h->lean = false;
         }
         // the cell-ordered record copy for the collision pre-check is taken only if it does not cost the table its place
         h->cell_copy = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, h->tab, 1).total <= budget ? 1 : 0;
         if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) h->cell_copy = h->cell_copy && atoi(t);
         h->lds_bytes = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, h->tab, h->cell_copy).total;
+        h->lay_std = {h->tab, h->rest_reg, h->cell_copy, h->lds_bytes};
+        if (h->lean) {                                   // the lean layout: window table streamed from L2, 33 KB of LDS
+            int cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, 1).total <= 53 * 1024 ? 1 : 0;
+            if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) cc = cc && atoi(t);
+            h->lay_lean = {0, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, cc).total};
+            // the in-kernel metrics borrow the region behind the episode state (clothhip_fused_supported): it must hold them here too
+            int NS_ = 1; while (NS_ < h->P) NS_ <<= 1;
+            const LdsLayout ll(tsz, h->Ppad, h->Spad, h->HT, 0, cc);
+            if (ll.total - ll.wtab < 2 * NS_ * tsz + (2 * (h->Ppad + 8) + 64) * 8) h->lean = false;
+        }
         if (h->lds_bytes > 160 * 1024) { free_handle(h); return fail(CLOTHHIP_EINVAL, "n_side %d needs %d B of LDS (> 160 KiB)", h->N, h->lds_bytes); }
-        if (h->lean) {                                   // both variants of the lean layout may run (the palette is checked per launch)
-            h->rest_reg = true;
-            for (int f = 0; f < 3; f++)
-                if (const void *fl = stepper_fn(h, f)) HC(hipFuncSetAttribute(fl, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            h->rest_reg = false;
+        if (h->lean) {                                   // the lean kernels too (which layout runs is decided per launch)
+            const clothhip_handle::Layout keep = {h->tab, h->rest_reg, h->cell_copy, h->lds_bytes};
+            h->tab = h->lay_lean.tab; h->rest_reg = h->lay_lean.rest_reg;
+            for (int f = 0; f < 3; f++) {
+                const void *fl = stepper_fn(h, f);
+                if (!fl) { free_handle(h); return fail(CLOTHHIP_EINVAL, "no lean stepper variant for n_side %d", h->N); }
+                HC(hipFuncSetAttribute(fl, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            }
+            h->tab = keep.tab; h->rest_reg = keep.rest_reg;
         }
         const void *fn = stepper_fn(h, 0), *fnf = stepper_fn(h, 1), *fnf2 = stepper_fn(h, 2);
         if (!fn || !fnf || !fnf2) { free_handle(h); return fail(CLOTHHIP_EINVAL, "no stepper variant for n_side %d", h->N); }
@@ -599,15 +622,15 @@ template <typename T> static StepArgs<T> make_args(clothhip_handle *h, const Clo
     return a;
 }
 
-// Which of the two variants of the lean layout runs now: the LEAN kernel when the device's shared rest table is a three-value
-// palette (re-checked whenever the table may have changed), else the (TAB 0, rest from L2) variant.
+// Which stepper runs the next launch: the LEAN variant (three cloths per CU) when this handle wants it and the device's shared
+// rest table is a three-value palette (re-checked whenever the table may have changed: per-env tables, i.e. tier 2, or odd
+// rest lengths uploaded by the caller switch back), else the standard variant. LDS is rebuilt by every launch, so the layout
+// may change from one launch to the next.
 static int lean_refresh(clothhip_handle *h) {
-    const bool pal_only = getenv("CLOTHHIP_DEBUG_LEAN") && atoi(getenv("CLOTHHIP_DEBUG_LEAN")) == 2;   // (experiment)
-    if (!h->lean && !pal_only) return 0;
-    if (pal_only) h->lean_stencil_ok = true;
+    if (!h->lean) return 0;
     if (h->lean_dirty) {
         h->lean_dirty = false; h->lean_ok = false;
-        if (h->lean_stencil_ok && h->rest_stride == 0) {
+        if (h->rest_stride == 0) {
             std::vector<float> r((size_t)h->Spad);
             HIPCHECK(hipStreamSynchronize(h->stream));
             HIPCHECK(hipMemcpy(r.data(), h->d_rest, r.size() * 4, hipMemcpyDeviceToHost));
@@ -621,7 +644,8 @@ static int lean_refresh(clothhip_handle *h) {
             h->lean_ok = ok && have[0] && have[1] && have[2];
         }
     }
-    if (!pal_only) h->rest_reg = h->lean_ok && h->rest_stride == 0;
+    const clothhip_handle::Layout &L = (h->lean_ok && h->rest_stride == 0) ? h->lay_lean : h->lay_std;
+    h->tab = L.tab; h->rest_reg = L.rest_reg; h->cell_copy = L.cell_copy; h->lds_bytes = L.lds_bytes;
     return 0;
 }
 
