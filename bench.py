@@ -259,6 +259,8 @@ def run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, rank
         n_conc = min(E, 512)                                  # resident cloths: 2 per CU (LDS-bound), 256 CUs
         act_only = n_conc * sb[0] / (tk[0] / 1e8) if tk[0] > 0 else None
         reset_only = n_conc * (sb[1] + sb[2]) / ((tk[1] + tk[2]) / 1e8) if (tk[1] + tk[2]) > 0 else None
+        if E > 512:                                           # larger batches run in generations, maybe with the LEAN variant at 3 per CU:
+            act_only = reset_only = None                      # the concurrency is not known here, the two figures are not given
         rec = {
             "value": n_sub_all / dt, "ms_per_step": dt / max(n_env_steps / (world * E), 1e-9) * 1e3, "dtype": precision,
             "config": {"workload": "%d batched %dx%d cloths per GPU, %s start, random pick-and-place actions, episodes "
@@ -541,9 +543,12 @@ def main():
                       n_side=25, E=512, precision=args.precision, init="tier2", mode=args.mode, steps=10, warmup=5, fuse_max=10,
                       step_ms=args.step_ms, **k5)
         if args.envs < 2048 and args.n_side == 25:
-            companion("2048 cloths per GPU (4 resident generations of workgroups per launch)", n_side=25, E=2048,
-                      precision=args.precision, init="tier1", mode="fused", steps=5, warmup=0, fuse_max=5,
+            companion("2048 cloths per GPU (LEAN stepper variant, 3 cloths per CU: 2.67 generations of 768 workgroups per launch)",
+                      n_side=25, E=2048, precision=args.precision, init="tier1", mode="fused", steps=5, warmup=0, fuse_max=5,
                       step_ms=4 * args.step_ms, **k5)
+            companion("1536 cloths per GPU (LEAN stepper variant: two full generations of 768 workgroups per launch)",
+                      n_side=25, E=1536, precision=args.precision, init="tier1", mode="fused", steps=5, warmup=0, fuse_max=5,
+                      step_ms=3 * args.step_ms, **k5)
         if args.n_side == 25:
             companion("BASELINE configs[4]: 50x50 x 1024 cloths, thickness 0.0095", n_side=50, E=1024,
                       precision=args.precision, init="tier1", mode="fused", steps=5, warmup=0, fuse_max=5, step_ms=2400.0,

@@ -131,6 +131,8 @@ template <typename T> struct StepArgs {
     const uint32_t *gather;  // [HK_SLOTS][Ppad]
     const uint32_t *wt_ent;  // [Spad] window table of the strain sweep (cloth_tables.hpp), Spad = (nW + padding windows) * 64
     const unsigned long long *wt_dep;   // [Spad] per slot: the lanes of its window the spring transitively depends on
+    T pal_struct, pal_shear, pal_bend;  // LEAN variant: the rest length of every structural / shearing / bending spring (one shared table
+                                        // whose fp32 values are one per type: checked by the host before the variant is chosen)
     int32_t nW, wt_rshift;   // windows that hold springs; unit (log2 windows) of the entries' reach field
     int32_t N, P, Ppad, S, Spad;
     int32_t HT, ht_bits;     // spatial hash table slots (power of two > P)
@@ -300,10 +302,10 @@ __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const
     unsigned long long edep[PD + 1];
     auto load = [&](int wi, uint32_t &ab_, T &r_) {
         if (LDS_TAB) { const WEnt<T> e_ = wt[wi * 64 + lane]; ab_ = e_.ab; r_ = e_.rest; }
-        else { ab_ = g_ent[wi * 64 + lane]; r_ = g_rest[wi * 64 + lane]; }
+        else { const uint32_t ix = (uint32_t)(wi * 64 + lane); ab_ = g_ent[ix]; r_ = g_rest[ix]; }    // (unsigned: scalar base + 32-bit offset addressing)
     };
 #pragma unroll
-    for (int j = 0; j <= PD; j++) edep[j] = g_dep[(w0 + j) * 64 + lane];
+    for (int j = 0; j <= PD; j++) edep[j] = g_dep[(uint32_t)((w0 + j) * 64 + lane)];
 #pragma unroll
     for (int j = 0; j <= PF; j++) load(w0 + j, eab[j], erest[j]);
     // Both loops are single-exit do-whiles with wave-uniform conditions (ballots), so they compile to plain scalar branches; the
@@ -330,7 +332,7 @@ __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const
 #pragma unroll
         for (int j = 0; j < PD; j++) edep[j] = edep[j + 1];
         load(w + PF + 1, eab[PF], erest[PF]);
-        edep[PD] = g_dep[(w + PD + 1) * 64 + lane];
+        edep[PD] = g_dep[(uint32_t)((w + PD + 1) * 64 + lane)];
         const int a = (int)(ab & WT_IDX_MASK), b = (int)((ab >> WT_IDX_BITS) & WT_IDX_MASK);
         P3 *const pa = reinterpret_cast<P3 *>(cur + a), *const pb = reinterpret_cast<P3 *>(cur + b);
         T ax, ay, az, bx, by, bz;
@@ -750,8 +752,30 @@ __device__ __forceinline__ void metrics_block(const Src &src, int P, int NS, int
 //   FUSED: 0 = one externally decoded schedule per env (clothhip_run); 1 = whole episodes per launch (clothhip_run_actions)
 //          with the resets of the flat tiers 1 and 3; 2 = also tier-2 resets. (The tier-2 reset code is cold, but its presence
 //          costs the substep loop registers: -7 % on the headline workload, so it is compiled in only where it is asked for.)
+// LEAN variant (TAB == 0 with REST_REG, fp32): the 12-slot gather stencil of a particle is recomputed from its grid position
+// instead of being held in 36 registers, and rest lengths come from a three-value palette instead of 36 more: the stepper then
+// fits 168 VGPRs and three cloths share a CU. Position k of the stencil = the k-th incident spring in ascending list index when
+// all twelve exist (cloth.pyx:134-146: the six springs the point owns, then those its later neighbours own):
+//   k      0    1    2      3      4     5    6   7    8      9    10     11
+//   nbr   -N   -1   -N-1   -N+1   -2N   -2   +1  +2   +N-1   +N   +N+1   +2N      (index i = r*N + c)
+//   type   S    S    Sh     Sh     B     B    S   B    Sh     S    Sh     B
+// (the host checks this against the gather table it builds from the reference's spring list before choosing the variant).
+__device__ __forceinline__ int lean_off(int k, int N) {
+    switch (k) {
+        case 0: return -N; case 1: return -1; case 2: return -N - 1; case 3: return -N + 1; case 4: return -2 * N; case 5: return -2;
+        case 6: return 1; case 7: return 2; case 8: return N - 1; case 9: return N; case 10: return N + 1; default: return 2 * N;
+    }
+}
+__host__ __device__ constexpr bool lean_bend(int k) { return k == 4 || k == 5 || k == 7 || k == 11; }
+__host__ __device__ constexpr bool lean_shear(int k) { return k == 2 || k == 3 || k == 8 || k == 10; }
+__host__ __device__ inline uint32_t lean_valid_mask(int r, int c, int N) {
+    const bool u1 = r >= 1, u2 = r >= 2, d1 = r + 1 < N, d2 = r + 2 < N, l1 = c >= 1, l2 = c >= 2, r1 = c + 1 < N, r2 = c + 2 < N;
+    return (u1 ? 1u : 0u) | (l1 ? 2u : 0u) | ((u1 && l1) ? 4u : 0u) | ((u1 && r1) ? 8u : 0u) | (u2 ? 16u : 0u) | (l2 ? 32u : 0u) |
+           (r1 ? 64u : 0u) | (r2 ? 128u : 0u) | ((d1 && l1) ? 256u : 0u) | (d1 ? 512u : 0u) | ((d1 && r1) ? 1024u : 0u) | (d2 ? 2048u : 0u);
+}
+
 template <typename T, int NT, int PPT, int TAB, bool REST_REG, int FUSED>
-__global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule(StepArgs<T> A) {
+__global__ __launch_bounds__(NT, ((TAB == 0 && REST_REG && sizeof(T) == 4) ? 3 : (NT <= 512 ? 2 : NT / 256))) void k_run_schedule(StepArgs<T> A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int e = blockIdx.x;
     const int tid = threadIdx.x;
@@ -794,9 +818,18 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
     T pvx[PPT], pvy[PPT], pvz[PPT];         // previous positions of the owned particles
     // their incident-spring gather entries (static): in registers for fp32; the fp64 instantiation has no room
     // (they ended up in scratch, reloaded one by one) and re-reads the L2-resident table, 12 loads in flight
-    constexpr bool GT_REG = sizeof(T) == 4;
+    constexpr bool LEAN = TAB == 0 && REST_REG && sizeof(T) == 4;
+    constexpr bool GT_REG = sizeof(T) == 4 && !LEAN;
+    constexpr bool REST_R = REST_REG && !LEAN;
     uint32_t gt[GT_REG ? PPT : 1][HK_SLOTS];
-    T rr[REST_REG ? PPT : 1][HK_SLOTS];     // and those springs' rest lengths
+    T rr[REST_R ? PPT : 1][HK_SLOTS];     // and those springs' rest lengths
+    uint32_t vm[LEAN ? PPT : 1];            // LEAN: which of the twelve stencil positions exist for the particle
+    auto lean_entry = [&](int i, uint32_t vmq, int sl) -> uint32_t {      // a gather entry without its table-slot field
+        const bool ok = ((vmq >> sl) & 1u) != 0u;
+        return (uint32_t)(ok ? i + lean_off(sl, A.N) : i) | (ok ? HK_VALID : 0u) | (sl < HK_SLOTS / 2 ? HK_ASB : 0u) |
+               (lean_bend(sl) ? HK_BEND : 0u);
+    };
+    auto lean_rest = [&](int sl) -> T { return lean_bend(sl) ? A.pal_bend : (lean_shear(sl) ? A.pal_shear : A.pal_struct); };
     {   // HBM -> LDS / registers, coalesced
         const T *gp = A.pos + (size_t)e * 3 * Ppad, *gq = A.prev + (size_t)e * 3 * Ppad;
         const uint8_t *gc = A.cnt + (size_t)e * Ppad;
@@ -807,11 +840,13 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
             const int i = tid + q * NT;
             const bool ok = i < P;
             pvx[q] = ok ? gq[i] : (T)0; pvy[q] = ok ? gq[Ppad + i] : (T)0; pvz[q] = ok ? gq[2 * Ppad + i] : (T)0;
+            if (LEAN) { const int r_ = i / A.N; vm[LEAN ? q : 0] = ok ? lean_valid_mask(r_, i - r_ * A.N, A.N) : 0u; }
+            else
 #pragma unroll
             for (int sl = 0; sl < HK_SLOTS; sl++) {
                 const uint32_t g0 = ok ? A.gather[sl * Ppad + i] : 0u;
                 if (GT_REG) gt[GT_REG ? q : 0][sl] = g0;
-                if (REST_REG) rr[q][sl] = g_rest[(g0 >> HK_POS_SHIFT) & HK_POS_MASK];
+                if (REST_R) rr[REST_R ? q : 0][sl] = g_rest[(g0 >> HK_POS_SHIFT) & HK_POS_MASK];
             }
         }
     }
@@ -992,13 +1027,13 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                             }
                             __syncthreads();
                             init_lds(0, F.wt_ent, F.rest + (size_t)e * F.rest_stride);
-                            if (REST_REG) {
+                            if (REST_R) {
 #pragma unroll
                                 for (int q = 0; q < PPT; q++)
 #pragma unroll
                                     for (int sl = 0; sl < HK_SLOTS; sl++) {
                                         const uint32_t g0 = GT_REG ? gt[GT_REG ? q : 0][sl] : 0u;
-                                        rr[REST_REG ? q : 0][sl] = rw[(g0 >> HK_POS_SHIFT) & HK_POS_MASK];
+                                        rr[REST_R ? q : 0][sl] = rw[(g0 >> HK_POS_SHIFT) & HK_POS_MASK];
                                     }
                             }
                         }
@@ -1356,8 +1391,11 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                     wme[q] = w_cnt(me.w);
                     T fx = (T)0 + (T)0, fy = (T)0 + (T)0, fz = (T)0 + k.mg;
                     uint32_t gl[HK_SLOTS];
+                    int iq_ = tid + q * NT; uint32_t vq_ = vm[LEAN ? q : 0];
+                    if (LEAN) asm volatile("" : "+v"(iq_), "+v"(vq_));     // opaque: the stencil is recomputed every substep, not hoisted and held
 #pragma unroll
-                    for (int sl = 0; sl < HK_SLOTS; sl++) gl[sl] = GT_REG ? gt[GT_REG ? q : 0][sl] : A.gather[sl * Ppad + tid + q * NT];
+                    for (int sl = 0; sl < HK_SLOTS; sl++)
+                        gl[sl] = LEAN ? lean_entry(iq_, vq_, sl) : (GT_REG ? gt[GT_REG ? q : 0][sl] : A.gather[sl * Ppad + tid + q * NT]);
                     // software pipeline: the neighbour records of the next springs are in flight while spring sl is
                     // evaluated (left to itself the scheduler, which minimises live registers at this kernel's pressure, issues
                     // each 16-byte read right before its use and waits out the whole LDS latency 12 times per particle)
@@ -1381,8 +1419,8 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                             nbq[sl % HK_AHEAD] = cur[gn & HK_NBR_MASK];
                         }
                         __builtin_amdgcn_sched_barrier(0);  // the reads above stay above the arithmetic below
-                        const T r = REST_REG ? rr[REST_REG ? q : 0][sl] : rest_at((g >> HK_POS_SHIFT) & HK_POS_MASK);
-                        const T kk = (g & HK_BEND) ? k.ks_bend : k.ks_str;
+                        const T r = LEAN ? lean_rest(sl) : (REST_R ? rr[REST_R ? q : 0][sl] : rest_at((g >> HK_POS_SHIFT) & HK_POS_MASK));
+                        const T kk = (LEAN ? lean_bend(sl) : (g & HK_BEND) != 0u) ? k.ks_bend : k.ks_str;
                         const T dx = nb.x - me.x, dy = nb.y - me.y, dz = nb.z - me.z;
                         const T l = fastnorm<T>(dx, dy, dz);                                      // :231
                         const T fm = dev_div<T>(kk * (l - r), l);                                 // :232
@@ -1499,46 +1537,95 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                 bool hit[PPT];
 #pragma unroll
                 for (int q = 0; q < PPT; q++) hit[q] = false;
-                if (A.cell_copy) {
-                    constexpr int CU = 2;
-                    // a read past the cell's range (another cell's record or the padding behind the array) is masked out
-                    // by the member count; the trip base is clamped so that no read leaves the padded array
-                    for (int b = 0; b < nmax; b += CU) {     // CU members x PPT particles per trip: their LDS reads overlap
-                        Pt<T> o[PPT][CU];
+                // (left to itself the compiler unrolls the member loops several times: fine at 256 VGPRs, 500 spilled registers at
+                //  the LEAN variant's 168 -- that variant gets its own copy of the loops, not unrolled)
+                if constexpr (LEAN) {
+                    if (A.cell_copy) {
+                        constexpr int CU = 2;
+                        // a read past the cell's range (another cell's record or the padding behind the array) is masked out
+                        // by the member count; the trip base is clamped so that no read leaves the padded array
+#pragma unroll 1
+                        for (int b = 0; b < nmax; b += CU) {     // CU members x PPT particles per trip: their LDS reads overlap
+                            Pt<T> o[PPT][CU];
 #pragma unroll
-                        for (int q = 0; q < PPT; q++) {
-                            const int base = cstart[q] + b < Ppad + 32 - CU ? cstart[q] + b : Ppad + 32 - CU;
+                            for (int q = 0; q < PPT; q++) {
+                                const int base = cstart[q] + b < Ppad + 32 - CU ? cstart[q] + b : Ppad + 32 - CU;
 #pragma unroll
-                            for (int u = 0; u < CU; u++) o[q][u] = cpos[base + u];
-                        }
-#pragma unroll
-                        for (int q = 0; q < PPT; q++)
-#pragma unroll
-                            for (int u = 0; u < CU; u++) {                              // branch-free on purpose (& not &&)
-                                const T dx = cme[q].x - o[q][u].x, dy = cme[q].y - o[q][u].y, dz = cme[q].z - o[q][u].z;
-                                const bool other = (b + u < cn[q]) & ((int)w_cnt(o[q][u].w) != tid + q * NT);
-                                hit[q] |= other & !(sumsq<T>(dx, dy, dz) > thr2);
+                                for (int u = 0; u < CU; u++) o[q][u] = cpos[base + u];
                             }
+#pragma unroll
+                            for (int q = 0; q < PPT; q++)
+#pragma unroll
+                                for (int u = 0; u < CU; u++) {                              // branch-free on purpose (& not &&)
+                                    const T dx = cme[q].x - o[q][u].x, dy = cme[q].y - o[q][u].y, dz = cme[q].z - o[q][u].z;
+                                    const bool other = (b + u < cn[q]) & ((int)w_cnt(o[q][u].w) != tid + q * NT);
+                                    hit[q] |= other & !(sumsq<T>(dx, dy, dz) > thr2);
+                                }
+                        }
+                    } else {
+#pragma unroll 1
+                        for (int b = 0; b < nmax; b += 4) {
+                            int jj[PPT][4];
+#pragma unroll
+                            for (int q = 0; q < PPT; q++)
+#pragma unroll
+                                for (int u = 0; u < 4; u++) {
+                                    const int bb = b + u < cn[q] ? b + u : 0;
+                                    jj[q][u] = (int)memb[cn[q] ? cstart[q] + bb : 0];
+                                }
+#pragma unroll
+                            for (int q = 0; q < PPT; q++)
+#pragma unroll
+                                for (int u = 0; u < 4; u++) {
+                                    const Pt<T> o = cur[jj[q][u]];
+                                    const T dx = cme[q].x - o.x, dy = cme[q].y - o.y, dz = cme[q].z - o.z;
+                                    const bool other = (b + u < cn[q]) & (jj[q][u] != tid + q * NT);
+                                    hit[q] |= other & !(sumsq<T>(dx, dy, dz) > thr2);
+                                }
+                        }
                     }
                 } else {
-                    for (int b = 0; b < nmax; b += 4) {
-                        int jj[PPT][4];
+                    if (A.cell_copy) {
+                        constexpr int CU = 2;
+                        // a read past the cell's range (another cell's record or the padding behind the array) is masked out
+                        // by the member count; the trip base is clamped so that no read leaves the padded array
+                        for (int b = 0; b < nmax; b += CU) {     // CU members x PPT particles per trip: their LDS reads overlap
+                            Pt<T> o[PPT][CU];
 #pragma unroll
-                        for (int q = 0; q < PPT; q++)
+                            for (int q = 0; q < PPT; q++) {
+                                const int base = cstart[q] + b < Ppad + 32 - CU ? cstart[q] + b : Ppad + 32 - CU;
 #pragma unroll
-                            for (int u = 0; u < 4; u++) {
-                                const int bb = b + u < cn[q] ? b + u : 0;
-                                jj[q][u] = (int)memb[cn[q] ? cstart[q] + bb : 0];
+                                for (int u = 0; u < CU; u++) o[q][u] = cpos[base + u];
                             }
 #pragma unroll
-                        for (int q = 0; q < PPT; q++)
+                            for (int q = 0; q < PPT; q++)
 #pragma unroll
-                            for (int u = 0; u < 4; u++) {
-                                const Pt<T> o = cur[jj[q][u]];
-                                const T dx = cme[q].x - o.x, dy = cme[q].y - o.y, dz = cme[q].z - o.z;
-                                const bool other = (b + u < cn[q]) & (jj[q][u] != tid + q * NT);
-                                hit[q] |= other & !(sumsq<T>(dx, dy, dz) > thr2);
-                            }
+                                for (int u = 0; u < CU; u++) {                              // branch-free on purpose (& not &&)
+                                    const T dx = cme[q].x - o[q][u].x, dy = cme[q].y - o[q][u].y, dz = cme[q].z - o[q][u].z;
+                                    const bool other = (b + u < cn[q]) & ((int)w_cnt(o[q][u].w) != tid + q * NT);
+                                    hit[q] |= other & !(sumsq<T>(dx, dy, dz) > thr2);
+                                }
+                        }
+                    } else {
+                        for (int b = 0; b < nmax; b += 4) {
+                            int jj[PPT][4];
+#pragma unroll
+                            for (int q = 0; q < PPT; q++)
+#pragma unroll
+                                for (int u = 0; u < 4; u++) {
+                                    const int bb = b + u < cn[q] ? b + u : 0;
+                                    jj[q][u] = (int)memb[cn[q] ? cstart[q] + bb : 0];
+                                }
+#pragma unroll
+                            for (int q = 0; q < PPT; q++)
+#pragma unroll
+                                for (int u = 0; u < 4; u++) {
+                                    const Pt<T> o = cur[jj[q][u]];
+                                    const T dx = cme[q].x - o.x, dy = cme[q].y - o.y, dz = cme[q].z - o.z;
+                                    const bool other = (b + u < cn[q]) & (jj[q][u] != tid + q * NT);
+                                    hit[q] |= other & !(sumsq<T>(dx, dy, dz) > thr2);
+                                }
+                        }
                     }
                 }
 #pragma unroll
@@ -1677,8 +1764,11 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                         const Pt<T> me = cur[tid + q * NT];
                         const uint32_t cme_ = w_cnt(me.w);
                         uint32_t gl[HK_SLOTS / 2];
+                        int iq_ = tid + q * NT; uint32_t vq_ = vm[LEAN ? q : 0];
+                        if (LEAN) asm volatile("" : "+v"(iq_), "+v"(vq_));
 #pragma unroll
-                        for (int sl = 0; sl < HK_SLOTS / 2; sl++) gl[sl] = GT_REG ? gt[GT_REG ? q : 0][sl] : A.gather[sl * Ppad + tid + q * NT];
+                        for (int sl = 0; sl < HK_SLOTS / 2; sl++)
+                            gl[sl] = LEAN ? lean_entry(iq_, vq_, sl) : (GT_REG ? gt[GT_REG ? q : 0][sl] : A.gather[sl * Ppad + tid + q * NT]);
                         // software pipeline, as in the Hooke phase: two neighbour reads in flight ahead of the test
                         constexpr int PP_AHEAD = 2;
                         Pt<T> nbq[PP_AHEAD];
@@ -1703,7 +1793,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
                                 nbq[sl % PP_AHEAD] = cur[gn & HK_NBR_MASK];
                             }
                             __builtin_amdgcn_sched_barrier(0);
-                            T r = REST_REG ? rr[REST_REG ? q : 0][sl] : rest_at((g >> HK_POS_SHIFT) & HK_POS_MASK);
+                            T r = LEAN ? lean_rest(sl) : (REST_R ? rr[REST_R ? q : 0][sl] : rest_at((g >> HK_POS_SHIFT) & HK_POS_MASK));
                             asm volatile("" : "+v"(r));     // or the thresholds below are hoisted out of the substep loop
                                                             // for all 18 springs and live in scratch
                             const T dx = nb.x - me.x, dy = nb.y - me.y, dz = nb.z - me.z;   // (ptA - ptB), as :270
@@ -1723,8 +1813,11 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) void k_run_schedule
 #pragma unroll
                             for (int sl = 0; sl < HK_SLOTS / 2; sl++) {
                                 if (cand & (1u << sl)) {
-                                    const uint32_t pos_ = (gl[sl] >> HK_POS_SHIFT) & HK_POS_MASK;
-                                    T r = REST_REG ? rr[REST_REG ? q : 0][sl] : rest_at(pos_);
+                                    // (LEAN: the spring's table slot is read from the gather table only now that it is needed: the table
+                                    //  is compacted, the sl-th stencil position is the particle's popcount(valid below sl)-th entry)
+                                    const uint32_t pos_ = ((LEAN ? A.gather[__popc(vm[LEAN ? q : 0] & ((1u << sl) - 1u)) * Ppad + tid + q * NT] : gl[sl])
+                                                           >> HK_POS_SHIFT) & HK_POS_MASK;
+                                    T r = LEAN ? lean_rest(sl) : (REST_R ? rr[REST_R ? q : 0][sl] : rest_at(pos_));
                                     asm volatile("" : "+v"(r));
                                     const T len2 = l2s[sl];
                                     const T t11 = r * k.c11, tt = r * k.tear_thresh;

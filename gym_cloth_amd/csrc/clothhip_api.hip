@@ -58,6 +58,12 @@ struct clothhip_handle {
     int HT = 0, ht_bits = 0, lds_bytes = 0, phase_mask = 15, nt = 256, ppt = 3;
     int tab = 0;            // the strain sweep's window table (+ rest lengths) resident in LDS: 0 no (streamed from L2), 1 yes
     bool rest_reg = false;
+    // LEAN stepper (fp32, n_side <= 27, batches of >= 1024 cloths): 168 VGPRs and 33 KB of LDS per cloth -> three cloths per CU.
+    // It needs ONE shared rest table whose fp32 values are one per spring type (checked on the device's table whenever that table
+    // may have changed) and the regular gather stencil (checked once); otherwise the (0, false) variant runs on the same layout.
+    bool lean = false, lean_dirty = true, lean_ok = false, lean_stencil_ok = false;
+    float pal[3] = {0, 0, 0};
+    struct Layout { int tab; bool rest_reg; int cell_copy; int lds_bytes; } lay_std = {0, false, 0, 0}, lay_lean = {0, true, 0, 0};
     double *d_levels = nullptr, *d_xy = nullptr, *d_radius = nullptr, *d_cov = nullptr, *d_vinv = nullptr;
     uint8_t *d_oob = nullptr;
     int32_t *d_hcnt = nullptr;      // per env: #points with z < thickness/2 (height reward, cloth_env.py:1047-1073)
@@ -280,11 +286,63 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
         if (const char *t = getenv("CLOTHHIP_DEBUG_TAB_LDS")) h->tab = std::min(h->tab, atoi(t));
         h->rest_reg = (h->nt == 256 && precision == CLOTHHIP_F32 && h->tab == 1);
         if (const char *t = getenv("CLOTHHIP_DEBUG_REST_REG")) h->rest_reg = h->rest_reg && atoi(t);
+        // LEAN variant: three cloths per CU instead of two, each stepping at 84 % of the standard variant's rate (measured). A
+        // launch runs its cloths in generations of what is resident, so it pays when ceil(E / 2 CUs) / ceil(E / 3 CUs) > 1.19.
+        {
+            hipDeviceProp_t dp;
+            int cus = 256;
+            if (hipGetDeviceProperties(&dp, device) == hipSuccess && dp.multiProcessorCount > 0) cus = dp.multiProcessorCount;
+            const int g2 = (h->E + 2 * cus - 1) / (2 * cus), g3 = (h->E + 3 * cus - 1) / (3 * cus);
+            h->lean = h->nt == 256 && precision == CLOTHHIP_F32 && (double)g2 > 1.19 * (double)g3;
+        }
+        if (const char *t = getenv("CLOTHHIP_DEBUG_LEAN")) h->lean = h->nt == 256 && precision == CLOTHHIP_F32 && atoi(t) != 0;
+        if (h->lean) {
+            // the arithmetic stencil of the LEAN kernel against the gather table built from the reference's spring list
+            h->lean_stencil_ok = true;
+            for (int i = 0; i < h->P && h->lean_stencil_ok; i++) {
+                const uint32_t vm = lean_valid_mask(i / h->N, i % h->N, h->N);
+                int slot = 0;
+                for (int k = 0; k < HK_SLOTS; k++) {
+                    if (!((vm >> k) & 1u)) continue;
+                    const int off[12] = {-h->N, -1, -h->N - 1, -h->N + 1, -2 * h->N, -2, 1, 2, h->N - 1, h->N, h->N + 1, 2 * h->N};
+                    const uint32_t want = (uint32_t)(i + off[k]) | HK_VALID | (k < HK_SLOTS / 2 ? HK_ASB : 0u) | (lean_bend(k) ? HK_BEND : 0u);
+                    const uint32_t g = gather[(size_t)slot * h->Ppad + i];
+                    const uint32_t have = g & (HK_NBR_MASK | HK_VALID | HK_ASB | HK_BEND);
+                    const int sp = h->wt.spring_at[(g >> HK_POS_SHIFT) & HK_POS_MASK];
+                    const int ty = sp >= 0 ? h->topo.type[sp] : -1;
+                    const int want_ty = lean_bend(k) ? SPRING_BENDING : (lean_shear(k) ? SPRING_SHEARING : SPRING_STRUCTURAL);
+                    if (have != want || ty != want_ty) h->lean_stencil_ok = false;
+                    slot++;
+                }
+                if (slot < HK_SLOTS && h->lean_stencil_ok && (gather[(size_t)slot * h->Ppad + i] & HK_VALID)) h->lean_stencil_ok = false;
+            }
+            if (!h->lean_stencil_ok) h->lean = false;
+        }
         // the cell-ordered record copy for the collision pre-check is taken only if it does not cost the table its place
         h->cell_copy = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, h->tab, 1).total <= budget ? 1 : 0;
         if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) h->cell_copy = h->cell_copy && atoi(t);
         h->lds_bytes = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, h->tab, h->cell_copy).total;
+        h->lay_std = {h->tab, h->rest_reg, h->cell_copy, h->lds_bytes};
+        if (h->lean) {                                   // the lean layout: window table streamed from L2, 33 KB of LDS
+            int cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, 1).total <= 53 * 1024 ? 1 : 0;
+            if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) cc = cc && atoi(t);
+            h->lay_lean = {0, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, cc).total};
+            // the in-kernel metrics borrow the region behind the episode state (clothhip_fused_supported): it must hold them here too
+            int NS_ = 1; while (NS_ < h->P) NS_ <<= 1;
+            const LdsLayout ll(tsz, h->Ppad, h->Spad, h->HT, 0, cc);
+            if (ll.total - ll.wtab < 2 * NS_ * tsz + (2 * (h->Ppad + 8) + 64) * 8) h->lean = false;
+        }
         if (h->lds_bytes > 160 * 1024) { free_handle(h); return fail(CLOTHHIP_EINVAL, "n_side %d needs %d B of LDS (> 160 KiB)", h->N, h->lds_bytes); }
+        if (h->lean) {                                   // the lean kernels too (which layout runs is decided per launch)
+            const clothhip_handle::Layout keep = {h->tab, h->rest_reg, h->cell_copy, h->lds_bytes};
+            h->tab = h->lay_lean.tab; h->rest_reg = h->lay_lean.rest_reg;
+            for (int f = 0; f < 3; f++) {
+                const void *fl = stepper_fn(h, f);
+                if (!fl) { free_handle(h); return fail(CLOTHHIP_EINVAL, "no lean stepper variant for n_side %d", h->N); }
+                HC(hipFuncSetAttribute(fl, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            }
+            h->tab = keep.tab; h->rest_reg = keep.rest_reg;
+        }
         const void *fn = stepper_fn(h, 0), *fnf = stepper_fn(h, 1), *fnf2 = stepper_fn(h, 2);
         if (!fn || !fnf || !fnf2) { free_handle(h); return fail(CLOTHHIP_EINVAL, "no stepper variant for n_side %d", h->N); }
         HC(hipFuncSetAttribute(fnf, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -409,6 +467,7 @@ extern "C" int clothhip_set_state(clothhip_handle *h, int32_t env0, int32_t n, c
         char *dst = (char *)h->d_rest + (rest_shared ? 0 : (size_t)env0 * h->Spad * h->tsz);
         HIPCHECK(hipMemcpy(dst, buf.data(), buf.size(), hipMemcpyHostToDevice));
         h->rest_stride = rest_shared ? 0 : h->Spad;
+        h->lean_dirty = true;
     }
     return 0;
 }
@@ -466,6 +525,7 @@ extern "C" int clothhip_reset_flat(clothhip_handle *h, const uint8_t *mask) {
         hipLaunchKernelGGL(k_reset_flat<float>, dim3(h->E), dim3(256), 0, h->stream, (float *)h->d_pos, (float *)h->d_prev, h->d_cnt,
                            h->d_tear, (const float *)h->d_flat, mask ? h->d_active : nullptr, h->Ppad, (float *)h->d_rest,
                            (const float *)h->d_flat_rest, h->rest_stride, h->Spad);
+    h->lean_dirty = true;
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(h->stream));
     return 0;
@@ -557,16 +617,44 @@ template <typename T> static StepArgs<T> make_args(clothhip_handle *h, const Clo
     a.HT = h->HT; a.ht_bits = h->ht_bits;
     a.rest_stride = h->rest_stride; a.phase_mask = h->phase_mask;
     a.k = make_consts<T>(h->prm);
+    a.pal_struct = (T)h->pal[SPRING_STRUCTURAL]; a.pal_shear = (T)h->pal[SPRING_SHEARING]; a.pal_bend = (T)h->pal[SPRING_BENDING];
     a.fz = nullptr;
     return a;
 }
 
+// Which stepper runs the next launch: the LEAN variant (three cloths per CU) when this handle wants it and the device's shared
+// rest table is a three-value palette (re-checked whenever the table may have changed: per-env tables, i.e. tier 2, or odd
+// rest lengths uploaded by the caller switch back), else the standard variant. LDS is rebuilt by every launch, so the layout
+// may change from one launch to the next.
+static int lean_refresh(clothhip_handle *h) {
+    if (!h->lean) return 0;
+    if (h->lean_dirty) {
+        h->lean_dirty = false; h->lean_ok = false;
+        if (h->rest_stride == 0) {
+            std::vector<float> r((size_t)h->Spad);
+            HIPCHECK(hipStreamSynchronize(h->stream));
+            HIPCHECK(hipMemcpy(r.data(), h->d_rest, r.size() * 4, hipMemcpyDeviceToHost));
+            bool have[3] = {false, false, false}, ok = true;
+            for (int sp = 0; sp < h->S && ok; sp++) {
+                const int ty = h->topo.type[sp];
+                const float v = r[h->wt.slot_of[sp]];
+                if (!have[ty]) { h->pal[ty] = v; have[ty] = true; }
+                else if (memcmp(&h->pal[ty], &v, 4) != 0) ok = false;
+            }
+            h->lean_ok = ok && have[0] && have[1] && have[2];
+        }
+    }
+    const clothhip_handle::Layout &L = (h->lean_ok && h->rest_stride == 0) ? h->lay_lean : h->lay_std;
+    h->tab = L.tab; h->rest_reg = L.rest_reg; h->cell_copy = L.cell_copy; h->lds_bytes = L.lds_bytes;
+    return 0;
+}
+
 // compile-time variants: (threads per cloth, particles per thread) x tables-in-LDS level x rest-in-registers
 #ifdef CLOTHHIP_FAST_BUILD           // development builds: the 25x25 variants only (make fast)
-#define CLOTH_VARIANTS(X, T) X(T, 256, 3, 1, true) X(T, 256, 3, 1, false) X(T, 256, 3, 0, false)
+#define CLOTH_VARIANTS(X, T) X(T, 256, 3, 1, true) X(T, 256, 3, 1, false) X(T, 256, 3, 0, false) X(T, 256, 3, 0, true)
 #else
 #define CLOTH_VARIANTS(X, T)                                              \
-    X(T, 256, 3, 1, true) X(T, 256, 3, 1, false) X(T, 256, 3, 0, false)   \
+    X(T, 256, 3, 1, true) X(T, 256, 3, 1, false) X(T, 256, 3, 0, false) X(T, 256, 3, 0, true)  \
     X(T, 512, 5, 0, false) X(T, 512, 5, 1, false) X(T, 1024, 3, 0, false) X(T, 1024, 4, 0, false)
 #endif
 
@@ -584,6 +672,7 @@ static const void *stepper_fn(const clothhip_handle *h, int fused) {
 }
 
 template <typename T, int FUSED> static void launch_run(clothhip_handle *h, const ClothSchedule *d_sched, const void *d_fz) {
+    (void)lean_refresh(h);                           // lean layout: which of its two variants may run now
     StepArgs<T> a = make_args<T>(h, d_sched);
     a.fz = (const FusedArgs<T> *)d_fz;
 #define X(T_, NT, PPT, TAB, RR)                                                                         \

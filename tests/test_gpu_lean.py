@@ -1,0 +1,50 @@
+"""The LEAN stepper variant (fp32, flat tiers; three cloths per CU: chosen by clothhip_create for batches it pays for, forced here
+with CLOTHHIP_DEBUG_LEAN): the gather stencil recomputed from the grid position and rest lengths from a three-value palette are a
+different HOME for the same numbers, not different arithmetic -- its records and particles equal the standard fp32 variant's bit
+for bit, over whole episode launches with resets and over the per-step path; and it steps aside (standard variant, same results)
+when the rest table is not a palette (tier 2: per-env rest lengths)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(tier, lean, monkeypatch, E=48, T=5):
+    import bench
+    from gym_cloth_amd.envs import ClothVecEnv
+    monkeypatch.setenv("CLOTHHIP_DEBUG_LEAN", "1" if lean else "0")
+    cfg = bench.bench_cfg(25, 0.02, tier)
+    env = ClothVecEnv(cfg, n_envs=E, precision="f32", consume_domrand_draws=False)
+    for e in range(E):
+        env.np_randoms[e] = np.random.RandomState(1000 + e)
+    env.reset()
+    acts = np.ascontiguousarray(np.stack([np.random.RandomState(2000 + e).uniform(-1, 1, size=(T, 4)) for e in range(E)], axis=1))
+    out = env.step_many(acts, auto_reset=True)                       # episode launch: actions, terminal tests, in-kernel resets
+    a = np.stack([np.random.RandomState(3000 + e).uniform(-1, 1, size=4) for e in range(E)])
+    obs, rew, done, info = env.step(a, auto_reset=False)              # the per-step path (plain stepper variant)
+    res = dict(rew=out["rew"].copy(), executed=out["executed"].copy(), done=out["done"].copy(), cov=out["actual_coverage"].copy(),
+               obs=out["obs"].copy(), obs2=obs.copy(), rew2=rew.copy(), exec2=env.last_executed.copy(),
+               state=[x.copy() for x in env.batch.get_state()])
+    env.close()
+    return res
+
+
+@pytest.mark.parametrize("tier", ["tier1", "tier3"])
+def test_lean_variant_is_bit_identical_to_the_standard_f32_variant(tier, monkeypatch):
+    a = _run(tier, False, monkeypatch)
+    b = _run(tier, True, monkeypatch)
+    assert a["executed"].sum() > 100000 and a["exec2"].sum() > 10000
+    for k in a:
+        if k == "state":
+            for x, y in zip(a[k], b[k]):
+                assert np.array_equal(x, y), k
+        else:
+            assert np.array_equal(a[k], b[k]), k
+
+
+def test_lean_handle_steps_aside_for_per_env_rest_tables(monkeypatch):
+    """Tier 2 gives every env its own rest lengths: no palette. A handle that wants the lean variant runs the standard one then."""
+    a = _run("tier2", False, monkeypatch, E=24, T=3)
+    b = _run("tier2", True, monkeypatch, E=24, T=3)
+    for k in ("rew", "executed", "obs", "obs2", "exec2"):
+        assert np.array_equal(a[k], b[k]), k
