@@ -543,10 +543,10 @@ def main():
                       n_side=25, E=512, precision=args.precision, init="tier2", mode=args.mode, steps=10, warmup=5, fuse_max=10,
                       step_ms=args.step_ms, **k5)
         if args.envs < 2048 and args.n_side == 25:
-            companion("2048 cloths per GPU (LEAN stepper variant, 3 cloths per CU: 2.67 generations of 768 workgroups per launch)",
+            companion("2048 cloths per GPU (LEAN stepper variant, 4 cloths per CU: two generations of 1024 workgroups per launch)",
                       n_side=25, E=2048, precision=args.precision, init="tier1", mode="fused", steps=5, warmup=0, fuse_max=5,
-                      step_ms=4 * args.step_ms, **k5)
-            companion("1536 cloths per GPU (LEAN stepper variant: two full generations of 768 workgroups per launch)",
+                      step_ms=3.4 * args.step_ms, **k5)
+            companion("1536 cloths per GPU (LEAN stepper variant, 3 cloths per CU: two generations of 768 workgroups per launch)",
                       n_side=25, E=1536, precision=args.precision, init="tier1", mode="fused", steps=5, warmup=0, fuse_max=5,
                       step_ms=3 * args.step_ms, **k5)
         if args.n_side == 25:

@@ -752,9 +752,9 @@ __device__ __forceinline__ void metrics_block(const Src &src, int P, int NS, int
 //   FUSED: 0 = one externally decoded schedule per env (clothhip_run); 1 = whole episodes per launch (clothhip_run_actions)
 //          with the resets of the flat tiers 1 and 3; 2 = also tier-2 resets. (The tier-2 reset code is cold, but its presence
 //          costs the substep loop registers: -7 % on the headline workload, so it is compiled in only where it is asked for.)
-// LEAN variant (TAB == 0 with REST_REG, fp32): the 12-slot gather stencil of a particle is recomputed from its grid position
-// instead of being held in 36 registers, and rest lengths come from a three-value palette instead of 36 more: the stepper then
-// fits 168 VGPRs and three cloths share a CU. Position k of the stencil = the k-th incident spring in ascending list index when
+// LEAN variant (TAB <= 0 with REST_REG, fp32): the 12-slot gather stencil of a particle is recomputed from its grid position
+// instead of being held in 36 registers, and rest lengths come from a three-value palette instead of 36 more: the stepper is then
+// compiled for 168 VGPRs (TAB 0: three cloths share a CU) or 128 (TAB -1: four). Position k of the stencil = the k-th incident spring in ascending list index when
 // all twelve exist (cloth.pyx:134-146: the six springs the point owns, then those its later neighbours own):
 //   k      0    1    2      3      4     5    6   7    8      9    10     11
 //   nbr   -N   -1   -N-1   -N+1   -2N   -2   +1  +2   +N-1   +N   +N+1   +2N      (index i = r*N + c)
@@ -775,7 +775,7 @@ __host__ __device__ inline uint32_t lean_valid_mask(int r, int c, int N) {
 }
 
 template <typename T, int NT, int PPT, int TAB, bool REST_REG, int FUSED>
-__global__ __launch_bounds__(NT, ((TAB == 0 && REST_REG && sizeof(T) == 4) ? 3 : (NT <= 512 ? 2 : NT / 256))) void k_run_schedule(StepArgs<T> A) {
+__global__ __launch_bounds__(NT, ((TAB <= 0 && REST_REG && sizeof(T) == 4) ? (TAB < 0 ? 4 : 3) : (NT <= 512 ? 2 : NT / 256))) void k_run_schedule(StepArgs<T> A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int e = blockIdx.x;
     const int tid = threadIdx.x;
@@ -818,7 +818,7 @@ __global__ __launch_bounds__(NT, ((TAB == 0 && REST_REG && sizeof(T) == 4) ? 3 :
     T pvx[PPT], pvy[PPT], pvz[PPT];         // previous positions of the owned particles
     // their incident-spring gather entries (static): in registers for fp32; the fp64 instantiation has no room
     // (they ended up in scratch, reloaded one by one) and re-reads the L2-resident table, 12 loads in flight
-    constexpr bool LEAN = TAB == 0 && REST_REG && sizeof(T) == 4;
+    constexpr bool LEAN = TAB <= 0 && REST_REG && sizeof(T) == 4;      // TAB 0: compiled for three cloths per CU (168 VGPRs), TAB -1: for four (128)
     constexpr bool GT_REG = sizeof(T) == 4 && !LEAN;
     constexpr bool REST_R = REST_REG && !LEAN;
     uint32_t gt[GT_REG ? PPT : 1][HK_SLOTS];

@@ -62,6 +62,7 @@ struct clothhip_handle {
     // It needs ONE shared rest table whose fp32 values are one per spring type (checked on the device's table whenever that table
     // may have changed) and the regular gather stencil (checked once); otherwise the (0, false) variant runs on the same layout.
     bool lean = false, lean_dirty = true, lean_ok = false, lean_stencil_ok = false;
+    int lean_r = 3;         // cloths per CU the chosen LEAN build is compiled for (3: 168 VGPRs, 4: 128 VGPRs)
     float pal[3] = {0, 0, 0};
     struct Layout { int tab; bool rest_reg; int cell_copy; int lds_bytes; } lay_std = {0, false, 0, 0}, lay_lean = {0, true, 0, 0};
     double *d_levels = nullptr, *d_xy = nullptr, *d_radius = nullptr, *d_cov = nullptr, *d_vinv = nullptr;
@@ -286,16 +287,27 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
         if (const char *t = getenv("CLOTHHIP_DEBUG_TAB_LDS")) h->tab = std::min(h->tab, atoi(t));
         h->rest_reg = (h->nt == 256 && precision == CLOTHHIP_F32 && h->tab == 1);
         if (const char *t = getenv("CLOTHHIP_DEBUG_REST_REG")) h->rest_reg = h->rest_reg && atoi(t);
-        // LEAN variant: three cloths per CU instead of two, each stepping at 84 % of the standard variant's rate (measured). A
-        // launch runs its cloths in generations of what is resident, so it pays when ceil(E / 2 CUs) / ceil(E / 3 CUs) > 1.19.
+        // LEAN variant: three or four cloths per CU instead of two, each stepping at 84 % / 58.5 % of the standard variant's rate
+        // (measured: 31.1 k, 26.1 k, 18.2 k substeps/s per resident cloth). A launch runs its cloths in generations of what is
+        // resident, so the batch size decides: the largest rate_r / ceil(E / (r * CUs)) wins.
         {
             hipDeviceProp_t dp;
             int cus = 256;
             if (hipGetDeviceProperties(&dp, device) == hipSuccess && dp.multiProcessorCount > 0) cus = dp.multiProcessorCount;
-            const int g2 = (h->E + 2 * cus - 1) / (2 * cus), g3 = (h->E + 3 * cus - 1) / (3 * cus);
-            h->lean = h->nt == 256 && precision == CLOTHHIP_F32 && (double)g2 > 1.19 * (double)g3;
+            const double rate[3] = {1.0, 0.84, 0.585};
+            double best = 0.0; int best_r = 2;
+            for (int r = 2; r <= 4; r++) {
+                const double v = rate[r - 2] / (double)((h->E + r * cus - 1) / (r * cus));
+                if (v > best * 1.02) { best = v; best_r = r; }
+            }
+            h->lean = h->nt == 256 && precision == CLOTHHIP_F32 && best_r > 2;
+            h->lean_r = best_r > 2 ? best_r : 3;
         }
-        if (const char *t = getenv("CLOTHHIP_DEBUG_LEAN")) h->lean = h->nt == 256 && precision == CLOTHHIP_F32 && atoi(t) != 0;
+        if (const char *t = getenv("CLOTHHIP_DEBUG_LEAN")) {      // 0: never, 3 (or 1) / 4: that build whatever the batch size
+            const int v = atoi(t);
+            h->lean = h->nt == 256 && precision == CLOTHHIP_F32 && v != 0;
+            if (v != 0) h->lean_r = v == 4 ? 4 : 3;
+        }
         if (h->lean) {
             // the arithmetic stencil of the LEAN kernel against the gather table built from the reference's spring list
             h->lean_stencil_ok = true;
@@ -324,9 +336,9 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
         h->lds_bytes = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, h->tab, h->cell_copy).total;
         h->lay_std = {h->tab, h->rest_reg, h->cell_copy, h->lds_bytes};
         if (h->lean) {                                   // the lean layout: window table streamed from L2, 33 KB of LDS
-            int cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, 1).total <= 53 * 1024 ? 1 : 0;
+            int cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, 1).total <= (h->lean_r == 4 ? 40 : 53) * 1024 ? 1 : 0;
             if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) cc = cc && atoi(t);
-            h->lay_lean = {0, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, cc).total};
+            h->lay_lean = {h->lean_r == 4 ? -1 : 0, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, cc).total};
             // the in-kernel metrics borrow the region behind the episode state (clothhip_fused_supported): it must hold them here too
             int NS_ = 1; while (NS_ < h->P) NS_ <<= 1;
             const LdsLayout ll(tsz, h->Ppad, h->Spad, h->HT, 0, cc);
@@ -651,10 +663,10 @@ static int lean_refresh(clothhip_handle *h) {
 
 // compile-time variants: (threads per cloth, particles per thread) x tables-in-LDS level x rest-in-registers
 #ifdef CLOTHHIP_FAST_BUILD           // development builds: the 25x25 variants only (make fast)
-#define CLOTH_VARIANTS(X, T) X(T, 256, 3, 1, true) X(T, 256, 3, 1, false) X(T, 256, 3, 0, false) X(T, 256, 3, 0, true)
+#define CLOTH_VARIANTS(X, T) X(T, 256, 3, 1, true) X(T, 256, 3, 1, false) X(T, 256, 3, 0, false) X(T, 256, 3, 0, true) X(T, 256, 3, -1, true)
 #else
 #define CLOTH_VARIANTS(X, T)                                              \
-    X(T, 256, 3, 1, true) X(T, 256, 3, 1, false) X(T, 256, 3, 0, false) X(T, 256, 3, 0, true)  \
+    X(T, 256, 3, 1, true) X(T, 256, 3, 1, false) X(T, 256, 3, 0, false) X(T, 256, 3, 0, true) X(T, 256, 3, -1, true)  \
     X(T, 512, 5, 0, false) X(T, 512, 5, 1, false) X(T, 1024, 3, 0, false) X(T, 1024, 4, 0, false)
 #endif
 

@@ -1,5 +1,5 @@
-"""The LEAN stepper variant (fp32, flat tiers; three cloths per CU: chosen by clothhip_create for batches it pays for, forced here
-with CLOTHHIP_DEBUG_LEAN): the gather stencil recomputed from the grid position and rest lengths from a three-value palette are a
+"""The LEAN stepper variant (fp32, flat tiers; compiled for three and for four cloths per CU: chosen by clothhip_create for batches
+it pays for, forced here with CLOTHHIP_DEBUG_LEAN): the gather stencil recomputed from the grid position and rest lengths from a three-value palette are a
 different HOME for the same numbers, not different arithmetic -- its records and particles equal the standard fp32 variant's bit
 for bit, over whole episode launches with resets and over the per-step path; and it steps aside (standard variant, same results)
 when the rest table is not a palette (tier 2: per-env rest lengths)."""
@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 def _run(tier, lean, monkeypatch, E=48, T=5):
     import bench
     from gym_cloth_amd.envs import ClothVecEnv
-    monkeypatch.setenv("CLOTHHIP_DEBUG_LEAN", "1" if lean else "0")
+    monkeypatch.setenv("CLOTHHIP_DEBUG_LEAN", str(lean) if lean else "0")           # 3 / 4: the build for three / four cloths per CU
     cfg = bench.bench_cfg(25, 0.02, tier)
     env = ClothVecEnv(cfg, n_envs=E, precision="f32", consume_domrand_draws=False)
     for e in range(E):
@@ -29,10 +29,10 @@ def _run(tier, lean, monkeypatch, E=48, T=5):
     return res
 
 
-@pytest.mark.parametrize("tier", ["tier1", "tier3"])
-def test_lean_variant_is_bit_identical_to_the_standard_f32_variant(tier, monkeypatch):
-    a = _run(tier, False, monkeypatch)
-    b = _run(tier, True, monkeypatch)
+@pytest.mark.parametrize("tier,build", [("tier1", 3), ("tier3", 3), ("tier1", 4)])
+def test_lean_variant_is_bit_identical_to_the_standard_f32_variant(tier, build, monkeypatch):
+    a = _run(tier, 0, monkeypatch)
+    b = _run(tier, build, monkeypatch)
     assert a["executed"].sum() > 100000 and a["exec2"].sum() > 10000
     for k in a:
         if k == "state":
@@ -44,7 +44,7 @@ def test_lean_variant_is_bit_identical_to_the_standard_f32_variant(tier, monkeyp
 
 def test_lean_handle_steps_aside_for_per_env_rest_tables(monkeypatch):
     """Tier 2 gives every env its own rest lengths: no palette. A handle that wants the lean variant runs the standard one then."""
-    a = _run("tier2", False, monkeypatch, E=24, T=3)
-    b = _run("tier2", True, monkeypatch, E=24, T=3)
+    a = _run("tier2", 0, monkeypatch, E=24, T=3)
+    b = _run("tier2", 3, monkeypatch, E=24, T=3)
     for k in ("rew", "executed", "obs", "obs2", "exec2"):
         assert np.array_equal(a[k], b[k]), k
