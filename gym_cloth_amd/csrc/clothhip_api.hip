@@ -663,17 +663,20 @@ static int lean_refresh(clothhip_handle *h) {
 
 // compile-time variants: (threads per cloth, particles per thread) x tables-in-LDS level x rest-in-registers
 #ifdef CLOTHHIP_FAST_BUILD           // development builds: the 25x25 variants only (make fast)
-#define CLOTH_VARIANTS(X, T) X(T, 256, 3, 1, true) X(T, 256, 3, 1, false) X(T, 256, 3, 0, false) X(T, 256, 3, 0, true) X(T, 256, 3, -1, true)
+#define CLOTH_VARIANTS(X, T) X(T, 256, 3, 1, true) X(T, 256, 3, 1, false) X(T, 256, 3, 0, false)
 #else
 #define CLOTH_VARIANTS(X, T)                                              \
-    X(T, 256, 3, 1, true) X(T, 256, 3, 1, false) X(T, 256, 3, 0, false) X(T, 256, 3, 0, true) X(T, 256, 3, -1, true)  \
+    X(T, 256, 3, 1, true) X(T, 256, 3, 1, false) X(T, 256, 3, 0, false)   \
     X(T, 512, 5, 0, false) X(T, 512, 5, 1, false) X(T, 1024, 3, 0, false) X(T, 1024, 4, 0, false)
 #endif
+// the LEAN builds (fp32 only: three / four cloths per CU)
+#define CLOTH_VARIANTS_LEAN(X, T) X(T, 256, 3, 0, true) X(T, 256, 3, -1, true)
 
 template <typename T, int FUSED> static const void *stepper_fn_t(const clothhip_handle *h) {
 #define X(T_, NT, PPT, TAB, RR) \
     if (h->nt == NT && h->ppt == PPT && h->tab == TAB && h->rest_reg == RR) return (const void *)k_run_schedule<T_, NT, PPT, TAB, RR, FUSED>;
     CLOTH_VARIANTS(X, T)
+    if constexpr (sizeof(T) == 4) { CLOTH_VARIANTS_LEAN(X, T) }
 #undef X
     return nullptr;
 }
@@ -693,6 +696,7 @@ template <typename T, int FUSED> static void launch_run(clothhip_handle *h, cons
         return;                                                                                         \
     }
     CLOTH_VARIANTS(X, T)
+    if constexpr (sizeof(T) == 4) { CLOTH_VARIANTS_LEAN(X, T) }
 #undef X
 }
 
