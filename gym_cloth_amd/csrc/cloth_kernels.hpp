@@ -1334,7 +1334,13 @@ __global__ __launch_bounds__(NT, ((TAB <= 0 && REST_REG && sizeof(T) == 4) ? (TA
         {
         const T dz_up = (T)sc.dz_up, dxp = (T)sc.dx_pull, dyp = (T)sc.dy_pull, dzp = (T)sc.dz_pull;
         const bool sliced = FUSED && Fp->budget_ticks != 0 && Fp->resume != nullptr;
+    const int tid_outer_ = tid;
     for (int it = resumed_run ? resume_it : 0; it < sc.n_total; it++) {
+        // LEAN: everything derived from the thread index (LDS addresses of the owned particles, table offsets) is formed anew in
+        // every substep instead of being hoisted out of the loop and held -- or spilled -- for the whole schedule
+        int tid = tid_outer_;
+        if (LEAN) asm volatile("" : "+v"(tid));
+        const int lane = tid & 63;
 
         // ---- ClothEnv._pull (cloth_env.py:352-367): adjust / nothing / release -------------------
         int mode = 0; T ax = 0, ay = 0, az = 0;

@@ -287,14 +287,14 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
         if (const char *t = getenv("CLOTHHIP_DEBUG_TAB_LDS")) h->tab = std::min(h->tab, atoi(t));
         h->rest_reg = (h->nt == 256 && precision == CLOTHHIP_F32 && h->tab == 1);
         if (const char *t = getenv("CLOTHHIP_DEBUG_REST_REG")) h->rest_reg = h->rest_reg && atoi(t);
-        // LEAN variant: three or four cloths per CU instead of two, each stepping at 84 % / 58.5 % of the standard variant's rate
-        // (measured: 31.1 k, 26.1 k, 18.2 k substeps/s per resident cloth). A launch runs its cloths in generations of what is
+        // LEAN variant: three or four cloths per CU instead of two, each stepping at 85 % / 72 % of the standard variant's rate
+        // (measured: 31.1 k, 26.4 k, 22.4 k substeps/s per resident cloth). A launch runs its cloths in generations of what is
         // resident, so the batch size decides: the largest rate_r / ceil(E / (r * CUs)) wins.
         {
             hipDeviceProp_t dp;
             int cus = 256;
             if (hipGetDeviceProperties(&dp, device) == hipSuccess && dp.multiProcessorCount > 0) cus = dp.multiProcessorCount;
-            const double rate[3] = {1.0, 0.84, 0.585};
+            const double rate[3] = {1.0, 0.85, 0.72};
             double best = 0.0; int best_r = 2;
             for (int r = 2; r <= 4; r++) {
                 const double v = rate[r - 2] / (double)((h->E + r * cus - 1) / (r * cus));
