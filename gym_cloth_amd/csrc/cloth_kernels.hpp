@@ -1336,10 +1336,10 @@ __global__ __launch_bounds__(NT, ((TAB <= 0 && REST_REG && sizeof(T) == 4) ? (TA
         const bool sliced = FUSED && Fp->budget_ticks != 0 && Fp->resume != nullptr;
     const int tid_outer_ = tid;
     for (int it = resumed_run ? resume_it : 0; it < sc.n_total; it++) {
-        // LEAN: everything derived from the thread index (LDS addresses of the owned particles, table offsets) is formed anew in
+        // LEAN and fp64: everything derived from the thread index (LDS addresses of the owned particles, table offsets) is formed anew in
         // every substep instead of being hoisted out of the loop and held -- or spilled -- for the whole schedule
         int tid = tid_outer_;
-        if (LEAN) asm volatile("" : "+v"(tid));
+        if (LEAN || sizeof(T) == 8) asm volatile("" : "+v"(tid));     // (fp64: 65 -> 0 spilled registers in the episode variant)
         const int lane = tid & 63;
 
         // ---- ClothEnv._pull (cloth_env.py:352-367): adjust / nothing / release -------------------
