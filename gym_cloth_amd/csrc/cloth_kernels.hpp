@@ -1339,7 +1339,7 @@ __global__ __launch_bounds__(NT, ((TAB <= 0 && REST_REG && sizeof(T) == 4) ? (TA
         // LEAN and fp64: everything derived from the thread index (LDS addresses of the owned particles, table offsets) is formed anew in
         // every substep instead of being hoisted out of the loop and held -- or spilled -- for the whole schedule
         int tid = tid_outer_;
-        if (LEAN || sizeof(T) == 8) asm volatile("" : "+v"(tid));     // (fp64: 65 -> 0 spilled registers in the episode variant)
+        if (LEAN || sizeof(T) == 8 || NT >= 512) asm volatile("" : "+v"(tid));     // (fp64: 65 -> 0 spilled registers; 50x50: +3 %)
         const int lane = tid & 63;
 
         // ---- ClothEnv._pull (cloth_env.py:352-367): adjust / nothing / release -------------------
