@@ -206,6 +206,24 @@ __device__ __forceinline__ int wave_incl_min(int v) {
     t = __builtin_amdgcn_update_dpp(v, v, 0x143, 0xC, 0xF, false); v = t < v ? t : v;     // lane 31 -> rows 2,3
     return v;
 }
+// fp32 sums over lanes by DPP (no LDS round trips): the whole wave's total (uniform), and the total of each row of 16 lanes
+// in every lane of the row (rotations: row_ror 8, 4, 2, 1)
+__device__ __forceinline__ float wave_sum_f32(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, true));     // lane 15 of rows 0,2 -> rows 1,3
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, true));     // lane 31 -> rows 2,3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float row_allsum_f32(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, true));     // row_ror:8
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xF, 0xF, true));     // row_ror:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xF, 0xF, true));     // row_ror:2
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xF, 0xF, true));     // row_ror:1
+    return v;
+}
 // relative slack of the conservative "could this comparison against a sqrt be true" pre-filters
 template <typename T> __device__ __forceinline__ T filt_slack();
 template <> __device__ __forceinline__ double filt_slack<double>() { return 1e-9; }
@@ -289,7 +307,7 @@ template <typename T, bool LDS_TAB, bool TIMED, bool STATS, bool TIC>
 __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const uint32_t *g_ent, const T *g_rest,
                                             const unsigned long long *g_dep, int w0, int w_end,
                                             int nW, int rshift, const DevConsts<T> &k, int lane, int &st_windows, int &st_passes, int &st_commits,
-                                            unsigned long long *tph) {
+                                            unsigned long long *tph, unsigned long long fmask = 0ull) {
     constexpr int PF = LDS_TAB ? 1 : 3;          // entry stream: windows read ahead
     constexpr int PD = sizeof(T) == 4 ? 3 : 2;   // dependency words (always from L2 / L1: one table for all cloths)
     static_assert(PF + 1 <= WT_PAD_WINDOWS && PD + 1 <= WT_PAD_WINDOWS, "the table is padded by the read-ahead distance");
@@ -314,6 +332,9 @@ __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const
     struct __attribute__((aligned(16))) P3 { T x, y, z; };
     int w = w0;
     if (w > w_end) return tear;
+#ifdef CLOTHHIP_CELL_COUNTERS
+    int corr_end_ = w0 - 1;                      // census: the last window a correction made so far can reach
+#endif
     // fp32: the particle records of the NEXT window are read while this window's passes run; they are good unless this window
     // corrected something (then they are read again): most windows of a walk correct nothing. (fp64: the sixteen registers
     // this costs are spilled, measured -2 %; there the records are read when the window starts.)
@@ -348,6 +369,9 @@ __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const
         const uint32_t dlo = (uint32_t)dep, dhi = (uint32_t)(dep >> 32);
         bool pl = true;                                             // this lane's spring is not finished
         if (STATS) st_windows++;
+#ifdef CLOTHHIP_CELL_COUNTERS
+        if (w > corr_end_ && !((fmask >> (w & 63)) & 1ull)) tph[3] += 64;   // census: no flagged spring, beyond every correction's reach
+#endif
         bool more;
         do {
             unsigned long long td0 = 0;
@@ -385,6 +409,9 @@ __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const
                 // every correction of the window may move particles whose springs sit as far as the window's reach
                 const int reach = w + ((int)((uint32_t)__builtin_amdgcn_readfirstlane((int)ab) >> WT_REACH_SHIFT) << rshift);
                 w_end = reach > w_end ? reach : w_end;
+#ifdef CLOTHHIP_CELL_COUNTERS
+                corr_end_ = reach > corr_end_ ? reach : corr_end_;
+#endif
                 dirty = true;
                 if (STATS) st_commits++;
                 if (trig & pl & !bad) {
@@ -426,7 +453,7 @@ __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const
 template <typename T>
 __device__ __forceinline__ int collide_cell_wave(Pt<T> *cur, uint16_t *m, const uint16_t *slot, int n,
                                                  const DevConsts<T> &k, int lane) {
-    int visits_ = 0;                                 // (profiling builds only read it)
+    int visits_ = 0, hits_ = 0;                      // (profiling builds only read them)
     const bool in = lane < n;
     const int mine = in ? (int)m[lane] : 0x7fff;
     int rank = 0;
@@ -461,19 +488,28 @@ __device__ __forceinline__ int collide_cell_wave(Pt<T> *cur, uint16_t *m, const 
         if (hit) {
             const T dist = dev_sqrt<T>(d2);                                             // :327
             hit = dist <= k.thresh;                                                     // :330
-            const T factor = dev_div<T>(k.thresh - dist, dist);                         // :331
+            const T factor = hit ? dev_div<T>(k.thresh - dist, dist) : (T)0;            // :331
             fx = dx * factor; fy = dy * factor; fz = dz * factor;
         }
         unsigned long long hm = ballot64(hit);
         if (!hm) continue;
         T tx = (T)0, ty = (T)0, tz = (T)0;
         int nh = 0;
+#ifndef CLOTHHIP_SERIAL_HITSUM
+        if constexpr (sizeof(T) == 4) {
+            // fp32 (parity is a tolerance): the hits' contributions (zero in the other lanes) summed by a DPP tree instead of one by
+            // one in ascending order -- the Gauss-Seidel visiting order is untouched, only the association of this one sum differs
+            tx = wave_sum_f32(fx); ty = wave_sum_f32(fy); tz = wave_sum_f32(fz);
+            nh = (int)__popcll(hm);
+        } else
+#endif
         while (hm) {                                                                    // ascending candidate order
             const int b = __builtin_amdgcn_readfirstlane(__ffsll((long long)hm) - 1);
             tx += bcast(fx, b); ty += bcast(fy, b); tz += bcast(fz, b);
             nh++;
             hm &= hm - 1ull;
         }
+        hits_ += nh;
         const T nf = (T)nh;                                                             // :336-343
         const T nxa = xa + dev_div<T>(dev_div<T>(tx, nf), k.sim_steps);
         const T nya = ya + dev_div<T>(dev_div<T>(ty, nf), k.sim_steps);
@@ -482,7 +518,7 @@ __device__ __forceinline__ int collide_cell_wave(Pt<T> *cur, uint16_t *m, const 
         todo |= ballot64(free_ && lane > a && !(d2 > thr2c));                           // a moved: later neighbours must look
     }
     if (moved) cur[i] = Pt<T>{x, y, z, me.w};
-    return visits_;
+    return visits_ | (hits_ << 16);
 }
 
 // 64/GSZ cells of at most GSZ (16 or 32) members each at once, one per GSZ-lane group of the wave; same exact
@@ -526,13 +562,19 @@ __device__ __forceinline__ void collide_cells_group(Pt<T> *cur, uint16_t *memb, 
         if (hit) {
             const T dist = dev_sqrt<T>(d2);                                             // :327
             hit = dist <= k.thresh;                                                     // :330
-            const T factor = dev_div<T>(k.thresh - dist, dist);                         // :331
+            const T factor = hit ? dev_div<T>(k.thresh - dist, dist) : (T)0;            // :331
             fx = dx * factor; fy = dy * factor; fz = dz * factor;
         }
         unsigned int hm = (unsigned int)((ballot64(hit) >> gsh) & GM);
         if (!__any(hm != 0u)) continue;
         T tx = (T)0, ty = (T)0, tz = (T)0;
         int nh = 0;
+#ifndef CLOTHHIP_SERIAL_HITSUM
+        if constexpr (sizeof(T) == 4 && GSZ == 16) {
+            tx = row_allsum_f32(fx); ty = row_allsum_f32(fy); tz = row_allsum_f32(fz);      // (see collide_cell_wave)
+            nh = __popc(hm);
+        } else
+#endif
         while (__any(hm != 0u)) {               // ascending candidate order; four hits are fetched per LDS round trip
             bool has[4]; T vx[4], vy[4], vz[4];
 #pragma unroll
@@ -775,7 +817,7 @@ __host__ __device__ inline uint32_t lean_valid_mask(int r, int c, int N) {
 }
 
 template <typename T, int NT, int PPT, int TAB, bool REST_REG, int FUSED>
-__global__ __launch_bounds__(NT, ((TAB <= 0 && REST_REG && sizeof(T) == 4) ? (TAB < 0 ? 4 : 3) : (NT <= 512 ? 2 : NT / 256))) void k_run_schedule(StepArgs<T> A) {
+__global__ __launch_bounds__(NT, (((TAB <= 0 || TAB == 2) && REST_REG && sizeof(T) == 4) ? (TAB == 2 ? (NT == 512 ? 4 : 2) : (TAB < 0 ? 4 : 3)) : (NT <= 512 ? 2 : NT / 256))) void k_run_schedule(StepArgs<T> A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int e = blockIdx.x;
     const int tid = threadIdx.x;
@@ -818,7 +860,8 @@ __global__ __launch_bounds__(NT, ((TAB <= 0 && REST_REG && sizeof(T) == 4) ? (TA
     T pvx[PPT], pvy[PPT], pvz[PPT];         // previous positions of the owned particles
     // their incident-spring gather entries (static): in registers for fp32; the fp64 instantiation has no room
     // (they ended up in scratch, reloaded one by one) and re-reads the L2-resident table, 12 loads in flight
-    constexpr bool LEAN = TAB <= 0 && REST_REG && sizeof(T) == 4;      // TAB 0: compiled for three cloths per CU (168 VGPRs), TAB -1: for four (128)
+    constexpr bool LEAN = (TAB <= 0 || TAB == 2) && REST_REG && sizeof(T) == 4;      // TAB 0: compiled for three cloths per CU (168 VGPRs), TAB -1: for four (128);
+                                                                                     // TAB 2: the LEAN arithmetic with the window table in LDS (two cloths per CU)
     constexpr bool GT_REG = sizeof(T) == 4 && !LEAN;
     constexpr bool REST_R = REST_REG && !LEAN;
     uint32_t gt[GT_REG ? PPT : 1][HK_SLOTS];
@@ -858,7 +901,7 @@ __global__ __launch_bounds__(NT, ((TAB <= 0 && REST_REG && sizeof(T) == 4) ? (TA
             for (int i = tid; i < A.Spad; i += NT) { WEnt<T> w_; w_.ab = s_ent[i]; w_.rest = s_rest[i]; d0[i] = w_; }
         }
         for (int h = tid; h < HT; h += NT) { hkey[h] = KEY_EMPTY; hco[h] = 0; }
-        if (tid == 0) { misc[0] = tear_flag; misc[1] = 0; misc[2] = 0; misc[3] = 0; misc[4] = 0; misc[5] = 0; misc[6] = 0; misc[10] = 0x7fffffff; misc[11] = -1; }
+        if (tid == 0) { misc[0] = tear_flag; misc[1] = 0; misc[2] = 0; misc[3] = 0; misc[4] = 0; misc[5] = 0; misc[6] = 0; misc[10] = 0x7fffffff; misc[11] = -1; misc[12] = 0; misc[13] = 0; misc[14] = 0; }
     };
     init_lds(A.tear[e], A.wt_ent, g_rest);
     __syncthreads();
@@ -876,7 +919,7 @@ __global__ __launch_bounds__(NT, ((TAB <= 0 && REST_REG && sizeof(T) == 4) ? (TA
 #else
     constexpr bool SWEEP_TIMED = false;
 #endif
-#ifdef CLOTHHIP_PHASE_STAMPS            // the sweep's window / pass / correction counters cost its loop three instructions per pass:
+#if defined(CLOTHHIP_PHASE_STAMPS) || defined(CLOTHHIP_CELL_COUNTERS)   // the sweep's window / pass / correction counters cost its loop three instructions per pass:
     constexpr bool SWEEP_STATS = true;  // profiling builds only (the production build counts sweeps)
 #else
     constexpr bool SWEEP_STATS = false;
@@ -1335,6 +1378,9 @@ __global__ __launch_bounds__(NT, ((TAB <= 0 && REST_REG && sizeof(T) == 4) ? (TA
         const T dz_up = (T)sc.dz_up, dxp = (T)sc.dx_pull, dyp = (T)sc.dy_pull, dzp = (T)sc.dz_pull;
         const bool sliced = FUSED && Fp->budget_ticks != 0 && Fp->resume != nullptr;
     const int tid_outer_ = tid;
+#ifdef CLOTHHIP_CELL_COUNTERS
+    bool frozen_prev_ = false;
+#endif
     for (int it = resumed_run ? resume_it : 0; it < sc.n_total; it++) {
         // LEAN and fp64: everything derived from the thread index (LDS addresses of the owned particles, table offsets) is formed anew in
         // every substep instead of being hoisted out of the loop and held -- or spilled -- for the whole schedule
@@ -1653,7 +1699,7 @@ __global__ __launch_bounds__(NT, ((TAB <= 0 && REST_REG && sizeof(T) == 4) ? (TA
             {
                 const int na = __builtin_amdgcn_readfirstlane(misc[2]);
 #ifdef CLOTHHIP_CELL_COUNTERS
-                tph[9] += 64 * na; tph[10] += 64 * nocc;
+                tph[9] += 64 * na; tph[10] += 64 * nocc; tph[0] += na == 0 ? 64 : 0;
                 tph[7] += 64 * (-__builtin_amdgcn_readlane(wave_incl_min(-nmax), 63));
 #endif
                 if (na) __builtin_amdgcn_s_setprio(2);     // serial per-cell sweeps: latency-critical like the strain sweep
@@ -1679,7 +1725,7 @@ __global__ __launch_bounds__(NT, ((TAB <= 0 && REST_REG && sizeof(T) == 4) ? (TA
                         if (n <= 64) {
                             const int nv_ = collide_cell_wave<T>(cur, m, slot, n, k, lane);
 #ifdef CLOTHHIP_CELL_COUNTERS
-                            tph[4] += 64; tph[5] += 64 * n; tph[6] += 64 * nv_;
+                            tph[4] += 64; tph[5] += 64 * n; tph[6] += 64 * (nv_ & 0xffff); tph[11] += 64 * (nv_ >> 16);
 #else
                             (void)nv_;
 #endif
@@ -1735,6 +1781,9 @@ __global__ __launch_bounds__(NT, ((TAB <= 0 && REST_REG && sizeof(T) == 4) ? (TA
                 const int i = tid + q * NT;
                 if (i >= P) continue;
                 const Pt<T> me = mq[q];
+#ifdef CLOTHHIP_CELL_COUNTERS
+                if (!w_cnt(me.w) && me.z >= k.min_z) atomicOr(&misc[12], 1);     // census: an unpinned particle the plane did not restore
+#endif
                 if (w_cnt(me.w) || me.z >= k.min_z) continue;
                 const T px = pvx[q], py = pvy[q], pz = pvz[q];
                 const T t = (k.min_z - pz) * (T)1.0;
@@ -1831,6 +1880,9 @@ __global__ __launch_bounds__(NT, ((TAB <= 0 && REST_REG && sizeof(T) == 4) ? (TA
                                     bool flag = len2 > tmin * tmin * ((T)1 + filt_slack<T>());
                                     if (!flag) { const T len = dev_sqrt<T>(len2); flag = len > t11 || len > tt; }
                                     if (flag) { nact++; pmin = (int)pos_ < pmin ? (int)pos_ : pmin; pmax = (int)pos_ > pmax ? (int)pos_ : pmax; }
+#ifdef CLOTHHIP_CELL_COUNTERS
+                                    if (flag) atomicOr(&misc[13 + (((int)pos_ >> 6) >> 5 & 1)], 1 << (((int)pos_ >> 6) & 31));
+#endif
                                 }
                             }
                         }
@@ -1844,6 +1896,9 @@ __global__ __launch_bounds__(NT, ((TAB <= 0 && REST_REG && sizeof(T) == 4) ? (TA
             }
             __syncthreads();
             TSTAMP(8)
+#ifdef CLOTHHIP_CELL_COUNTERS
+            int swept_ = 0;
+#endif
             if (tid < 64 && (misc[1] || (pm & PH_NOSKIP))) {
                 __builtin_amdgcn_s_setprio(3);            // the serial sweep is the critical path of the whole cloth
                 const bool all_ = (pm & PH_NOSKIP) != 0;
@@ -1852,17 +1907,38 @@ __global__ __launch_bounds__(NT, ((TAB <= 0 && REST_REG && sizeof(T) == 4) ? (TA
                 st_sweeps++;
                 // tear_thresh >= 1.1 (every shipped configuration): only a stretching spring can tear, the test sits in the commit
                 const bool tic = __builtin_amdgcn_readfirstlane(!(k.tear_thresh < k.c11) ? 1 : 0) != 0;
+#ifdef CLOTHHIP_CELL_COUNTERS
+                const unsigned long long fmask_ = (unsigned long long)(uint32_t)misc[13] | ((unsigned long long)(uint32_t)misc[14] << 32);
+                swept_ = 1;
+#else
+                const unsigned long long fmask_ = 0ull;
+#endif
                 const int tear = tic ? strain_sweep<T, (TAB >= 1), SWEEP_TIMED, SWEEP_STATS, true>(cur, wtab, A.wt_ent, g_rest, A.wt_dep, w0, w1, A.nW, A.wt_rshift, k,
-                                                                                                 lane, st_windows, st_passes, st_commits, tph)
+                                                                                                 lane, st_windows, st_passes, st_commits, tph, fmask_)
                                      : strain_sweep<T, (TAB >= 1), SWEEP_TIMED, SWEEP_STATS, false>(cur, wtab, A.wt_ent, g_rest, A.wt_dep, w0, w1, A.nW, A.wt_rshift, k,
-                                                                                                  lane, st_windows, st_passes, st_commits, tph);
+                                                                                                  lane, st_windows, st_passes, st_commits, tph, fmask_);
                 if (__any(tear) && lane == 0) misc[0] = 1;
                 if (lane == 0) { misc[1] = 0; misc[10] = 0x7fffffff; misc[11] = -1; }
+#ifdef CLOTHHIP_CELL_COUNTERS
+                if (lane == 0) { misc[13] = 0; misc[14] = 0; }
+#endif
                 __builtin_amdgcn_s_setprio(0);
             }
             __syncthreads();
 #ifndef CLOTHHIP_SWEEP_STAMPS          // (that build uses slots 9-11 for the sweep's passes)
             TSTAMP(9)
+#endif
+#ifdef CLOTHHIP_CELL_COUNTERS
+            // census (wave 0): a substep in which nothing was adjusted, the plane restored every unpinned particle to its old
+            // position (friction 1) and no spring was over-stretched leaves the positions as they were: tph[1] counts those,
+            // tph[2] those whose predecessor was one too (state(t+1) == state(t): a fixed point)
+            if (tid < 64) {
+                const bool frozen_ = mode != 1 && misc[12] == 0 && !swept_ && k.one_m_fric == (T)0;
+                tph[1] += frozen_ ? 64 : 0; tph[2] += (frozen_ && frozen_prev_) ? 64 : 0;
+                frozen_prev_ = frozen_;
+            }
+            __syncthreads();
+            if (tid == 0) misc[12] = 0;
 #endif
         }
         if (timing) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory"); }

@@ -307,6 +307,11 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
             const int v = atoi(t);
             h->lean = h->nt == 256 && precision == CLOTHHIP_F32 && v != 0;
             if (v != 0) h->lean_r = v == 4 ? 4 : 3;
+#ifdef CLOTHHIP_EXP_V8
+            // experiment: the LEAN arithmetic at two cloths per CU with the window table in LDS: 2 = 256 threads x 3 particles,
+            // 8 = 512 threads x 2 particles (eight waves per cloth, 128 VGPRs). No standard fallback in this build.
+            if (h->lean && (v == 2 || v == 8)) { h->lean_r = 2; if (v == 8) { h->nt = 512; h->ppt = 2; } }
+#endif
         }
         if (h->lean) {
             // the arithmetic stencil of the LEAN kernel against the gather table built from the reference's spring list
@@ -339,6 +344,12 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
             int cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, 1).total <= (h->lean_r == 4 ? 40 : 53) * 1024 ? 1 : 0;
             if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) cc = cc && atoi(t);
             h->lay_lean = {h->lean_r == 4 ? -1 : 0, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, cc).total};
+            if (h->lean_r == 2) {
+                cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 1, 1).total <= 80 * 1024 ? 1 : 0;
+                h->lay_lean = {2, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 1, cc).total};
+                h->lay_std = h->lay_lean;
+                h->tab = 2; h->rest_reg = true; h->cell_copy = cc; h->lds_bytes = h->lay_lean.lds_bytes;
+            }
             // the in-kernel metrics borrow the region behind the episode state (clothhip_fused_supported): it must hold them here too
             int NS_ = 1; while (NS_ < h->P) NS_ <<= 1;
             const LdsLayout ll(tsz, h->Ppad, h->Spad, h->HT, 0, cc);
@@ -670,7 +681,11 @@ static int lean_refresh(clothhip_handle *h) {
     X(T, 512, 5, 0, false) X(T, 512, 5, 1, false) X(T, 1024, 3, 0, false) X(T, 1024, 4, 0, false)
 #endif
 // the LEAN builds (fp32 only: three / four cloths per CU)
+#ifdef CLOTHHIP_EXP_V8
+#define CLOTH_VARIANTS_LEAN(X, T) X(T, 256, 3, 0, true) X(T, 256, 3, -1, true) X(T, 512, 2, 2, true) X(T, 256, 3, 2, true)
+#else
 #define CLOTH_VARIANTS_LEAN(X, T) X(T, 256, 3, 0, true) X(T, 256, 3, -1, true)
+#endif
 
 template <typename T, int FUSED> static const void *stepper_fn_t(const clothhip_handle *h) {
 #define X(T_, NT, PPT, TAB, RR) \
