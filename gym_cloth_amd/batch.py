@@ -344,6 +344,18 @@ class ClothBatch(object):
         check(self._L.clothhip_debug_stats(self._h, _lib.i32p(st)))
         return st
 
+    def last_variant(self):
+        """Which compiled stepper variant the last launch of this handle ran (clothhip_last_variant): a dict with the template
+        parameters, whether the LEAN arithmetic ran, LDS bytes per cloth, resident cloths per CU and the device's CU count, plus a
+        one-line `name`."""
+        v = np.zeros(10, dtype=np.int32)
+        check(self._L.clothhip_last_variant(self._h, _lib.i32p(v)))
+        d = dict(threads=int(v[0]), particles_per_thread=int(v[1]), table_mode=int(v[2]), rest_reg=int(v[3]), lean=bool(v[4]),
+                 fused=int(v[5]), lds_bytes=int(v[6]), cloths_per_cu=int(v[7]), n_cus=int(v[8]), precision="f32" if v[9] else "f64")
+        d["name"] = "k_run_schedule<%s,%d,%d,%d,%s,%d>%s: %d B LDS, %d cloths per CU" % (
+            "float" if v[9] else "double", v[0], v[1], v[2], "true" if v[3] else "false", v[5], " (LEAN)" if v[4] else "", v[6], v[7])
+        return d
+
     @property
     def last_kernel_ms(self):
         return float(self._L.clothhip_last_kernel_ms(self._h))

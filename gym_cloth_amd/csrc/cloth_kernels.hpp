@@ -17,7 +17,8 @@
 //   plane            cloth.pyx:345-370        per point (owner thread: it holds the previous position)
 //   strain limit     cloth.pyx:258-296        dependency levels packed into 64-slot windows (one spring per lane, lane order ==
 //                                             level order) walked by ONE wave from the first over-stretched spring to the last
-//                                             window its corrections can reach; per pass the first correcting level commits
+//                                             window its corrections can reach; a pass finishes every spring none of whose
+//                                             predecessors in the window (static per-slot dependency masks) is over-stretched
 // DESIGN.md section 4 has the exactness argument of every phase.
 #pragma once
 
@@ -267,6 +268,9 @@ template <typename T> struct WEnt;
 template <> struct __attribute__((aligned(8))) WEnt<float> { uint32_t ab; float rest; };
 template <> struct __attribute__((aligned(16))) WEnt<double> { uint32_t ab; uint32_t _pad; double rest; };
 
+constexpr int EPSTATE_LDS_BYTES = 240;
+static_assert(sizeof(EpState) <= EPSTATE_LDS_BYTES, "EpState outgrew its LDS slot (LdsLayout::eps): the window table / hash region follows it");
+static_assert(WT_IDX_BITS == 12 && HK_NBR_MASK == WT_IDX_MASK, "point indices are 12 bits in the gather entries and in the window table alike");
 // LDS carve-up (dynamic shared memory), all offsets in bytes, 16-byte aligned.
 // tab: 0 = the window table stays in global memory (L2), 1 = table + rest lengths resident in LDS
 struct LdsLayout {
@@ -275,7 +279,7 @@ struct LdsLayout {
         int o = 0;
         auto take = [&](int bytes) { int r = o; o += (bytes + 15) / 16 * 16; return r; };
         cur = take(4 * Ppad * tsz);
-        eps = take(240);             // EpState (fused episodes)
+        eps = take(EPSTATE_LDS_BYTES);   // EpState (fused episodes)
         wtab = take(tab >= 1 ? Spad * (tsz == 8 ? 16 : 8) : 0);   // WEnt<T>[Spad]; everything from here on doubles as scratch of the
                                                                   // in-kernel metrics and is rebuilt afterwards
         hkey = take(HT * 4);
@@ -294,10 +298,14 @@ struct LdsLayout {
 // Strain limit + tear (cloth.pyx:258-296) by ONE wave, exactly in the reference's order.
 //
 // The springs sit in the window table (cloth_tables.hpp): window = 64 slots = one spring per lane, consecutive dependency
-// levels in lane order, each level one "group". A pass evaluates every not yet finished group of the window against the same
-// particle state; the FIRST group (in level order) that holds an over-stretched spring commits its corrections -- the springs of
-// a level share no particle -- the groups before it are finished (they provably changed nothing), the groups behind it may have
-// read stale particles and are evaluated again by the next pass. A window without a correction costs one pass.
+// levels in lane order. A PASS evaluates every not yet finished spring of the window against the same particle state. A spring
+// is VALID in that pass when none of the earlier springs of the window it depends on -- shares a particle with, transitively: a
+// static 64-bit lane mask per table slot -- is over-stretched now: every predecessor that touches one of its particles then
+// leaves it alone, so the spring sees exactly what the sequential sweep shows it. All valid springs are finished by the pass, the
+// over-stretched ones corrected at once (two valid over-stretched springs share no particle, or the later one would not be
+// valid); the others are evaluated again by the next pass. The first over-stretched spring in table order is always valid, so
+// every pass with work makes progress; a window without a correction costs one pass. tests/test_sweep_rule.py pins this rule,
+// on the tables the library exports (clothhip_selftest_windows), to the reference's sequential loop bit for bit (CPU).
 // The walk starts at the window of the first spring the pre-pass flagged (nothing before it is over-stretched and nothing has
 // moved yet) and ends behind the last window that can hold work: the last flagged spring, pushed out by every correction to the
 // last window that holds a spring of one of the two moved particles (the entry's static `reach`). Everything outside
@@ -817,7 +825,7 @@ __host__ __device__ inline uint32_t lean_valid_mask(int r, int c, int N) {
 }
 
 template <typename T, int NT, int PPT, int TAB, bool REST_REG, int FUSED>
-__global__ __launch_bounds__(NT, (((TAB <= 0 || TAB == 2) && REST_REG && sizeof(T) == 4) ? (TAB == 2 ? (NT == 512 ? 4 : 2) : (TAB < 0 ? 4 : 3)) : (NT <= 512 ? 2 : NT / 256))) void k_run_schedule(StepArgs<T> A) {
+__global__ __launch_bounds__(NT, (((TAB <= 0 || TAB == 2) && REST_REG && sizeof(T) == 4) ? (TAB == 2 ? (NT == 512 ? 4 : (NT == 384 ? 3 : 2)) : (TAB < 0 ? 4 : 3)) : (NT <= 512 ? 2 : NT / 256))) void k_run_schedule(StepArgs<T> A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int e = blockIdx.x;
     const int tid = threadIdx.x;

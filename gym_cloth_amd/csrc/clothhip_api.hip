@@ -64,6 +64,9 @@ struct clothhip_handle {
     bool lean = false, lean_dirty = true, lean_ok = false, lean_stencil_ok = false;
     int lean_r = 3;         // cloths per CU the chosen LEAN build is compiled for (3: 168 VGPRs, 4: 128 VGPRs)
     float pal[3] = {0, 0, 0};
+    int32_t last_variant[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // what the last launch ran (clothhip_last_variant)
+    bool have_variant = false;
+    int n_cus = 0;
     struct Layout { int tab; bool rest_reg; int cell_copy; int lds_bytes; } lay_std = {0, false, 0, 0}, lay_lean = {0, true, 0, 0};
     double *d_levels = nullptr, *d_xy = nullptr, *d_radius = nullptr, *d_cov = nullptr, *d_vinv = nullptr;
     uint8_t *d_oob = nullptr;
@@ -294,6 +297,7 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
             hipDeviceProp_t dp;
             int cus = 256;
             if (hipGetDeviceProperties(&dp, device) == hipSuccess && dp.multiProcessorCount > 0) cus = dp.multiProcessorCount;
+            h->n_cus = cus;
             const double rate[3] = {1.0, 0.85, 0.72};
             double best = 0.0; int best_r = 2;
             for (int r = 2; r <= 4; r++) {
@@ -310,7 +314,7 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
 #ifdef CLOTHHIP_EXP_V8
             // experiment: the LEAN arithmetic at two cloths per CU with the window table in LDS: 2 = 256 threads x 3 particles,
             // 8 = 512 threads x 2 particles (eight waves per cloth, 128 VGPRs). No standard fallback in this build.
-            if (h->lean && (v == 2 || v == 8)) { h->lean_r = 2; if (v == 8) { h->nt = 512; h->ppt = 2; } }
+            if (h->lean && (v == 2 || v == 8 || v == 6)) { h->lean_r = 2; if (v == 8) { h->nt = 512; h->ppt = 2; } if (v == 6) { h->nt = 384; h->ppt = 2; } }
 #endif
         }
         if (h->lean) {
@@ -548,7 +552,7 @@ extern "C" int clothhip_reset_flat(clothhip_handle *h, const uint8_t *mask) {
         hipLaunchKernelGGL(k_reset_flat<float>, dim3(h->E), dim3(256), 0, h->stream, (float *)h->d_pos, (float *)h->d_prev, h->d_cnt,
                            h->d_tear, (const float *)h->d_flat, mask ? h->d_active : nullptr, h->Ppad, (float *)h->d_rest,
                            (const float *)h->d_flat_rest, h->rest_stride, h->Spad);
-    h->lean_dirty = true;
+    // (the LEAN palette verdict stands: a shared rest table is not touched here, and per-env tables rule the variant out anyway)
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(h->stream));
     return 0;
@@ -682,7 +686,7 @@ static int lean_refresh(clothhip_handle *h) {
 #endif
 // the LEAN builds (fp32 only: three / four cloths per CU)
 #ifdef CLOTHHIP_EXP_V8
-#define CLOTH_VARIANTS_LEAN(X, T) X(T, 256, 3, 0, true) X(T, 256, 3, -1, true) X(T, 512, 2, 2, true) X(T, 256, 3, 2, true)
+#define CLOTH_VARIANTS_LEAN(X, T) X(T, 256, 3, 0, true) X(T, 256, 3, -1, true) X(T, 512, 2, 2, true) X(T, 384, 2, 2, true) X(T, 256, 3, 2, true)
 #else
 #define CLOTH_VARIANTS_LEAN(X, T) X(T, 256, 3, 0, true) X(T, 256, 3, -1, true)
 #endif
@@ -701,13 +705,17 @@ static const void *stepper_fn(const clothhip_handle *h, int fused) {
     return h->precision == CLOTHHIP_F64 ? stepper_fn_t<double, 0>(h) : stepper_fn_t<float, 0>(h);
 }
 
+// (the caller has run lean_refresh(h) -- which of the handle's two layouts may run now -- BEFORE recording its start event)
 template <typename T, int FUSED> static void launch_run(clothhip_handle *h, const ClothSchedule *d_sched, const void *d_fz) {
-    (void)lean_refresh(h);                           // lean layout: which of its two variants may run now
     StepArgs<T> a = make_args<T>(h, d_sched);
     a.fz = (const FusedArgs<T> *)d_fz;
 #define X(T_, NT, PPT, TAB, RR)                                                                         \
     if (h->nt == NT && h->ppt == PPT && h->tab == TAB && h->rest_reg == RR) {                           \
         hipLaunchKernelGGL((k_run_schedule<T_, NT, PPT, TAB, RR, FUSED>), dim3(h->E), dim3(NT), h->lds_bytes, h->stream, a); \
+        int occ_ = 0;                                                                                   \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_, (const void *)k_run_schedule<T_, NT, PPT, TAB, RR, FUSED>, NT, (size_t)h->lds_bytes) != hipSuccess) { (void)hipGetLastError(); occ_ = 0; } \
+        const int32_t v_[10] = {NT, PPT, TAB, RR ? 1 : 0, ((TAB <= 0 || TAB == 2) && RR && sizeof(T_) == 4) ? 1 : 0, FUSED, h->lds_bytes, occ_, h->n_cus, sizeof(T_) == 4 ? 1 : 0}; \
+        memcpy(h->last_variant, v_, sizeof(v_)); h->have_variant = true;                                \
         return;                                                                                         \
     }
     CLOTH_VARIANTS(X, T)
@@ -717,6 +725,7 @@ template <typename T, int FUSED> static void launch_run(clothhip_handle *h, cons
 
 static int run_common(clothhip_handle *h, const ClothSchedule *d_sched) {
     if (int rc = drop_in_flight(h, nullptr, d_sched)) return rc;
+    if (int rc = lean_refresh(h)) return rc;         // (may synchronise and read the rest table back: outside the timed events)
     HIPCHECK(hipEventRecord(h->ev0, h->stream));
     if (h->precision == CLOTHHIP_F64) launch_run<double, 0>(h, d_sched, nullptr);
     else launch_run<float, 0>(h, d_sched, nullptr);
@@ -903,6 +912,7 @@ extern "C" int clothhip_run_actions_begin(clothhip_handle *h, const ClothEpisode
                            rng_states != nullptr, rng_tier, domrand_words, NS, NH);
     HIPCHECK(hipMemcpyAsync(h->d_fz, fzbuf, 1024, hipMemcpyHostToDevice, h->stream));
     HIPCHECK(hipStreamSynchronize(h->stream));          // fzbuf is on this stack frame
+    if (int rc = lean_refresh(h)) return rc;
     HIPCHECK(hipEventRecord(h->ev0, h->stream));
     if (tier2 || policy == CLOTHHIP_POLICY_HIGHEST_POINT) {   // the variant that also carries the tier-2 reset code and the cold policies
         if (h->precision == CLOTHHIP_F64) launch_run<double, 2>(h, h->d_sched, h->d_fz);
@@ -1139,6 +1149,13 @@ extern "C" int clothhip_debug_stats(clothhip_handle *h, int32_t *stats) {
     HIPCHECK(hipSetDevice(h->device));
     HIPCHECK(hipStreamSynchronize(h->stream));
     HIPCHECK(hipMemcpy(stats, h->d_stats, (size_t)h->E * 64, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int clothhip_last_variant(clothhip_handle *h, int32_t v[10]) {
+    if (!h || !v) return fail(CLOTHHIP_EINVAL, "NULL argument");
+    if (!h->have_variant) return fail(CLOTHHIP_ESTATE, "no stepper launch on this handle yet");
+    memcpy(v, h->last_variant, sizeof(h->last_variant));
     return 0;
 }
 

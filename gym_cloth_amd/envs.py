@@ -712,6 +712,8 @@ class ClothVecEnv(object):
                 self.init_side[e] = rng.rand() > 0.5
                 draws = rng.rand(P)                                   # one rand() per point, r-major
                 pos_all[k], rest_all[k] = self.batch.init_grid(2, self.init_side[e], draws)
+                if e == 0:
+                    self._built_pos0 = pos_all[k].copy()              # what env 0's cloth was built with (Point.orig_*, the façade's view)
             zeros_pin = np.zeros((len(idx), P), dtype=np.uint8)
             k = 0
             while k < len(idx):                                       # one upload per run of consecutive envs
@@ -725,6 +727,8 @@ class ClothVecEnv(object):
             for e in idx:
                 self.init_side[e] = self.np_randoms[e].rand() > 0.5
             self.batch.reset_flat(None if len(idx) == E else m)       # flat grid, nothing pinned, no tear: on the device
+            if m[0]:
+                self._built_pos0 = None                                # the flat grid (ClothEnv.reset asks init_grid for it)
         self.num_steps[m] = 0
         self.num_sim_steps[m] = 0
         self.have_tear[m] = False
@@ -898,6 +902,7 @@ class ClothEnv(object):
             v.batch.set_state(s['pos'][None], s['prev'][None], s['pinned'][None],
                               s['rest'] if 'rest' in s else None, rest_shared=True if 'rest' in s else None)
             v.num_steps[:] = 0; v.num_sim_steps[:] = 0; v.have_tear[:] = False
+            self.cloth._rebuilt(s['pos'])                              # the new Cloth's springs / colour set / orig_* 
             cov, vinv, _, _ = v.batch.metrics()
             v._prev_reward[:] = cov; v._start_coverage[:] = cov; v._start_variance_inv[:] = vinv
             v._current_coverage[:] = 0.0
@@ -909,6 +914,8 @@ class ClothEnv(object):
             return self.state
         obs = self._vec.reset()[0]
         self.cloth.init_side = bool(self._vec.init_side[0])
+        built = getattr(self._vec, "_built_pos0", None)
+        self.cloth._rebuilt(built if built is not None else self._vec.batch.init_grid(1)[0])
         return obs
 
     def step(self, action, initialize=False):

@@ -141,6 +141,16 @@ class Cloth(object):
     def _invalidate(self):
         self._mirror, self._dirty, self._pin_dirty = None, False, False
 
+    def _rebuilt(self, orig=None):
+        """The env rebuilt the cloth (ClothEnv.reset constructs a new Cloth, cloth_env.py:737-746): everything derived from the
+        construction is dropped -- Spring.rest_length (tier 2 measures new ones on every reset, cloth.pyx:417), the colour set
+        and the points' orig_x/y/z (cloth.pyx:147-164, point.pyx:30-32), which come from the positions the cloth is BUILT with
+        (`orig`; default: the device's current ones)."""
+        self._invalidate()
+        self._springs = None
+        self._cmask = None
+        self._orig = (self.batch.positions(self.env, 1)[0] if orig is None else np.asarray(orig, dtype=np.float64)).copy()
+
     # ---- reference API -----------------------------------------------------------------------------------
     @property
     def pts(self):

@@ -54,6 +54,7 @@ def load():
     L.ncclGetUniqueId.argtypes = [C.POINTER(_UniqueId)]
     L.ncclCommInitRank.argtypes = [C.POINTER(vp), C.c_int, _UniqueId, C.c_int]
     L.ncclCommDestroy.argtypes = [vp]
+    L.ncclCommCount.argtypes = [vp, C.POINTER(C.c_int)]
     L.ncclBroadcast.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, vp, vp]
     L.ncclAllGather.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, vp]
     L.ncclAllReduce.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, vp, vp]
@@ -66,14 +67,31 @@ def _check(rc, what):
         raise RcclError("%s failed: %s" % (what, load().ncclGetErrorString(rc).decode("utf8", "replace")))
 
 
+def _private_dir():
+    """A directory only this user can write to (0700, owned by us, not a symlink) under TMPDIR: the default home of the id file
+    when no launcher handed one over, so that nobody else on the box can plant or pre-create it."""
+    d = os.path.join(os.environ.get("TMPDIR", "/tmp"), "clothhip_rdzv_%d" % os.getuid())
+    try:
+        os.mkdir(d, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(d)
+    import stat as _stat
+    if not _stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise RcclError("rendezvous directory %s is not a private directory of this user (mode %o, uid %d); set "
+                        "CLOTHHIP_RDZV_FILE to a path in one" % (d, st.st_mode & 0o7777, st.st_uid))
+    return d
+
+
 def rendezvous_path():
-    """Where rank 0 leaves the unique id. CLOTHHIP_RDZV_FILE wins (bench.py's own launcher sets it); under
-    torch.distributed.run the ranks share MASTER_PORT, the run id and their parent (the agent process)."""
+    """Where rank 0 leaves the unique id. CLOTHHIP_RDZV_FILE wins (bench.py's own launcher sets it, inside a fresh 0700
+    directory); under torch.distributed.run the ranks share MASTER_PORT, the run id and their parent (the agent process), and the
+    file lives in a per-user 0700 directory."""
     p = os.environ.get("CLOTHHIP_RDZV_FILE")
     if p:
         return p
     key = "%s_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid())
-    return os.path.join(os.environ.get("TMPDIR", "/tmp"), "clothhip_rccl_%s.id" % key)
+    return os.path.join(_private_dir(), "clothhip_rccl_%s.id" % key)
 
 
 _MAGIC = b"CLTHRCCL"
@@ -107,17 +125,30 @@ def exchange_unique_id(rank, world, path=None, timeout_s=300.0):
             os.remove(path)                                   # whatever an earlier run left there
         except OSError:
             pass
-        tmp = "%s.tmp%d" % (path, os.getpid())
-        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
-        with os.fdopen(fd, "wb") as fh:
-            fh.write(head + bytes(uid.internal))
-        os.replace(tmp, path)
+        import tempfile
+        fd, tmp = tempfile.mkstemp(prefix=os.path.basename(path) + ".", suffix=".tmp", dir=os.path.dirname(path) or ".")   # unique, 0600, O_EXCL:
+        try:                                                                   # a leftover of a crashed run (reused pid) cannot collide
+            with os.fdopen(fd, "wb") as fh:
+                fh.write(head + C.string_at(C.byref(uid), NCCL_UNIQUE_ID_BYTES))    # (NOT uid.internal: ctypes cuts a c_char array field at its first NUL)
+            os.replace(tmp, path)
+        except BaseException:
+            try:
+                os.remove(tmp)
+            except OSError:
+                pass
+            raise
     else:
         t0 = time.time()
         while True:
             try:
-                with open(path, "rb") as fh:
-                    raw = fh.read()
+                # never through a symlink, and only a regular file of OUR user counts (a foreign file with the right header is ignored)
+                fd = os.open(path, os.O_RDONLY | getattr(os, "O_NOFOLLOW", 0))
+                try:
+                    import stat as _stat
+                    st = os.fstat(fd)
+                    raw = os.read(fd, len(head) + NCCL_UNIQUE_ID_BYTES + 1) if (_stat.S_ISREG(st.st_mode) and st.st_uid == os.getuid()) else b""
+                finally:
+                    os.close(fd)
                 if len(raw) == len(head) + NCCL_UNIQUE_ID_BYTES and raw[:len(head)] == head:
                     raw = raw[len(head):]
                     break
@@ -140,6 +171,13 @@ class Communicator(object):
         comm = C.c_void_p()
         _check(self._L.ncclCommInitRank(C.byref(comm), self.world, uid, self.rank), "ncclCommInitRank")
         self._comm = comm
+
+    @property
+    def nranks(self):
+        """ncclCommCount: how many ranks RCCL itself says this communicator has (the bench line prints it)."""
+        n = C.c_int(-1)
+        _check(self._L.ncclCommCount(self._comm, C.byref(n)), "ncclCommCount")
+        return int(n.value)
 
     def rendezvous_done(self):
         """Call after the first collective has completed on every rank: rank 0 removes the id file."""

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CLOTHHIP_ABI_VERSION 4
+#define CLOTHHIP_ABI_VERSION 5
 
 enum {
     CLOTHHIP_OK = 0,
@@ -359,6 +359,17 @@ void *clothhip_stream(clothhip_handle *h);
 /* Timing of the last clothhip_run/_async/_update launch measured with HIP events recorded on the
  * handle's stream around the stepper kernel: milliseconds, or a negative value if none. */
 double clothhip_last_kernel_ms(clothhip_handle *h);
+
+/* (new, ABI 5) Which compiled stepper variant the handle's LAST launch ran (clothhip_run*, clothhip_update, clothhip_run_actions*),
+ * so that tests and the benchmark can tell the variants apart instead of inferring them from the batch size:
+ *   v[0] threads per cloth, v[1] particles per thread, v[2] table mode (1: strain-sweep window table resident in LDS, 0: streamed
+ *   from L2; LEAN builds: 0 = compiled for three cloths per CU, -1 = for four, 2 = LEAN arithmetic with the table in LDS),
+ *   v[3] rest lengths in registers / LEAN flag as compiled (0/1), v[4] 1 when the LEAN arithmetic ran (gather stencil recomputed,
+ *   rest lengths from the three-value palette), v[5] episode-loop flavour (0 plain schedule, 1 flat-tier episodes, 2 + tier-2 /
+ *   highest-point code), v[6] dynamic LDS bytes per cloth, v[7] cloths resident per CU for that kernel and LDS size
+ *   (hipOccupancyMaxActiveBlocksPerMultiprocessor), v[8] compute units of the device, v[9] precision (0 f64, 1 f32).
+ * Returns CLOTHHIP_ESTATE when the handle has not launched a stepper yet. */
+int clothhip_last_variant(clothhip_handle *h, int32_t v[10]);
 
 /* Diagnostics of the last clothhip_run*: stats[E][16]: [0..3] = {strain sweeps run, 64-spring windows walked, passes
  * over a window, passes in which a correction was applied}; [15] = shader clocks/1024 the env's whole schedule

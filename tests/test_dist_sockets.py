@@ -8,6 +8,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -148,3 +149,37 @@ def test_rendezvous_file_ignores_stale_and_foreign_ids(tmp_path, monkeypatch):
     monkeypatch.setenv("CLOTHHIP_RDZV_NONCE", "xyz")
     rccl._generation.pop(path, None)
     assert rccl._nonce(path, 2) != n0    # another launch
+
+
+def test_rendezvous_reader_takes_only_a_regular_file_of_this_user(tmp_path, monkeypatch):
+    """the polling ranks open the id file without following symlinks and accept it only when it is a regular file owned
+    by this user; the default location is a private (0700) per-user directory."""
+    sys.path.insert(0, ROOT)
+    from gym_cloth_amd import rccl
+    try:
+        rccl.load()
+    except rccl.RcclError:
+        pytest.skip("librccl.so not installed")
+    monkeypatch.setenv("CLOTHHIP_RDZV_NONCE", "n1")
+    real, link = str(tmp_path / "real.id"), str(tmp_path / "link.id")
+    rccl._generation.pop(link, None)
+    head = rccl._MAGIC + rccl._nonce(link, 2) + (2).to_bytes(4, "little")
+    with open(real, "wb") as fh:
+        fh.write(head + bytes(range(128)))
+    os.symlink(real, link)
+    rccl._generation.pop(link, None)
+    with pytest.raises(rccl.RcclError):                      # a symlink to a perfectly good id: not followed
+        rccl.exchange_unique_id(1, 2, link, timeout_s=0.3)
+    os.remove(link)
+    os.rename(real, link)
+    rccl._generation.pop(link, None)
+    uid, _ = rccl.exchange_unique_id(1, 2, link, timeout_s=5.0)
+    import ctypes as C
+    assert C.string_at(C.byref(uid), 128) == bytes(range(128))
+    monkeypatch.setenv("TMPDIR", str(tmp_path))
+    monkeypatch.delenv("CLOTHHIP_RDZV_FILE", raising=False)
+    d = os.path.dirname(rccl.rendezvous_path())
+    assert os.stat(d).st_mode & 0o777 == 0o700 and os.stat(d).st_uid == os.getuid()
+    os.chmod(d, 0o755)
+    with pytest.raises(rccl.RcclError):                      # somebody else could write there: refused
+        rccl.rendezvous_path()

@@ -70,3 +70,25 @@ def test_rccl_single_rank_collectives(tmp_path):
     tk, sb = v.batch.op_ticks()
     assert tk.shape == (4, 4) and sb[:, 0].sum() == o3["executed"].sum() and tk[:, 0].sum() > 0
     tv.close(); t.close(); b.close(); v.close(); w.close()
+
+
+def test_rccl_unique_id_file_round_trip_and_comm_count(tmp_path, monkeypatch):
+    """The REAL 128-byte ncclUniqueId (binary: it holds NUL bytes early on) written by rank 0 must come back whole for the ranks that
+    poll for it -- a world size > 1 cannot be run on this box, but this is exactly what its ranks 1.. do; and ncclCommCount of the
+    one-rank communicator (the bench prints it as config.rccl_nranks)."""
+    import ctypes as C
+    from gym_cloth_amd import ClothBatch, rccl
+    from gym_cloth_amd.dist import RcclTransport
+    monkeypatch.setenv("CLOTHHIP_RDZV_NONCE", "roundtrip")
+    b = ClothBatch(base_cfg("tier1", 1), n_envs=2, precision="f32")         # (brings the HIP runtime up)
+    path = str(tmp_path / "pair.id")
+    rccl._generation.pop(path, None)
+    uid0, _ = rccl.exchange_unique_id(0, 2, path)
+    raw0 = C.string_at(C.byref(uid0), rccl.NCCL_UNIQUE_ID_BYTES)
+    assert os.path.getsize(path) == len(rccl._MAGIC) + 16 + 4 + rccl.NCCL_UNIQUE_ID_BYTES
+    rccl._generation.pop(path, None)
+    uid1, _ = rccl.exchange_unique_id(1, 2, path, timeout_s=10.0)
+    assert C.string_at(C.byref(uid1), rccl.NCCL_UNIQUE_ID_BYTES) == raw0
+    t = RcclTransport(0, 1, b, rdzv_path=str(tmp_path / "one.id"))
+    assert t.comm.nranks == 1
+    t.close(); b.close()

@@ -20,19 +20,27 @@ def _run(tier, lean, monkeypatch, E=48, T=5):
     env.reset()
     acts = np.ascontiguousarray(np.stack([np.random.RandomState(2000 + e).uniform(-1, 1, size=(T, 4)) for e in range(E)], axis=1))
     out = env.step_many(acts, auto_reset=True)                       # episode launch: actions, terminal tests, in-kernel resets
+    var_fused = env.batch.last_variant()
     a = np.stack([np.random.RandomState(3000 + e).uniform(-1, 1, size=4) for e in range(E)])
     obs, rew, done, info = env.step(a, auto_reset=False)              # the per-step path (plain stepper variant)
+    var_step = env.batch.last_variant()
     res = dict(rew=out["rew"].copy(), executed=out["executed"].copy(), done=out["done"].copy(), cov=out["actual_coverage"].copy(),
                obs=out["obs"].copy(), obs2=obs.copy(), rew2=rew.copy(), exec2=env.last_executed.copy(),
                state=[x.copy() for x in env.batch.get_state()])
     env.close()
-    return res
+    return res, var_fused, var_step
 
 
 @pytest.mark.parametrize("tier,build", [("tier1", 3), ("tier3", 3), ("tier1", 4)])
 def test_lean_variant_is_bit_identical_to_the_standard_f32_variant(tier, build, monkeypatch):
-    a = _run(tier, 0, monkeypatch)
-    b = _run(tier, build, monkeypatch)
+    a, va_f, va_s = _run(tier, 0, monkeypatch)
+    b, vb_f, vb_s = _run(tier, build, monkeypatch)
+    # the library says which kernel ran: without this the comparison below could not tell "bit-identical" from "never ran"
+    assert not va_f["lean"] and not va_s["lean"] and va_f["fused"] >= 1 and va_s["fused"] == 0, (va_f, va_s)
+    for v in (vb_f, vb_s):
+        assert v["lean"] and v["threads"] == 256 and v["table_mode"] == (0 if build == 3 else -1), v
+        assert v["cloths_per_cu"] == build, v                        # three / four cloths resident per CU
+    assert va_f["cloths_per_cu"] == 2, va_f
     assert a["executed"].sum() > 100000 and a["exec2"].sum() > 10000
     for k in a:
         if k == "state":
@@ -44,7 +52,8 @@ def test_lean_variant_is_bit_identical_to_the_standard_f32_variant(tier, build, 
 
 def test_lean_handle_steps_aside_for_per_env_rest_tables(monkeypatch):
     """Tier 2 gives every env its own rest lengths: no palette. A handle that wants the lean variant runs the standard one then."""
-    a = _run("tier2", 0, monkeypatch, E=24, T=3)
-    b = _run("tier2", 3, monkeypatch, E=24, T=3)
+    a, _, _ = _run("tier2", 0, monkeypatch, E=24, T=3)
+    b, vf, vs = _run("tier2", 3, monkeypatch, E=24, T=3)
+    assert not vf["lean"] and not vs["lean"], (vf, vs)              # it did step aside (clothhip_last_variant)
     for k in ("rew", "executed", "obs", "obs2", "exec2"):
         assert np.array_equal(a[k], b[k]), k

@@ -61,12 +61,19 @@ def test_f64_bit_exact_vs_reference_golden(name, oracle_lib):
     assert not bad, bad[:5]
 
 
-@pytest.mark.parametrize("name", F32_WINDOWS)
-def test_f32_teacher_forced_windows(name, oracle_lib):
+# (name, CLOTHHIP_DEBUG_LEAN): 0 = the standard fp32 variant; 3 / 4 = the LEAN variant's two builds (25x25 only), pinned to the
+# reference's checkpoints DIRECTLY (cloth.pyx:221-237 evaluation order), not only to the standard variant
+F32_WINDOW_CASES = [(n, 0) for n in F32_WINDOWS] + [(n, l) for n in F32_WINDOWS if "_50" not in n for l in (3, 4)]
+
+
+@pytest.mark.parametrize("name,lean", F32_WINDOW_CASES)
+def test_f32_teacher_forced_windows(name, lean, oracle_lib, monkeypatch):
     """fp32 instantiation, teacher-forced: restart from every reference checkpoint, run to the next one
     (<= ~200 substeps) and compare. Tolerance (stated): 2e-4 absolute on positions for
-    windows up to 200 substeps, 2e-5 for windows of <= 10 substeps."""
+    windows up to 200 substeps, 2e-5 for windows of <= 10 substeps. Run for the standard variant and for both builds of the
+    LEAN variant; the library reports which variant each launch ran (clothhip_last_variant)."""
     from gym_cloth_amd import ClothBatch
+    monkeypatch.setenv("CLOTHHIP_DEBUG_LEAN", str(lean))
     g = oracle_lib.load_golden(name)
     b = ClothBatch(cfg_from_golden(g), n_envs=1, precision="f32")
     rp = BatchReplay(b)
@@ -85,13 +92,17 @@ def test_f32_teacher_forced_windows(name, oracle_lib):
         if ext:
             b.pin_points(0, ext)
         oracle_lib.replay_ops(rp, seg)
+        var = b.last_variant()
+        assert var["lean"] == (lean != 0) and var["precision"] == "f32", var
+        if lean:
+            assert var["table_mode"] == (0 if lean == 3 else -1) and var["threads"] == 256, var
         pos = b.positions()[0]
         err = max_abs(pos, g["cp_pos"][k + 1])
         tol = 5e-7 if nsub == 1 else (5e-6 if nsub <= 10 else (1e-4 if nsub <= 60 else 2e-3))
         if "friction" in name and nsub > 10:                 # softer, less damped material (ks 7000, damping 1.2): errors grow
             tol *= 4                                         # faster; measured 2.5e-4 after 60 and 3.5e-3 after 140 substeps
         worst.append((k, nsub, err, tol))
-    print("\nfp32 windows %s: %s" % (name, ["cp%d n=%d err=%.2e" % w[:3] for w in worst]))
+    print("\nfp32 windows %s (lean %d): %s" % (name, lean, ["cp%d n=%d err=%.2e" % w[:3] for w in worst]))
     assert worst
     assert all(w[2] <= w[3] for w in worst), worst
 

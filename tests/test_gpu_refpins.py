@@ -148,3 +148,24 @@ def test_physics_facade_springs_and_colour_points(oracle_lib):
     n_col = len(e.cloth.color_pts)                      # base_cfg: color_pts 'diag1' -> |(1 - x) - y| < 0.05 on the flat grid
     assert n_col == len(e.cloth.colorpts_arr) and n_col + len(e.cloth.noncolorpts_arr) == 625 and 25 <= n_col <= 75
     e.close()
+
+
+def test_physics_facade_follows_the_rebuilt_cloth_tier2_f64():
+    """The reference builds a new Cloth and new Springs in every reset() (cloth_env.py:737-746); tier 2 measures new rest lengths on
+    each new noisy sheet (cloth.pyx:94-116, :417) and the points' orig_* are that sheet's positions. The façade's cached views must
+    follow: Spring.rest_length == the device's rest table after every reset, orig_* == the positions the cloth was built with."""
+    from gym_cloth_amd.envs import ClothEnv
+    e = ClothEnv(base_cfg("tier2", 1338), precision="f64")
+    e.seed(1338); e.reset()
+    r1 = np.array([s.rest_length for s in e.cloth.springs])
+    o1 = np.array([[p.orig_x, p.orig_y, p.orig_z] for p in e.cloth.pts])
+    assert np.array_equal(r1, e._vec.batch.get_rest(0, 1)[0])
+    side1 = e.cloth.init_side
+    assert np.all((o1[:, 0] <= 0.005) if side1 else (o1[:, 0] >= 0.995)) and np.ptp(o1[:, 2]) > 0.9     # the vertical sheet, not where the reset left it
+    e.step(np.array([0.3, -0.2, 0.4, 0.3]))
+    e.reset()
+    r2 = np.array([s.rest_length for s in e.cloth.springs])
+    o2 = np.array([[p.orig_x, p.orig_y, p.orig_z] for p in e.cloth.pts])
+    assert np.array_equal(r2, e._vec.batch.get_rest(0, 1)[0]) and not np.array_equal(r1, r2)
+    assert not np.array_equal(o1, o2) and np.ptp(o2[:, 2]) > 0.9
+    e.close()

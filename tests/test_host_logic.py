@@ -41,7 +41,7 @@ def test_abi_exports_every_declared_symbol(lib):
     assert declared == bound, (declared ^ bound)
     for name in declared:
         assert getattr(L, name) is not None
-    assert L.clothhip_abi_version() == lib.ABI_VERSION == 4
+    assert L.clothhip_abi_version() == lib.ABI_VERSION == 5
     assert C.sizeof(lib.ClothSchedule) == 64 and C.sizeof(lib.ClothParams) == 104
 
 
