@@ -824,8 +824,18 @@ __host__ __device__ inline uint32_t lean_valid_mask(int r, int c, int N) {
            (r1 ? 64u : 0u) | (r2 ? 128u : 0u) | ((d1 && l1) ? 256u : 0u) | (d1 ? 512u : 0u) | ((d1 && r1) ? 1024u : 0u) | (d2 ? 2048u : 0u);
 }
 
+// How a (TAB, REST_REG, precision) triple is compiled:
+//   standard arithmetic   TAB 1: window table + rest lengths resident in LDS; TAB 0: streamed from L2
+//   LEAN arithmetic       (REST_REG, fp32) TAB 0: built for three cloths per CU (168 VGPRs), -1: for four (128), 3: the whole CU for one cloth
+//                         (the large grids); the table is streamed from L2 in all three
+constexpr bool v_lean(int TAB, bool RR, int tsz) { return (TAB <= 0 || TAB == 3) && RR && tsz == 4; }
+constexpr bool v_ldstab(int TAB) { return TAB == 1; }
+constexpr int v_waves_per_eu(int NT, int TAB, bool lean) {      // __launch_bounds__' second argument: waves per SIMD
+    if (!lean || TAB == 3) return NT <= 512 ? 2 : NT / 256;
+    return TAB < 0 ? 4 : 3;
+}
 template <typename T, int NT, int PPT, int TAB, bool REST_REG, int FUSED>
-__global__ __launch_bounds__(NT, (((TAB <= 0 || TAB == 2) && REST_REG && sizeof(T) == 4) ? (TAB == 2 ? (NT == 512 ? 4 : (NT == 384 ? 3 : 2)) : (TAB < 0 ? 4 : 3)) : (NT <= 512 ? 2 : NT / 256))) void k_run_schedule(StepArgs<T> A) {
+__global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (int)sizeof(T)))) void k_run_schedule(StepArgs<T> A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int e = blockIdx.x;
     const int tid = threadIdx.x;
@@ -848,7 +858,7 @@ __global__ __launch_bounds__(NT, (((TAB <= 0 || TAB == 2) && REST_REG && sizeof(
         sc.dz_up = sc.dx_pull = sc.dy_pull = sc.dz_pull = 0.0;
     }
     const int P = A.P, Ppad = A.Ppad, HT = A.HT;
-    const LdsLayout lay((int)sizeof(T), Ppad, A.Spad, HT, TAB, A.cell_copy);
+    const LdsLayout lay((int)sizeof(T), Ppad, A.Spad, HT, v_ldstab(TAB) ? 1 : 0, A.cell_copy);
     Pt<T> *cur = reinterpret_cast<Pt<T> *>(smem + lay.cur);
     uint32_t *hkey = reinterpret_cast<uint32_t *>(smem + lay.hkey);
     uint32_t *hco = reinterpret_cast<uint32_t *>(smem + lay.hco);
@@ -862,14 +872,17 @@ __global__ __launch_bounds__(NT, (((TAB <= 0 || TAB == 2) && REST_REG && sizeof(
     const T *g_rest = A.rest + (size_t)e * A.rest_stride;
     const WEnt<T> *wtab = reinterpret_cast<const WEnt<T> *>(smem + lay.wtab);    // TAB >= 1 only
     // rest length of the spring in window-table slot i (Hooke, pre-pass; the sweep streams its own)
-    auto rest_at = [&](uint32_t i) -> T { return TAB >= 1 ? wtab[i].rest : g_rest[i]; };
+    auto rest_at = [&](uint32_t i) -> T { return v_ldstab(TAB) ? wtab[i].rest : g_rest[i]; };
+#ifdef CLOTHHIP_FORCE_PM            // register-pressure bisection (dev): the phase mask as a compile-time constant
+    const int pm = CLOTHHIP_FORCE_PM;
+#else
     const int pm = A.phase_mask;
+#endif
 
     T pvx[PPT], pvy[PPT], pvz[PPT];         // previous positions of the owned particles
     // their incident-spring gather entries (static): in registers for fp32; the fp64 instantiation has no room
     // (they ended up in scratch, reloaded one by one) and re-reads the L2-resident table, 12 loads in flight
-    constexpr bool LEAN = (TAB <= 0 || TAB == 2) && REST_REG && sizeof(T) == 4;      // TAB 0: compiled for three cloths per CU (168 VGPRs), TAB -1: for four (128);
-                                                                                     // TAB 2: the LEAN arithmetic with the window table in LDS (two cloths per CU)
+    constexpr bool LEAN = v_lean(TAB, REST_REG, (int)sizeof(T));      // (the variants: see v_lean above)
     constexpr bool GT_REG = sizeof(T) == 4 && !LEAN;
     constexpr bool REST_R = REST_REG && !LEAN;
     uint32_t gt[GT_REG ? PPT : 1][HK_SLOTS];
@@ -904,7 +917,7 @@ __global__ __launch_bounds__(NT, (((TAB <= 0 || TAB == 2) && REST_REG && sizeof(
     // everything in LDS behind the particle records: static tables, hash table, sweep flags (also re-run after the in-kernel
     // metrics, which borrow that region as scratch)
     auto init_lds = [&](int tear_flag, const uint32_t *s_ent, const T *s_rest) {
-        if (TAB >= 1) {
+        if (v_ldstab(TAB)) {
             WEnt<T> *d0 = reinterpret_cast<WEnt<T> *>(smem + lay.wtab);
             for (int i = tid; i < A.Spad; i += NT) { WEnt<T> w_; w_.ab = s_ent[i]; w_.rest = s_rest[i]; d0[i] = w_; }
         }
@@ -1599,49 +1612,43 @@ __global__ __launch_bounds__(NT, (((TAB <= 0 || TAB == 2) && REST_REG && sizeof(
                 for (int q = 0; q < PPT; q++) hit[q] = false;
                 // (left to itself the compiler unrolls the member loops several times: fine at 256 VGPRs, 500 spilled registers at
                 //  the LEAN variant's 168 -- that variant gets its own copy of the loops, not unrolled)
+#ifndef CLOTHHIP_BISECT_NOPRECHECK
                 if constexpr (LEAN) {
-                    if (A.cell_copy) {
-                        constexpr int CU = 2;
-                        // a read past the cell's range (another cell's record or the padding behind the array) is masked out
-                        // by the member count; the trip base is clamped so that no read leaves the padded array
+                    // register-lean form: one owned particle after the other (a real branch each: a scheduling region of its own),
+                    // the member loop not unrolled; the trip count is the wave's largest member count for THAT particle
+#pragma unroll
+                    for (int q = 0; q < PPT; q++) {
+                        const int nq = -__builtin_amdgcn_readlane(wave_incl_min(-cn[q]), 63);
+                        if (nq > 0) {
+                            int iq_ = tid + q * NT;
+                            asm volatile("" : "+v"(iq_));
+                            const Pt<T> me_ = cur[iq_ < P ? iq_ : 0];
+                            const int cs_ = cstart[q], cn_ = cn[q];
+                            bool h_ = false;
+                            if (A.cell_copy) {
+                                // a read past the cell's range (another cell's record or the padding behind the array) is masked out
+                                // by the member count; the trip base is clamped so that no read leaves the padded array
 #pragma unroll 1
-                        for (int b = 0; b < nmax; b += CU) {     // CU members x PPT particles per trip: their LDS reads overlap
-                            Pt<T> o[PPT][CU];
-#pragma unroll
-                            for (int q = 0; q < PPT; q++) {
-                                const int base = cstart[q] + b < Ppad + 32 - CU ? cstart[q] + b : Ppad + 32 - CU;
-#pragma unroll
-                                for (int u = 0; u < CU; u++) o[q][u] = cpos[base + u];
+                                for (int b = 0; b < nq; b += 2) {
+                                    const int base = cs_ + b < Ppad + 30 ? cs_ + b : Ppad + 30;
+                                    const Pt<T> o0 = cpos[base], o1 = cpos[base + 1];
+                                    const T dx0 = me_.x - o0.x, dy0 = me_.y - o0.y, dz0 = me_.z - o0.z;
+                                    const T dx1 = me_.x - o1.x, dy1 = me_.y - o1.y, dz1 = me_.z - o1.z;
+                                    h_ |= (b < cn_) & ((int)w_cnt(o0.w) != iq_) & !(sumsq<T>(dx0, dy0, dz0) > thr2);       // branch-free on purpose (& not &&)
+                                    h_ |= (b + 1 < cn_) & ((int)w_cnt(o1.w) != iq_) & !(sumsq<T>(dx1, dy1, dz1) > thr2);
+                                }
+                            } else {
+#pragma unroll 1
+                                for (int b = 0; b < nq; b += 2) {
+                                    const int j0 = (int)memb[cn_ ? cs_ + (b < cn_ ? b : 0) : 0], j1 = (int)memb[cn_ ? cs_ + (b + 1 < cn_ ? b + 1 : 0) : 0];
+                                    const Pt<T> o0 = cur[j0], o1 = cur[j1];
+                                    const T dx0 = me_.x - o0.x, dy0 = me_.y - o0.y, dz0 = me_.z - o0.z;
+                                    const T dx1 = me_.x - o1.x, dy1 = me_.y - o1.y, dz1 = me_.z - o1.z;
+                                    h_ |= (b < cn_) & (j0 != iq_) & !(sumsq<T>(dx0, dy0, dz0) > thr2);
+                                    h_ |= (b + 1 < cn_) & (j1 != iq_) & !(sumsq<T>(dx1, dy1, dz1) > thr2);
+                                }
                             }
-#pragma unroll
-                            for (int q = 0; q < PPT; q++)
-#pragma unroll
-                                for (int u = 0; u < CU; u++) {                              // branch-free on purpose (& not &&)
-                                    const T dx = cme[q].x - o[q][u].x, dy = cme[q].y - o[q][u].y, dz = cme[q].z - o[q][u].z;
-                                    const bool other = (b + u < cn[q]) & ((int)w_cnt(o[q][u].w) != tid + q * NT);
-                                    hit[q] |= other & !(sumsq<T>(dx, dy, dz) > thr2);
-                                }
-                        }
-                    } else {
-#pragma unroll 1
-                        for (int b = 0; b < nmax; b += 4) {
-                            int jj[PPT][4];
-#pragma unroll
-                            for (int q = 0; q < PPT; q++)
-#pragma unroll
-                                for (int u = 0; u < 4; u++) {
-                                    const int bb = b + u < cn[q] ? b + u : 0;
-                                    jj[q][u] = (int)memb[cn[q] ? cstart[q] + bb : 0];
-                                }
-#pragma unroll
-                            for (int q = 0; q < PPT; q++)
-#pragma unroll
-                                for (int u = 0; u < 4; u++) {
-                                    const Pt<T> o = cur[jj[q][u]];
-                                    const T dx = cme[q].x - o.x, dy = cme[q].y - o.y, dz = cme[q].z - o.z;
-                                    const bool other = (b + u < cn[q]) & (jj[q][u] != tid + q * NT);
-                                    hit[q] |= other & !(sumsq<T>(dx, dy, dz) > thr2);
-                                }
+                            hit[q] = h_;
                         }
                     }
                 } else {
@@ -1688,6 +1695,7 @@ __global__ __launch_bounds__(NT, (((TAB <= 0 || TAB == 2) && REST_REG && sizeof(
                         }
                     }
                 }
+#endif
 #pragma unroll
                 for (int q = 0; q < PPT; q++) {
                     if (hit[q]) {
@@ -1731,7 +1739,11 @@ __global__ __launch_bounds__(NT, (((TAB <= 0 || TAB == 2) && REST_REG && sizeof(
                         const int n = (int)(co & 0xFFFFu);
                         uint16_t *m = memb + (int)(co >> 16);
                         if (n <= 64) {
+#ifndef CLOTHHIP_BISECT_NOWAVE
                             const int nv_ = collide_cell_wave<T>(cur, m, slot, n, k, lane);
+#else
+                            const int nv_ = 0;
+#endif
 #ifdef CLOTHHIP_CELL_COUNTERS
                             tph[4] += 64; tph[5] += 64 * n; tph[6] += 64 * (nv_ & 0xffff); tph[11] += 64 * (nv_ >> 16);
 #else
@@ -1762,7 +1774,9 @@ __global__ __launch_bounds__(NT, (((TAB <= 0 || TAB == 2) && REST_REG && sizeof(
 #ifdef CLOTHHIP_CELL_COUNTERS
                         tph[8] += 64;
 #endif
+#ifndef CLOTHHIP_BISECT_NOGROUP
                         collide_cells_group<T, 16>(cur, memb, slot, hco, hs, k, lane);
+#endif
                     }
                     sbase += nsb;
 #ifdef CLOTHHIP_CELL_STAMPS
@@ -1878,7 +1892,7 @@ __global__ __launch_bounds__(NT, (((TAB <= 0 || TAB == 2) && REST_REG && sizeof(
                                 if (cand & (1u << sl)) {
                                     // (LEAN: the spring's table slot is read from the gather table only now that it is needed: the table
                                     //  is compacted, the sl-th stencil position is the particle's popcount(valid below sl)-th entry)
-                                    const uint32_t pos_ = ((LEAN ? A.gather[__popc(vm[LEAN ? q : 0] & ((1u << sl) - 1u)) * Ppad + tid + q * NT] : gl[sl])
+                                    const uint32_t pos_ = ((LEAN ? A.gather[__popc(vq_ & ((1u << sl) - 1u)) * Ppad + iq_] : gl[sl])      // (the opaque copies: nothing of this is hoisted out of the substep loop and held)
                                                            >> HK_POS_SHIFT) & HK_POS_MASK;
                                     T r = LEAN ? lean_rest(sl) : (REST_R ? rr[REST_R ? q : 0][sl] : rest_at(pos_));
                                     asm volatile("" : "+v"(r));
@@ -1921,9 +1935,9 @@ __global__ __launch_bounds__(NT, (((TAB <= 0 || TAB == 2) && REST_REG && sizeof(
 #else
                 const unsigned long long fmask_ = 0ull;
 #endif
-                const int tear = tic ? strain_sweep<T, (TAB >= 1), SWEEP_TIMED, SWEEP_STATS, true>(cur, wtab, A.wt_ent, g_rest, A.wt_dep, w0, w1, A.nW, A.wt_rshift, k,
+                const int tear = tic ? strain_sweep<T, v_ldstab(TAB), SWEEP_TIMED, SWEEP_STATS, true>(cur, wtab, A.wt_ent, g_rest, A.wt_dep, w0, w1, A.nW, A.wt_rshift, k,
                                                                                                  lane, st_windows, st_passes, st_commits, tph, fmask_)
-                                     : strain_sweep<T, (TAB >= 1), SWEEP_TIMED, SWEEP_STATS, false>(cur, wtab, A.wt_ent, g_rest, A.wt_dep, w0, w1, A.nW, A.wt_rshift, k,
+                                     : strain_sweep<T, v_ldstab(TAB), SWEEP_TIMED, SWEEP_STATS, false>(cur, wtab, A.wt_ent, g_rest, A.wt_dep, w0, w1, A.nW, A.wt_rshift, k,
                                                                                                   lane, st_windows, st_passes, st_commits, tph, fmask_);
                 if (__any(tear) && lane == 0) misc[0] = 1;
                 if (lane == 0) { misc[1] = 0; misc[10] = 0x7fffffff; misc[11] = -1; }

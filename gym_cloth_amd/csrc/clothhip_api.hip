@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "cloth_kernels.hpp"
+#include "lean_rates.hpp"
 #include "cloth_render.hpp"
 
 using namespace clothhip;
@@ -298,7 +299,9 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
             int cus = 256;
             if (hipGetDeviceProperties(&dp, device) == hipSuccess && dp.multiProcessorCount > 0) cus = dp.multiProcessorCount;
             h->n_cus = cus;
-            const double rate[3] = {1.0, 0.85, 0.72};
+            // substeps/s of ONE resident cloth at 2 (standard), 3 and 4 cloths per CU, relative to the standard variant's: measured
+            // by tools/measure_pick_table.py on the bench workload and written to lean_rates.hpp (its output: profiles/)
+            const double rate[3] = {1.0, LEAN_RATE_3_PER_CU, LEAN_RATE_4_PER_CU};
             double best = 0.0; int best_r = 2;
             for (int r = 2; r <= 4; r++) {
                 const double v = rate[r - 2] / (double)((h->E + r * cus - 1) / (r * cus));
@@ -306,16 +309,14 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
             }
             h->lean = h->nt == 256 && precision == CLOTHHIP_F32 && best_r > 2;
             h->lean_r = best_r > 2 ? best_r : 3;
+            // the large grids (512 threads x 5 particles, one cloth per CU): the LEAN arithmetic frees the 60 registers of gather
+            // entries and takes the rest lengths off the L2 path; the standard variant stays as the fallback (per-env rest tables)
+            if (h->nt == 512 && h->ppt == 5 && precision == CLOTHHIP_F32) { h->lean = true; h->lean_r = 1; }
         }
-        if (const char *t = getenv("CLOTHHIP_DEBUG_LEAN")) {      // 0: never, 3 (or 1) / 4: that build whatever the batch size
+        if (const char *t = getenv("CLOTHHIP_DEBUG_LEAN")) {      // 0: never; 3 (or 1) / 4: that build whatever the batch size (256-thread grids)
             const int v = atoi(t);
-            h->lean = h->nt == 256 && precision == CLOTHHIP_F32 && v != 0;
-            if (v != 0) h->lean_r = v == 4 ? 4 : 3;
-#ifdef CLOTHHIP_EXP_V8
-            // experiment: the LEAN arithmetic at two cloths per CU with the window table in LDS: 2 = 256 threads x 3 particles,
-            // 8 = 512 threads x 2 particles (eight waves per cloth, 128 VGPRs). No standard fallback in this build.
-            if (h->lean && (v == 2 || v == 8 || v == 6)) { h->lean_r = 2; if (v == 8) { h->nt = 512; h->ppt = 2; } if (v == 6) { h->nt = 384; h->ppt = 2; } }
-#endif
+            if (v == 0) h->lean = false;
+            else if (h->nt == 256 && precision == CLOTHHIP_F32) { h->lean = true; h->lean_r = v == 4 ? 4 : 3; }
         }
         if (h->lean) {
             // the arithmetic stencil of the LEAN kernel against the gather table built from the reference's spring list
@@ -345,14 +346,13 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
         h->lds_bytes = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, h->tab, h->cell_copy).total;
         h->lay_std = {h->tab, h->rest_reg, h->cell_copy, h->lds_bytes};
         if (h->lean) {                                   // the lean layout: window table streamed from L2, 33 KB of LDS
-            int cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, 1).total <= (h->lean_r == 4 ? 40 : 53) * 1024 ? 1 : 0;
+            int cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, 1).total <= (160 * 1024) / std::max(h->lean_r, 3) ? 1 : 0;
             if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) cc = cc && atoi(t);
-            h->lay_lean = {h->lean_r == 4 ? -1 : 0, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, cc).total};
-            if (h->lean_r == 2) {
-                cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 1, 1).total <= 80 * 1024 ? 1 : 0;
-                h->lay_lean = {2, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 1, cc).total};
-                h->lay_std = h->lay_lean;
-                h->tab = 2; h->rest_reg = true; h->cell_copy = cc; h->lds_bytes = h->lay_lean.lds_bytes;
+            h->lay_lean = {h->lean_r >= 4 ? 3 - h->lean_r : 0, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, cc).total};
+            if (h->lean_r == 1) {                        // the whole CU: same LDS budget as the standard variant of these grids
+                cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, 1).total <= 160 * 1024 ? 1 : 0;
+                if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) cc = cc && atoi(t);
+                h->lay_lean = {3, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, cc).total};
             }
             // the in-kernel metrics borrow the region behind the episode state (clothhip_fused_supported): it must hold them here too
             int NS_ = 1; while (NS_ < h->P) NS_ <<= 1;
@@ -684,11 +684,11 @@ static int lean_refresh(clothhip_handle *h) {
     X(T, 256, 3, 1, true) X(T, 256, 3, 1, false) X(T, 256, 3, 0, false)   \
     X(T, 512, 5, 0, false) X(T, 512, 5, 1, false) X(T, 1024, 3, 0, false) X(T, 1024, 4, 0, false)
 #endif
-// the LEAN builds (fp32 only: three / four cloths per CU)
-#ifdef CLOTHHIP_EXP_V8
-#define CLOTH_VARIANTS_LEAN(X, T) X(T, 256, 3, 0, true) X(T, 256, 3, -1, true) X(T, 512, 2, 2, true) X(T, 384, 2, 2, true) X(T, 256, 3, 2, true)
-#else
+// the LEAN builds (fp32 only: three / four cloths per CU for the 25x25 class; the whole CU for the 512 x 5 grids)
+#ifdef CLOTHHIP_FAST_BUILD
 #define CLOTH_VARIANTS_LEAN(X, T) X(T, 256, 3, 0, true) X(T, 256, 3, -1, true)
+#else
+#define CLOTH_VARIANTS_LEAN(X, T) X(T, 256, 3, 0, true) X(T, 256, 3, -1, true) X(T, 512, 5, 3, true)
 #endif
 
 template <typename T, int FUSED> static const void *stepper_fn_t(const clothhip_handle *h) {
@@ -714,7 +714,7 @@ template <typename T, int FUSED> static void launch_run(clothhip_handle *h, cons
         hipLaunchKernelGGL((k_run_schedule<T_, NT, PPT, TAB, RR, FUSED>), dim3(h->E), dim3(NT), h->lds_bytes, h->stream, a); \
         int occ_ = 0;                                                                                   \
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_, (const void *)k_run_schedule<T_, NT, PPT, TAB, RR, FUSED>, NT, (size_t)h->lds_bytes) != hipSuccess) { (void)hipGetLastError(); occ_ = 0; } \
-        const int32_t v_[10] = {NT, PPT, TAB, RR ? 1 : 0, ((TAB <= 0 || TAB == 2) && RR && sizeof(T_) == 4) ? 1 : 0, FUSED, h->lds_bytes, occ_, h->n_cus, sizeof(T_) == 4 ? 1 : 0}; \
+        const int32_t v_[10] = {NT, PPT, TAB, RR ? 1 : 0, v_lean(TAB, RR, (int)sizeof(T_)) ? 1 : 0, FUSED, h->lds_bytes, occ_, h->n_cus, sizeof(T_) == 4 ? 1 : 0}; \
         memcpy(h->last_variant, v_, sizeof(v_)); h->have_variant = true;                                \
         return;                                                                                         \
     }
@@ -813,7 +813,7 @@ static int fused_scratch(const clothhip_handle *h, int *need_out) {
     int NS = 1; while (NS < h->P) NS <<= 1;
     const int NH = h->Ppad + 8;
     *need_out = 2 * NS * (int)h->tsz + (2 * NH + 64) * 8;
-    const LdsLayout lay((int)h->tsz, h->Ppad, h->Spad, h->HT, h->tab, h->cell_copy);
+    const LdsLayout lay((int)h->tsz, h->Ppad, h->Spad, h->HT, v_ldstab(h->tab) ? 1 : 0, h->cell_copy);
     return lay.total - lay.wtab;
 }
 

@@ -39,7 +39,8 @@ def test_lean_variant_is_bit_identical_to_the_standard_f32_variant(tier, build, 
     assert not va_f["lean"] and not va_s["lean"] and va_f["fused"] >= 1 and va_s["fused"] == 0, (va_f, va_s)
     for v in (vb_f, vb_s):
         assert v["lean"] and v["threads"] == 256 and v["table_mode"] == (0 if build == 3 else -1), v
-        assert v["cloths_per_cu"] == build, v                        # three / four cloths resident per CU
+        assert v["cloths_per_cu"] >= build, v                        # three / four cloths resident per CU (a build that needs fewer
+                                                                     # registers than its cap may fit one more)
     assert va_f["cloths_per_cu"] == 2, va_f
     assert a["executed"].sum() > 100000 and a["exec2"].sum() > 10000
     for k in a:

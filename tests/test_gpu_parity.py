@@ -63,7 +63,8 @@ def test_f64_bit_exact_vs_reference_golden(name, oracle_lib):
 
 # (name, CLOTHHIP_DEBUG_LEAN): 0 = the standard fp32 variant; 3 / 4 = the LEAN variant's two builds (25x25 only), pinned to the
 # reference's checkpoints DIRECTLY (cloth.pyx:221-237 evaluation order), not only to the standard variant
-F32_WINDOW_CASES = [(n, 0) for n in F32_WINDOWS] + [(n, l) for n in F32_WINDOWS if "_50" not in n for l in (3, 4)]
+# 50x50 (512 threads x 5 particles, one cloth per CU): -1 = whatever clothhip_create picks, which is the LEAN arithmetic
+F32_WINDOW_CASES = [(n, 0) for n in F32_WINDOWS] + [(n, l) for n in F32_WINDOWS if "_50" not in n for l in (3, 4)] + [("g_traj_fold_50.npz", -1)]
 
 
 @pytest.mark.parametrize("name,lean", F32_WINDOW_CASES)
@@ -73,7 +74,10 @@ def test_f32_teacher_forced_windows(name, lean, oracle_lib, monkeypatch):
     windows up to 200 substeps, 2e-5 for windows of <= 10 substeps. Run for the standard variant and for both builds of the
     LEAN variant; the library reports which variant each launch ran (clothhip_last_variant)."""
     from gym_cloth_amd import ClothBatch
-    monkeypatch.setenv("CLOTHHIP_DEBUG_LEAN", str(lean))
+    if lean >= 0:
+        monkeypatch.setenv("CLOTHHIP_DEBUG_LEAN", str(lean))
+    else:
+        monkeypatch.delenv("CLOTHHIP_DEBUG_LEAN", raising=False)
     g = oracle_lib.load_golden(name)
     b = ClothBatch(cfg_from_golden(g), n_envs=1, precision="f32")
     rp = BatchReplay(b)
@@ -94,8 +98,10 @@ def test_f32_teacher_forced_windows(name, lean, oracle_lib, monkeypatch):
         oracle_lib.replay_ops(rp, seg)
         var = b.last_variant()
         assert var["lean"] == (lean != 0) and var["precision"] == "f32", var
-        if lean:
+        if lean > 0:
             assert var["table_mode"] == (0 if lean == 3 else -1) and var["threads"] == 256, var
+        if lean < 0:
+            assert var["table_mode"] == 3 and var["threads"] == 512 and var["cloths_per_cu"] == 1, var
         pos = b.positions()[0]
         err = max_abs(pos, g["cp_pos"][k + 1])
         tol = 5e-7 if nsub == 1 else (5e-6 if nsub <= 10 else (1e-4 if nsub <= 60 else 2e-3))
