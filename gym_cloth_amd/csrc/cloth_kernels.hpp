@@ -280,9 +280,8 @@ struct LdsLayout {
         auto take = [&](int bytes) { int r = o; o += (bytes + 15) / 16 * 16; return r; };
         cur = take(4 * Ppad * tsz);
         eps = take(EPSTATE_LDS_BYTES);   // EpState (fused episodes)
-        wtab = take(tab >= 1 ? Spad * (tsz == 8 ? 16 : 8) : 0);   // WEnt<T>[Spad]; everything from here on doubles as scratch of the
-                                                                  // in-kernel metrics and is rebuilt afterwards
-        hkey = take(HT * 4);
+        wtab = take(tab >= 1 ? Spad * (tsz == 8 ? 16 : 8) : 0);   // WEnt<T>[Spad]
+        hkey = take(HT * 4);         // everything from here on doubles as scratch of the in-kernel metrics and is rebuilt afterwards
         hco = take(HT * 4);          // (fill cursor << 16) | member count
         memb = take(Ppad * 2);
         slot = take(Ppad * 2);
@@ -917,7 +916,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
     // everything in LDS behind the particle records: static tables, hash table, sweep flags (also re-run after the in-kernel
     // metrics, which borrow that region as scratch)
     auto init_lds = [&](int tear_flag, const uint32_t *s_ent, const T *s_rest) {
-        if (v_ldstab(TAB)) {
+        if (v_ldstab(TAB) && s_ent != nullptr) {         // (nullptr: the table in LDS is intact, only the scratch behind it is rebuilt)
             WEnt<T> *d0 = reinterpret_cast<WEnt<T> *>(smem + lay.wtab);
             for (int i = tid; i < A.Spad; i += NT) { WEnt<T> w_; w_.ab = s_ent[i]; w_.rest = s_rest[i]; d0[i] = w_; }
         }
@@ -1995,8 +1994,10 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
             if (op == OP_ACTION || op == OP_RESET_COND || op == OP_RESET_END) {
                 // cloth_env.py:1020-1098 on the LDS-resident state; the sort buffers borrow the LDS behind the particle records
                 auto src = [&](int i, double &x, double &y, double &z) { const Pt<T> c = cur[i]; x = (double)c.x; y = (double)c.y; z = (double)c.z; };
-                metrics_block<NT, T>(src, P, F.NS, F.NH, smem + lay.wtab, tid, F.half_thickness, mo);
-                init_lds(tear_now, F.wt_ent, F.rest + (size_t)e * F.rest_stride);
+                // (the sort buffers and the hull stack live BEHIND the window table -- hash table, member lists, cell-ordered copy: all
+                //  rebuilt below --, so the table itself stays in LDS for the whole launch and is not re-read from L2 after every action)
+                metrics_block<NT, T>(src, P, F.NS, F.NH, smem + lay.hkey, tid, F.half_thickness, mo);
+                init_lds(tear_now, nullptr, nullptr);
                 __syncthreads();
             }
             if (op == OP_ACTION && F.obs) {                                                       // '1d' observation, cloth_env.py:196-200

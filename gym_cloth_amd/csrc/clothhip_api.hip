@@ -357,7 +357,7 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
             // the in-kernel metrics borrow the region behind the episode state (clothhip_fused_supported): it must hold them here too
             int NS_ = 1; while (NS_ < h->P) NS_ <<= 1;
             const LdsLayout ll(tsz, h->Ppad, h->Spad, h->HT, 0, cc);
-            if (ll.total - ll.wtab < 2 * NS_ * tsz + (2 * (h->Ppad + 8) + 64) * 8) h->lean = false;
+            if (ll.total - ll.hkey < 2 * NS_ * tsz + (2 * (h->Ppad + 8) + 64) * 8) h->lean = false;
         }
         if (h->lds_bytes > 160 * 1024) { free_handle(h); return fail(CLOTHHIP_EINVAL, "n_side %d needs %d B of LDS (> 160 KiB)", h->N, h->lds_bytes); }
         if (h->lean) {                                   // the lean kernels too (which layout runs is decided per launch)
@@ -814,7 +814,7 @@ static int fused_scratch(const clothhip_handle *h, int *need_out) {
     const int NH = h->Ppad + 8;
     *need_out = 2 * NS * (int)h->tsz + (2 * NH + 64) * 8;
     const LdsLayout lay((int)h->tsz, h->Ppad, h->Spad, h->HT, v_ldstab(h->tab) ? 1 : 0, h->cell_copy);
-    return lay.total - lay.wtab;
+    return lay.total - lay.hkey;
 }
 
 extern "C" int clothhip_fused_supported(const clothhip_handle *h) {
