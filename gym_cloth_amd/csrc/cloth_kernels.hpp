@@ -826,11 +826,13 @@ __host__ __device__ inline uint32_t lean_valid_mask(int r, int c, int N) {
 // How a (TAB, REST_REG, precision) triple is compiled:
 //   standard arithmetic   TAB 1: window table + rest lengths resident in LDS; TAB 0: streamed from L2
 //   LEAN arithmetic       (REST_REG, fp32) TAB 0: built for three cloths per CU (168 VGPRs), -1: for four (128), 3: the whole CU for one cloth
-//                         (the large grids); the table is streamed from L2 in all three
-constexpr bool v_lean(int TAB, bool RR, int tsz) { return (TAB <= 0 || TAB == 3) && RR && tsz == 4; }
-constexpr bool v_ldstab(int TAB) { return TAB == 1; }
+//                         (the large grids) -- the table streamed from L2 in these three --; 2: window table in LDS, two cloths per CU
+//                         (with 512 threads x 2 particles: eight waves per cloth at 128 VGPRs, the headline variant)
+constexpr bool v_lean(int TAB, bool RR, int tsz) { return (TAB <= 0 || TAB == 2 || TAB == 3) && RR && tsz == 4; }
+constexpr bool v_ldstab(int TAB) { return TAB == 1 || TAB == 2; }
 constexpr int v_waves_per_eu(int NT, int TAB, bool lean) {      // __launch_bounds__' second argument: waves per SIMD
     if (!lean || TAB == 3) return NT <= 512 ? 2 : NT / 256;
+    if (TAB == 2) return NT / 128;                               // two cloths per CU
     return TAB < 0 ? 4 : 3;
 }
 template <typename T, int NT, int PPT, int TAB, bool REST_REG, int FUSED>

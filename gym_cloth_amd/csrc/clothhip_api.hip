@@ -63,12 +63,12 @@ struct clothhip_handle {
     // It needs ONE shared rest table whose fp32 values are one per spring type (checked on the device's table whenever that table
     // may have changed) and the regular gather stencil (checked once); otherwise the (0, false) variant runs on the same layout.
     bool lean = false, lean_dirty = true, lean_ok = false, lean_stencil_ok = false;
-    int lean_r = 3;         // cloths per CU the chosen LEAN build is compiled for (3: 168 VGPRs, 4: 128 VGPRs)
+    int lean_r = 3;         // cloths per CU the chosen LEAN build is compiled for (3: 168 VGPRs, 4: 128 VGPRs; 2: eight waves per cloth, table in LDS; 1: the large grids)
     float pal[3] = {0, 0, 0};
     int32_t last_variant[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // what the last launch ran (clothhip_last_variant)
     bool have_variant = false;
     int n_cus = 0;
-    struct Layout { int tab; bool rest_reg; int cell_copy; int lds_bytes; } lay_std = {0, false, 0, 0}, lay_lean = {0, true, 0, 0};
+    struct Layout { int nt, ppt, tab; bool rest_reg; int cell_copy; int lds_bytes; } lay_std = {256, 3, 0, false, 0, 0}, lay_lean = {256, 3, 0, true, 0, 0};
     double *d_levels = nullptr, *d_xy = nullptr, *d_radius = nullptr, *d_cov = nullptr, *d_vinv = nullptr;
     uint8_t *d_oob = nullptr;
     int32_t *d_hcnt = nullptr;      // per env: #points with z < thickness/2 (height reward, cloth_env.py:1047-1073)
@@ -301,22 +301,25 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
             h->n_cus = cus;
             // substeps/s of ONE resident cloth at 2 (standard), 3 and 4 cloths per CU, relative to the standard variant's: measured
             // by tools/measure_pick_table.py on the bench workload and written to lean_rates.hpp (its output: profiles/)
-            const double rate[3] = {1.0, LEAN_RATE_3_PER_CU, LEAN_RATE_4_PER_CU};
+            // r = 2: the EIGHT-WAVE build (512 threads x 2 particles, LEAN arithmetic, window table in LDS) when the flat palette holds, else
+            // the standard variant (256 x 3); r = 3, 4: the LEAN builds with the table streamed from L2
+            const bool lean_able = h->nt == 256 && precision == CLOTHHIP_F32;
+            const double rate[3] = {lean_able ? LEAN_RATE_2_PER_CU_8W : 1.0, LEAN_RATE_3_PER_CU, LEAN_RATE_4_PER_CU};
             double best = 0.0; int best_r = 2;
             for (int r = 2; r <= 4; r++) {
                 const double v = rate[r - 2] / (double)((h->E + r * cus - 1) / (r * cus));
                 if (v > best * 1.02) { best = v; best_r = r; }
             }
-            h->lean = h->nt == 256 && precision == CLOTHHIP_F32 && best_r > 2;
-            h->lean_r = best_r > 2 ? best_r : 3;
+            h->lean = lean_able;
+            h->lean_r = best_r;
             // the large grids (512 threads x 5 particles, one cloth per CU): the LEAN arithmetic frees the 60 registers of gather
             // entries and takes the rest lengths off the L2 path; the standard variant stays as the fallback (per-env rest tables)
             if (h->nt == 512 && h->ppt == 5 && precision == CLOTHHIP_F32) { h->lean = true; h->lean_r = 1; }
         }
-        if (const char *t = getenv("CLOTHHIP_DEBUG_LEAN")) {      // 0: never; 3 (or 1) / 4: that build whatever the batch size (256-thread grids)
+        if (const char *t = getenv("CLOTHHIP_DEBUG_LEAN")) {      // 0: never; 8 (or 2): the eight-wave build; 3 (or 1) / 4: that LEAN build whatever the batch size
             const int v = atoi(t);
             if (v == 0) h->lean = false;
-            else if (h->nt == 256 && precision == CLOTHHIP_F32) { h->lean = true; h->lean_r = v == 4 ? 4 : 3; }
+            else if (h->nt == 256 && precision == CLOTHHIP_F32) { h->lean = true; h->lean_r = (v == 8 || v == 2) ? 2 : (v == 4 ? 4 : 3); }
         }
         if (h->lean) {
             // the arithmetic stencil of the LEAN kernel against the gather table built from the reference's spring list
@@ -344,15 +347,21 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
         h->cell_copy = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, h->tab, 1).total <= budget ? 1 : 0;
         if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) h->cell_copy = h->cell_copy && atoi(t);
         h->lds_bytes = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, h->tab, h->cell_copy).total;
-        h->lay_std = {h->tab, h->rest_reg, h->cell_copy, h->lds_bytes};
+        h->lay_std = {h->nt, h->ppt, h->tab, h->rest_reg, h->cell_copy, h->lds_bytes};
         if (h->lean) {                                   // the lean layout: window table streamed from L2, 33 KB of LDS
             int cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, 1).total <= (160 * 1024) / std::max(h->lean_r, 3) ? 1 : 0;
             if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) cc = cc && atoi(t);
-            h->lay_lean = {h->lean_r >= 4 ? 3 - h->lean_r : 0, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, cc).total};
+            h->lay_lean = {h->nt, h->ppt, h->lean_r >= 4 ? 3 - h->lean_r : 0, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, cc).total};
+            if (h->lean_r == 2) {                        // eight waves per cloth, two cloths per CU: the standard variant's LDS budget
+                cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 1, 1).total <= 80 * 1024 ? 1 : 0;
+                if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) cc = cc && atoi(t);
+                h->lay_lean = {512, 2, 2, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 1, cc).total};
+                if (h->lay_lean.lds_bytes > 80 * 1024 || h->P > 1024) h->lean = false;      // (the table must fit beside a second cloth)
+            }
             if (h->lean_r == 1) {                        // the whole CU: same LDS budget as the standard variant of these grids
                 cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, 1).total <= 160 * 1024 ? 1 : 0;
                 if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) cc = cc && atoi(t);
-                h->lay_lean = {3, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, cc).total};
+                h->lay_lean = {h->nt, h->ppt, 3, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, cc).total};
             }
             // the in-kernel metrics borrow the region behind the episode state (clothhip_fused_supported): it must hold them here too
             int NS_ = 1; while (NS_ < h->P) NS_ <<= 1;
@@ -361,14 +370,14 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
         }
         if (h->lds_bytes > 160 * 1024) { free_handle(h); return fail(CLOTHHIP_EINVAL, "n_side %d needs %d B of LDS (> 160 KiB)", h->N, h->lds_bytes); }
         if (h->lean) {                                   // the lean kernels too (which layout runs is decided per launch)
-            const clothhip_handle::Layout keep = {h->tab, h->rest_reg, h->cell_copy, h->lds_bytes};
-            h->tab = h->lay_lean.tab; h->rest_reg = h->lay_lean.rest_reg;
+            const clothhip_handle::Layout keep = {h->nt, h->ppt, h->tab, h->rest_reg, h->cell_copy, h->lds_bytes};
+            h->nt = h->lay_lean.nt; h->ppt = h->lay_lean.ppt; h->tab = h->lay_lean.tab; h->rest_reg = h->lay_lean.rest_reg;
             for (int f = 0; f < 3; f++) {
                 const void *fl = stepper_fn(h, f);
                 if (!fl) { free_handle(h); return fail(CLOTHHIP_EINVAL, "no lean stepper variant for n_side %d", h->N); }
                 HC(hipFuncSetAttribute(fl, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             }
-            h->tab = keep.tab; h->rest_reg = keep.rest_reg;
+            h->nt = keep.nt; h->ppt = keep.ppt; h->tab = keep.tab; h->rest_reg = keep.rest_reg;
         }
         const void *fn = stepper_fn(h, 0), *fnf = stepper_fn(h, 1), *fnf2 = stepper_fn(h, 2);
         if (!fn || !fnf || !fnf2) { free_handle(h); return fail(CLOTHHIP_EINVAL, "no stepper variant for n_side %d", h->N); }
@@ -672,7 +681,7 @@ static int lean_refresh(clothhip_handle *h) {
         }
     }
     const clothhip_handle::Layout &L = (h->lean_ok && h->rest_stride == 0) ? h->lay_lean : h->lay_std;
-    h->tab = L.tab; h->rest_reg = L.rest_reg; h->cell_copy = L.cell_copy; h->lds_bytes = L.lds_bytes;
+    h->nt = L.nt; h->ppt = L.ppt; h->tab = L.tab; h->rest_reg = L.rest_reg; h->cell_copy = L.cell_copy; h->lds_bytes = L.lds_bytes;
     return 0;
 }
 
@@ -684,11 +693,11 @@ static int lean_refresh(clothhip_handle *h) {
     X(T, 256, 3, 1, true) X(T, 256, 3, 1, false) X(T, 256, 3, 0, false)   \
     X(T, 512, 5, 0, false) X(T, 512, 5, 1, false) X(T, 1024, 3, 0, false) X(T, 1024, 4, 0, false)
 #endif
-// the LEAN builds (fp32 only: three / four cloths per CU for the 25x25 class; the whole CU for the 512 x 5 grids)
+// the LEAN builds (fp32 only; 25x25 class: three / four cloths per CU, and eight waves per cloth at two per CU; the whole CU for the 512 x 5 grids)
 #ifdef CLOTHHIP_FAST_BUILD
-#define CLOTH_VARIANTS_LEAN(X, T) X(T, 256, 3, 0, true) X(T, 256, 3, -1, true)
+#define CLOTH_VARIANTS_LEAN(X, T) X(T, 256, 3, 0, true) X(T, 256, 3, -1, true) X(T, 512, 2, 2, true)
 #else
-#define CLOTH_VARIANTS_LEAN(X, T) X(T, 256, 3, 0, true) X(T, 256, 3, -1, true) X(T, 512, 5, 3, true)
+#define CLOTH_VARIANTS_LEAN(X, T) X(T, 256, 3, 0, true) X(T, 256, 3, -1, true) X(T, 512, 2, 2, true) X(T, 512, 5, 3, true)
 #endif
 
 template <typename T, int FUSED> static const void *stepper_fn_t(const clothhip_handle *h) {

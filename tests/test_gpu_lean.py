@@ -1,5 +1,5 @@
-"""The LEAN stepper variant (fp32, flat tiers; compiled for three and for four cloths per CU: chosen by clothhip_create for batches
-it pays for, forced here with CLOTHHIP_DEBUG_LEAN): the gather stencil recomputed from the grid position and rest lengths from a three-value palette are a
+"""The LEAN stepper variant (fp32, flat tiers; compiled for three and for four cloths per CU and -- eight waves per cloth, window table in
+LDS -- for two: chosen by clothhip_create from the batch size, forced here with CLOTHHIP_DEBUG_LEAN): the gather stencil recomputed from the grid position and rest lengths from a three-value palette are a
 different HOME for the same numbers, not different arithmetic -- its records and particles equal the standard fp32 variant's bit
 for bit, over whole episode launches with resets and over the per-step path; and it steps aside (standard variant, same results)
 when the rest table is not a palette (tier 2: per-env rest lengths)."""
@@ -31,13 +31,16 @@ def _run(tier, lean, monkeypatch, E=48, T=5):
     return res, var_fused, var_step
 
 
-@pytest.mark.parametrize("tier,build", [("tier1", 3), ("tier3", 3), ("tier1", 4)])
+@pytest.mark.parametrize("tier,build", [("tier1", 3), ("tier3", 3), ("tier1", 4), ("tier1", 8), ("tier3", 8)])
 def test_lean_variant_is_bit_identical_to_the_standard_f32_variant(tier, build, monkeypatch):
     a, va_f, va_s = _run(tier, 0, monkeypatch)
     b, vb_f, vb_s = _run(tier, build, monkeypatch)
     # the library says which kernel ran: without this the comparison below could not tell "bit-identical" from "never ran"
     assert not va_f["lean"] and not va_s["lean"] and va_f["fused"] >= 1 and va_s["fused"] == 0, (va_f, va_s)
     for v in (vb_f, vb_s):
+        if build == 8:                                               # eight waves per cloth, window table in LDS, two cloths per CU
+            assert v["lean"] and v["threads"] == 512 and v["particles_per_thread"] == 2 and v["table_mode"] == 2 and v["cloths_per_cu"] >= 2, v
+            continue
         assert v["lean"] and v["threads"] == 256 and v["table_mode"] == (0 if build == 3 else -1), v
         assert v["cloths_per_cu"] >= build, v                        # three / four cloths resident per CU (a build that needs fewer
                                                                      # registers than its cap may fit one more)

@@ -61,10 +61,11 @@ def test_f64_bit_exact_vs_reference_golden(name, oracle_lib):
     assert not bad, bad[:5]
 
 
-# (name, CLOTHHIP_DEBUG_LEAN): 0 = the standard fp32 variant; 3 / 4 = the LEAN variant's two builds (25x25 only), pinned to the
+# (name, CLOTHHIP_DEBUG_LEAN): 0 = the standard fp32 variant; 3 / 4 = the LEAN variant's builds for three / four cloths per CU, 8 = its
+# eight-wave build (512 threads x 2 particles, window table in LDS: what a batch of <= 512 flat-tier cloths runs), 25x25 only, pinned to the
 # reference's checkpoints DIRECTLY (cloth.pyx:221-237 evaluation order), not only to the standard variant
 # 50x50 (512 threads x 5 particles, one cloth per CU): -1 = whatever clothhip_create picks, which is the LEAN arithmetic
-F32_WINDOW_CASES = [(n, 0) for n in F32_WINDOWS] + [(n, l) for n in F32_WINDOWS if "_50" not in n for l in (3, 4)] + [("g_traj_fold_50.npz", -1)]
+F32_WINDOW_CASES = [(n, 0) for n in F32_WINDOWS] + [(n, l) for n in F32_WINDOWS if "_50" not in n for l in (3, 4, 8)] + [("g_traj_fold_50.npz", -1)]
 
 
 @pytest.mark.parametrize("name,lean", F32_WINDOW_CASES)
@@ -98,8 +99,10 @@ def test_f32_teacher_forced_windows(name, lean, oracle_lib, monkeypatch):
         oracle_lib.replay_ops(rp, seg)
         var = b.last_variant()
         assert var["lean"] == (lean != 0) and var["precision"] == "f32", var
-        if lean > 0:
+        if lean in (3, 4):
             assert var["table_mode"] == (0 if lean == 3 else -1) and var["threads"] == 256, var
+        if lean == 8:
+            assert var["table_mode"] == 2 and var["threads"] == 512 and var["particles_per_thread"] == 2, var
         if lean < 0:
             assert var["table_mode"] == 3 and var["threads"] == 512 and var["cloths_per_cu"] == 1, var
         pos = b.positions()[0]
