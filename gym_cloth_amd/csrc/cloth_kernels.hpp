@@ -830,13 +830,14 @@ __host__ __device__ inline uint32_t lean_valid_mask(int r, int c, int N) {
 //                         (with 512 threads x 2 particles: eight waves per cloth at 128 VGPRs, the headline variant)
 constexpr bool v_lean(int TAB, bool RR, int tsz) { return (TAB <= 0 || TAB == 2 || TAB == 3) && RR && tsz == 4; }
 constexpr bool v_ldstab(int TAB) { return TAB == 1 || TAB == 2; }
-constexpr int v_waves_per_eu(int NT, int TAB, bool lean) {      // __launch_bounds__' second argument: waves per SIMD
+constexpr int v_waves_per_eu(int NT, int TAB, bool lean, int PPT = 0) {      // __launch_bounds__' second argument: waves per SIMD
+    if (!lean && NT == 512 && PPT == 2) return 4;                // eight waves per cloth, two cloths per CU (standard arithmetic)
     if (!lean || TAB == 3) return NT <= 512 ? 2 : NT / 256;
     if (TAB == 2) return NT / 128;                               // two cloths per CU
     return TAB < 0 ? 4 : 3;
 }
 template <typename T, int NT, int PPT, int TAB, bool REST_REG, int FUSED>
-__global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (int)sizeof(T)))) void k_run_schedule(StepArgs<T> A) {
+__global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (int)sizeof(T)), PPT)) void k_run_schedule(StepArgs<T> A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int e = blockIdx.x;
     const int tid = threadIdx.x;
@@ -1614,8 +1615,8 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
                 // (left to itself the compiler unrolls the member loops several times: fine at 256 VGPRs, 500 spilled registers at
                 //  the LEAN variant's 168 -- that variant gets its own copy of the loops, not unrolled)
 #ifndef CLOTHHIP_BISECT_NOPRECHECK
-                if constexpr (LEAN) {
-                    // register-lean form: one owned particle after the other (a real branch each: a scheduling region of its own),
+                if constexpr (LEAN || (NT == 512 && PPT == 2)) {
+                    // register-lean form (the builds with a VGPR cap: LEAN, eight waves per cloth): one owned particle after the other (a real branch each: a scheduling region of its own),
                     // the member loop not unrolled; the trip count is the wave's largest member count for THAT particle
 #pragma unroll
                     for (int q = 0; q < PPT; q++) {

@@ -223,7 +223,12 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
     h->wt = build_windows(h->topo, build_levels(h->topo));
     h->S = h->topo.S; h->Spad = h->wt.n_slots;               // rest-length arrays are kept in window-table slot order
     // threads per cloth x particles per thread (compile-time variants of the stepper)
-    if (h->P <= 768) { h->nt = 256; h->ppt = 3; }
+    // P <= 768 (the 25x25 class, two cloths per CU): EIGHT waves per cloth -- 512 threads x 2 particles, compiled for 128 VGPRs: the cell
+    // sweeps have eight ticket takers and the parallel phases two waves per SIMD to hide their LDS latency (+4 % fp32 standard
+    // arithmetic, +9 % fp64, +13 % tier 2 over the four-wave 256 x 3 variants, bit-identical; CLOTHHIP_DEBUG_W8=0 selects those)
+    const bool small_grid = h->P <= 768;
+    const bool w8 = !(getenv("CLOTHHIP_DEBUG_W8") && atoi(getenv("CLOTHHIP_DEBUG_W8")) == 0);
+    if (small_grid) { h->nt = w8 ? 512 : 256; h->ppt = w8 ? 2 : 3; }
     else if (h->P <= 2560 && !getenv("CLOTHHIP_DEBUG_NT1024")) { h->nt = 512; h->ppt = 5; }
     else if (h->P <= 3072) { h->nt = 1024; h->ppt = 3; } else { h->nt = 1024; h->ppt = 4; }
     h->HT = 64; h->ht_bits = 0;
@@ -285,7 +290,7 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
     {
         const int tsz = (int)h->tsz;
         // 256-thread variants: two cloths per CU (<= 80 KiB each); the larger ones own the CU (<= 160 KiB)
-        const int budget = h->nt == 256 ? 80 * 1024 : 160 * 1024;
+        const int budget = small_grid ? 80 * 1024 : 160 * 1024;
         const int tmax = h->nt <= 512 ? 1 : 0;
         h->tab = (tmax >= 1 && LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 1, 0).total <= budget) ? 1 : 0;
         if (const char *t = getenv("CLOTHHIP_DEBUG_TAB_LDS")) h->tab = std::min(h->tab, atoi(t));
@@ -303,7 +308,7 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
             // by tools/measure_pick_table.py on the bench workload and written to lean_rates.hpp (its output: profiles/)
             // r = 2: the EIGHT-WAVE build (512 threads x 2 particles, LEAN arithmetic, window table in LDS) when the flat palette holds, else
             // the standard variant (256 x 3); r = 3, 4: the LEAN builds with the table streamed from L2
-            const bool lean_able = h->nt == 256 && precision == CLOTHHIP_F32;
+            const bool lean_able = small_grid && precision == CLOTHHIP_F32;
             const double rate[3] = {lean_able ? LEAN_RATE_2_PER_CU_8W : 1.0, LEAN_RATE_3_PER_CU, LEAN_RATE_4_PER_CU};
             double best = 0.0; int best_r = 2;
             for (int r = 2; r <= 4; r++) {
@@ -312,14 +317,15 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
             }
             h->lean = lean_able;
             h->lean_r = best_r;
-            // the large grids (512 threads x 5 particles, one cloth per CU): the LEAN arithmetic frees the 60 registers of gather
-            // entries and takes the rest lengths off the L2 path; the standard variant stays as the fallback (per-env rest tables)
-            if (h->nt == 512 && h->ppt == 5 && precision == CLOTHHIP_F32) { h->lean = true; h->lean_r = 1; }
+            // the large grids (one cloth per CU): the LEAN arithmetic frees the registers of the gather entries and takes the rest lengths
+            // off the L2 path, which lets SIXTEEN waves step a cloth at 128 VGPRs (1024 threads x 3 or 4 particles; 50x50: 2.90 M/s
+            // standard 512 x 5 -> 3.05 LEAN 512 x 5 -> 3.26 LEAN 1024 x 3); the standard variant stays as the fallback (per-env rest tables)
+            if (!small_grid && precision == CLOTHHIP_F32) { h->lean = true; h->lean_r = 1; }
         }
         if (const char *t = getenv("CLOTHHIP_DEBUG_LEAN")) {      // 0: never; 8 (or 2): the eight-wave build; 3 (or 1) / 4: that LEAN build whatever the batch size
             const int v = atoi(t);
             if (v == 0) h->lean = false;
-            else if (h->nt == 256 && precision == CLOTHHIP_F32) { h->lean = true; h->lean_r = (v == 8 || v == 2) ? 2 : (v == 4 ? 4 : 3); }
+            else if (small_grid && precision == CLOTHHIP_F32) { h->lean = true; h->lean_r = (v == 8 || v == 2) ? 2 : (v == 4 ? 4 : 3); }
         }
         if (h->lean) {
             // the arithmetic stencil of the LEAN kernel against the gather table built from the reference's spring list
@@ -351,7 +357,7 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
         if (h->lean) {                                   // the lean layout: window table streamed from L2, 33 KB of LDS
             int cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, 1).total <= (160 * 1024) / std::max(h->lean_r, 3) ? 1 : 0;
             if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) cc = cc && atoi(t);
-            h->lay_lean = {h->nt, h->ppt, h->lean_r >= 4 ? 3 - h->lean_r : 0, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, cc).total};
+            h->lay_lean = {256, 3, h->lean_r >= 4 ? 3 - h->lean_r : 0, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, cc).total};   // (r = 3, 4: four waves per cloth)
             if (h->lean_r == 2) {                        // eight waves per cloth, two cloths per CU: the standard variant's LDS budget
                 cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 1, 1).total <= 80 * 1024 ? 1 : 0;
                 if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) cc = cc && atoi(t);
@@ -361,7 +367,7 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
             if (h->lean_r == 1) {                        // the whole CU: same LDS budget as the standard variant of these grids
                 cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, 1).total <= 160 * 1024 ? 1 : 0;
                 if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) cc = cc && atoi(t);
-                h->lay_lean = {h->nt, h->ppt, 3, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, cc).total};
+                h->lay_lean = {1024, h->P <= 3072 ? 3 : 4, 3, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, cc).total};
             }
             // the in-kernel metrics borrow the region behind the episode state (clothhip_fused_supported): it must hold them here too
             int NS_ = 1; while (NS_ < h->P) NS_ <<= 1;
@@ -686,10 +692,11 @@ static int lean_refresh(clothhip_handle *h) {
 }
 
 // compile-time variants: (threads per cloth, particles per thread) x tables-in-LDS level x rest-in-registers
-#ifdef CLOTHHIP_FAST_BUILD           // development builds: the 25x25 variants only (make fast)
-#define CLOTH_VARIANTS(X, T) X(T, 256, 3, 1, true) X(T, 256, 3, 1, false) X(T, 256, 3, 0, false)
+#ifdef CLOTHHIP_FAST_BUILD           // development builds: the 25x25-class variants only (make fast)
+#define CLOTH_VARIANTS(X, T) X(T, 512, 2, 1, false) X(T, 512, 2, 0, false) X(T, 256, 3, 1, true) X(T, 256, 3, 1, false) X(T, 256, 3, 0, false)
 #else
 #define CLOTH_VARIANTS(X, T)                                              \
+    X(T, 512, 2, 1, false) X(T, 512, 2, 0, false)                         \
     X(T, 256, 3, 1, true) X(T, 256, 3, 1, false) X(T, 256, 3, 0, false)   \
     X(T, 512, 5, 0, false) X(T, 512, 5, 1, false) X(T, 1024, 3, 0, false) X(T, 1024, 4, 0, false)
 #endif
@@ -697,7 +704,7 @@ static int lean_refresh(clothhip_handle *h) {
 #ifdef CLOTHHIP_FAST_BUILD
 #define CLOTH_VARIANTS_LEAN(X, T) X(T, 256, 3, 0, true) X(T, 256, 3, -1, true) X(T, 512, 2, 2, true)
 #else
-#define CLOTH_VARIANTS_LEAN(X, T) X(T, 256, 3, 0, true) X(T, 256, 3, -1, true) X(T, 512, 2, 2, true) X(T, 512, 5, 3, true)
+#define CLOTH_VARIANTS_LEAN(X, T) X(T, 256, 3, 0, true) X(T, 256, 3, -1, true) X(T, 512, 2, 2, true) X(T, 1024, 3, 3, true) X(T, 1024, 4, 3, true)
 #endif
 
 template <typename T, int FUSED> static const void *stepper_fn_t(const clothhip_handle *h) {

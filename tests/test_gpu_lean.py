@@ -61,3 +61,32 @@ def test_lean_handle_steps_aside_for_per_env_rest_tables(monkeypatch):
     assert not vf["lean"] and not vs["lean"], (vf, vs)              # it did step aside (clothhip_last_variant)
     for k in ("rew", "executed", "obs", "obs2", "exec2"):
         assert np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_four_wave_standard_variants_equal_the_eight_wave_ones(prec, monkeypatch):
+    """The standard arithmetic runs eight waves per cloth (512 threads x 2 particles) for the 25x25 class; the four-wave builds
+    (256 x 3, CLOTHHIP_DEBUG_W8=0) are the same arithmetic in another thread layout: identical records and particles, fp32 and fp64."""
+    import bench
+    from gym_cloth_amd.envs import ClothVecEnv
+    res = []
+    for w8 in ("1", "0"):
+        monkeypatch.setenv("CLOTHHIP_DEBUG_LEAN", "0")
+        monkeypatch.setenv("CLOTHHIP_DEBUG_W8", w8)
+        E, T = 16, 3
+        env = ClothVecEnv(bench.bench_cfg(25, 0.02, "tier1"), n_envs=E, precision=prec, consume_domrand_draws=False)
+        for e in range(E):
+            env.np_randoms[e] = np.random.RandomState(1000 + e)
+        env.reset()
+        acts = np.ascontiguousarray(np.stack([np.random.RandomState(2000 + e).uniform(-1, 1, size=(T, 4)) for e in range(E)], axis=1))
+        out = env.step_many(acts, auto_reset=True)
+        var = env.batch.last_variant()
+        assert not var["lean"] and var["threads"] == (512 if w8 == "1" else 256) and var["particles_per_thread"] == (2 if w8 == "1" else 3), var
+        assert var["cloths_per_cu"] >= 2, var
+        res.append((out["rew"].copy(), out["executed"].copy(), out["obs"].copy(), [x.copy() for x in env.batch.get_state()]))
+        env.close()
+    a, b = res
+    assert a[1].sum() > 20000
+    assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    for x, y in zip(a[3], b[3]):
+        assert np.array_equal(x, y)

@@ -64,7 +64,7 @@ def test_f64_bit_exact_vs_reference_golden(name, oracle_lib):
 # (name, CLOTHHIP_DEBUG_LEAN): 0 = the standard fp32 variant; 3 / 4 = the LEAN variant's builds for three / four cloths per CU, 8 = its
 # eight-wave build (512 threads x 2 particles, window table in LDS: what a batch of <= 512 flat-tier cloths runs), 25x25 only, pinned to the
 # reference's checkpoints DIRECTLY (cloth.pyx:221-237 evaluation order), not only to the standard variant
-# 50x50 (512 threads x 5 particles, one cloth per CU): -1 = whatever clothhip_create picks, which is the LEAN arithmetic
+# 50x50 (one cloth per CU): -1 = whatever clothhip_create picks, which is the LEAN arithmetic on sixteen waves (1024 threads x 3 particles)
 F32_WINDOW_CASES = [(n, 0) for n in F32_WINDOWS] + [(n, l) for n in F32_WINDOWS if "_50" not in n for l in (3, 4, 8)] + [("g_traj_fold_50.npz", -1)]
 
 
@@ -104,7 +104,7 @@ def test_f32_teacher_forced_windows(name, lean, oracle_lib, monkeypatch):
         if lean == 8:
             assert var["table_mode"] == 2 and var["threads"] == 512 and var["particles_per_thread"] == 2, var
         if lean < 0:
-            assert var["table_mode"] == 3 and var["threads"] == 512 and var["cloths_per_cu"] == 1, var
+            assert var["table_mode"] == 3 and var["threads"] == 1024 and var["particles_per_thread"] == 3 and var["cloths_per_cu"] == 1, var
         pos = b.positions()[0]
         err = max_abs(pos, g["cp_pos"][k + 1])
         tol = 5e-7 if nsub == 1 else (5e-6 if nsub <= 10 else (1e-4 if nsub <= 60 else 2e-3))
