@@ -595,10 +595,10 @@ def main():
                       n_side=25, E=512, precision=args.precision, init="tier2", mode=args.mode, steps=10, warmup=5, fuse_max=10,
                       step_ms=args.step_ms, **k5)
         if args.envs < 2048 and args.n_side == 25:
-            companion("2048 cloths per GPU (LEAN stepper variant, 4 cloths per CU: two generations of 1024 workgroups per launch)",
+            companion("2048 cloths per GPU (LEAN stepper variant at the residency clothhip_create picks: config.variant)",
                       n_side=25, E=2048, precision=args.precision, init="tier1", mode="fused", steps=5, warmup=0, fuse_max=5,
                       step_ms=1.3 * args.step_ms, **k5)
-            companion("1536 cloths per GPU (LEAN stepper variant, 3 cloths per CU: two generations of 768 workgroups per launch)",
+            companion("1536 cloths per GPU (LEAN stepper variant at the residency clothhip_create picks: config.variant)",
                       n_side=25, E=1536, precision=args.precision, init="tier1", mode="fused", steps=5, warmup=0, fuse_max=5,
                       step_ms=1.1 * args.step_ms, **k5)
         if args.n_side == 25:

@@ -147,6 +147,12 @@ def load():
         raise ClothHipError(
             "libclothhip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C gym_cloth_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    # ROCr keeps a per-queue scratch pool and serves a kernel whose scratch at full occupancy exceeds HSA_SCRATCH_SINGLE_LIMIT
+    # (default 140 MB) with a throttled wave count -- and, measured on MI355X / ROCm 7.2, a process that has once run such a kernel
+    # may then run a LATER stepper variant below its residency too (two 50x50 cloths per CU became 1.33: 5.0 -> 3.3 M substeps/s).
+    # The stepper variants with a VGPR cap spill a few registers in their cold episode code, so they all own some scratch. Unless
+    # the caller has set the limit, raise it (512 MB) before the HIP runtime comes up; a runtime that is already up ignores this.
+    os.environ.setdefault("HSA_SCRATCH_SINGLE_LIMIT", str(512 << 20))
     try:
         L = C.CDLL(LIB_PATH)
     except OSError as e:

@@ -136,7 +136,7 @@ template <typename T> struct StepArgs {
                                         // whose fp32 values are one per type: checked by the host before the variant is chosen)
     int32_t nW, wt_rshift;   // windows that hold springs; unit (log2 windows) of the entries' reach field
     int32_t N, P, Ppad, S, Spad;
-    int32_t HT, ht_bits;     // spatial hash table slots (power of two > P)
+    int32_t HT, ht_bits;     // spatial hash table slots (> P) and log2 of it (0: not a power of two)
     int32_t rest_stride;     // 0: one shared table
     int32_t cell_copy;       // 1: LDS holds a cell-ordered copy of the particle records for the collision pre-check
     int32_t phase_mask;      // debug/ablation: bit0 hooke+verlet, bit1 collide, bit2 plane, bit3 strain, bit4 no-skip
@@ -681,17 +681,22 @@ __device__ __forceinline__ void mt_skip_block(uint32_t *mt, uint64_t n, int tid)
 // ---- per-env metrics (cloth_env.py:1020-1098): coverage = area of the convex hull of the clipped (x,y) (same
 // monotone-chain + shoelace arithmetic, in double, as clothhip_hull_area on the host), variance_inv of z, out-of-bounds,
 // #(z < thickness/2). ONE workgroup of NT threads; `src(i, x, y, z)` yields particle i as doubles. Scratch (LDS):
-// sx/sy[NS] sort buffers + hx/hy[NH] hull stack (NH >= P + 2) + 64 doubles = (2 NS + 2 NH + 64) * 8 bytes.
+// sx/sy[NS] sort buffers (the handle's precision) + hx/hy[NH] hull stack of doubles (NH >= P + 2) + 64 doubles =
+// 2 NS sizeof(K) + (2 NH + 64) * 8 bytes (HULL_IDX: see below).
 // The reductions are done by the first 256 threads in a fixed tree, so the result does not depend on NT: the stand-alone
 // kernel (256 threads) and the in-kernel call of the episode stepper give the same bits.
 // Results: out[0] coverage, out[1] variance_inv, out[2] out-of-bounds (0/1), out[3] #(z < half_thick); valid for ALL
 // threads on return (the function ends with a barrier).
-template <int NT, typename K, typename Src>
+// HULL_IDX: the hull stack holds u16 INDICES into the sorted, de-duplicated points instead of their coordinates as doubles -- the chain's
+// arithmetic reads the same (double)sx / (double)sy values either way, at an eighth of the LDS: the variants whose LDS is tight take
+// it (two large-grid cloths per CU, five / six 25x25 cloths per CU); scratch = 2 NS sizeof(K) + 512 + 2 NH bytes then.
+template <int NT, typename K, typename Src, bool HULL_IDX = false>
 __device__ __forceinline__ void metrics_block(const Src &src, int P, int NS, int NH, unsigned char *scr, int tid, double half_thick,
                                               double out[4]) {
     K *sx = reinterpret_cast<K *>(scr), *sy = sx + NS;
-    double *hx = reinterpret_cast<double *>(sy + NS), *hy = hx + NH;
-    double *red = hy + NH;                                    // [64] reduction scratch
+    double *hx = reinterpret_cast<double *>(sy + NS), *hy = hx + (HULL_IDX ? 0 : NH);
+    double *red = HULL_IDX ? hx : hy + NH;                    // [64] reduction scratch
+    uint16_t *hs = reinterpret_cast<uint16_t *>(red + 64);    // HULL_IDX: [NH] hull stack of indices
     const int lane = tid & 63, wave = tid >> 6;
     const double INF = __longlong_as_double(0x7ff0000000000000LL);
     double mnx = INF, mxx = -INF, mny = INF, mxy = -INF, mnz = INF, mxz = -INF, sum = 0.0;
@@ -767,21 +772,24 @@ __device__ __forceinline__ void metrics_block(const Src &src, int P, int NS, int
             auto cross = [](double ox, double oy, double ax, double ay, double bx, double by) {
                 return (ax - ox) * (by - oy) - (ay - oy) * (bx - ox);
             };
+            auto HX = [&](int q) -> double { if constexpr (HULL_IDX) return (double)sx[hs[q]]; else return hx[q]; };
+            auto HY = [&](int q) -> double { if constexpr (HULL_IDX) return (double)sy[hs[q]]; else return hy[q]; };
+            auto PUSH = [&](int q, int i) { if constexpr (HULL_IDX) hs[q] = (uint16_t)i; else { hx[q] = (double)sx[i]; hy[q] = (double)sy[i]; } };
             int k = 0;
             for (int i = 0; i < m; i++) {
-                while (k >= 2 && cross(hx[k - 2], hy[k - 2], hx[k - 1], hy[k - 1], (double)sx[i], (double)sy[i]) <= 0) k--;
-                hx[k] = (double)sx[i]; hy[k] = (double)sy[i]; k++;
+                while (k >= 2 && cross(HX(k - 2), HY(k - 2), HX(k - 1), HY(k - 1), (double)sx[i], (double)sy[i]) <= 0) k--;
+                PUSH(k, i); k++;
             }
             for (int i = m - 2, t = k + 1; i >= 0; i--) {
-                while (k >= t && cross(hx[k - 2], hy[k - 2], hx[k - 1], hy[k - 1], (double)sx[i], (double)sy[i]) <= 0) k--;
-                hx[k] = (double)sx[i]; hy[k] = (double)sy[i]; k++;
+                while (k >= t && cross(HX(k - 2), HY(k - 2), HX(k - 1), HY(k - 1), (double)sx[i], (double)sy[i]) <= 0) k--;
+                PUSH(k, i); k++;
             }
             k--;
             if (k >= 3) {
                 double a2 = 0.0;
                 for (int i = 0; i < k; i++) {
                     const int n = (i + 1) % k;
-                    a2 += (hx[i] - hx[0]) * (hy[n] - hy[0]) - (hx[n] - hx[0]) * (hy[i] - hy[0]);
+                    a2 += (HX(i) - HX(0)) * (HY(n) - HY(0)) - (HX(n) - HX(0)) * (HY(i) - HY(0));
                 }
                 area = 0.5 * fabs(a2);
             }
@@ -826,15 +834,16 @@ __host__ __device__ inline uint32_t lean_valid_mask(int r, int c, int N) {
 // How a (TAB, REST_REG, precision) triple is compiled:
 //   standard arithmetic   TAB 1: window table + rest lengths resident in LDS; TAB 0: streamed from L2
 //   LEAN arithmetic       (REST_REG, fp32) TAB 0: built for three cloths per CU (168 VGPRs), -1: for four (128), 3: the whole CU for one cloth
-//                         (the large grids) -- the table streamed from L2 in these three --; 2: window table in LDS, two cloths per CU
+//                         (the large grids), 4: two large-grid cloths per CU -- the table streamed from L2 in these --; 2: table in LDS, two per CU
 //                         (with 512 threads x 2 particles: eight waves per cloth at 128 VGPRs, the headline variant)
-constexpr bool v_lean(int TAB, bool RR, int tsz) { return (TAB <= 0 || TAB == 2 || TAB == 3) && RR && tsz == 4; }
+constexpr bool v_lean(int TAB, bool RR, int tsz) { return (TAB <= 0 || TAB == 2 || TAB == 3 || TAB == 4) && RR && tsz == 4; }
 constexpr bool v_ldstab(int TAB) { return TAB == 1 || TAB == 2; }
+constexpr bool v_hull_idx(int TAB) { return TAB == 4 || TAB <= -2; }      // the in-kernel metrics' hull stack as u16 indices (tight LDS)
 constexpr int v_waves_per_eu(int NT, int TAB, bool lean, int PPT = 0) {      // __launch_bounds__' second argument: waves per SIMD
     if (!lean && NT == 512 && PPT == 2) return 4;                // eight waves per cloth, two cloths per CU (standard arithmetic)
     if (!lean || TAB == 3) return NT <= 512 ? 2 : NT / 256;
-    if (TAB == 2) return NT / 128;                               // two cloths per CU
-    return TAB < 0 ? 4 : 3;
+    if (TAB == 2 || TAB == 4) return NT / 128;                   // two cloths per CU (4: the large grids, table streamed)
+    return TAB < 0 ? 3 - TAB : 3;                                // TAB 0, -1, -2, -3: three, four, five, six cloths per CU
 }
 template <typename T, int NT, int PPT, int TAB, bool REST_REG, int FUSED>
 __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (int)sizeof(T)), PPT)) void k_run_schedule(StepArgs<T> A) {
@@ -1531,7 +1540,9 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
                     const int i = tid + q * NT;
                     const Pt<T> c = cur[i < P ? i : 0];                                           // own slot: no hazard
                     ckey[q] = cell_key<T>(k, c.x, c.y, c.z);
-                    ch[q] = (ckey[q] * 2654435761u) >> (32 - A.ht_bits);
+                    // (ht_bits 0: a table whose size is not a power of two -- the two-per-CU layout of the large grids -- is indexed by the
+                    //  high half of hash x size; which slot a cell gets never shows in the results)
+                    ch[q] = A.ht_bits ? (ckey[q] * 2654435761u) >> (32 - A.ht_bits) : __umulhi(ckey[q] * 2654435761u, (uint32_t)HT);
                     pend[q] = i < P; made[q] = false; anyp |= pend[q];
                 }
                 // linear probing; the table has >= 1.5 P slots, so a free one always exists -- the probe bound only
@@ -1543,7 +1554,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
                         if (pend[q]) {
                             const uint32_t old = atomicCAS(&hkey[ch[q]], KEY_EMPTY, ckey[q]);
                             if (old == KEY_EMPTY || old == ckey[q]) { pend[q] = false; made[q] = old == KEY_EMPTY; }
-                            else { ch[q] = (ch[q] + 1) & (uint32_t)(HT - 1); anyp = true; }
+                            else { ch[q] = ch[q] + 1u >= (uint32_t)HT ? 0u : ch[q] + 1u; anyp = true; }
                         }
                     }
                 }
@@ -1999,7 +2010,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
                 auto src = [&](int i, double &x, double &y, double &z) { const Pt<T> c = cur[i]; x = (double)c.x; y = (double)c.y; z = (double)c.z; };
                 // (the sort buffers and the hull stack live BEHIND the window table -- hash table, member lists, cell-ordered copy: all
                 //  rebuilt below --, so the table itself stays in LDS for the whole launch and is not re-read from L2 after every action)
-                metrics_block<NT, T>(src, P, F.NS, F.NH, smem + lay.hkey, tid, F.half_thickness, mo);
+                metrics_block<NT, T, decltype(src), v_hull_idx(TAB)>(src, P, F.NS, F.NH, smem + lay.hkey, tid, F.half_thickness, mo);
                 init_lds(tear_now, nullptr, nullptr);
                 __syncthreads();
             }

@@ -40,6 +40,11 @@ static int fail(int code, const char *fmt, ...) {
     } while (0)
 
 
+// LDS scratch of metrics_block (cloth_kernels.hpp): two sort buffers of NS values in the handle's precision, 64 doubles, NH u16 hull indices
+static inline int metrics_scratch_bytes(int NS, int NH, int tsz, bool hull_idx = false) {
+    return hull_idx ? 2 * NS * tsz + 64 * 8 + ((2 * NH + 15) / 16) * 16 : 2 * NS * tsz + (2 * NH + 64) * 8;
+}
+
 struct clothhip_handle {
     ClothParams prm{};
     int E = 0, N = 0, P = 0, Ppad = 0, S = 0, Spad = 0, precision = 0, device = 0;
@@ -68,7 +73,7 @@ struct clothhip_handle {
     int32_t last_variant[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // what the last launch ran (clothhip_last_variant)
     bool have_variant = false;
     int n_cus = 0;
-    struct Layout { int nt, ppt, tab; bool rest_reg; int cell_copy; int lds_bytes; } lay_std = {256, 3, 0, false, 0, 0}, lay_lean = {256, 3, 0, true, 0, 0};
+    struct Layout { int nt, ppt, tab; bool rest_reg; int cell_copy; int lds_bytes; int HT, ht_bits; } lay_std = {256, 3, 0, false, 0, 0, 0, 0}, lay_lean = {256, 3, 0, true, 0, 0, 0, 0};
     double *d_levels = nullptr, *d_xy = nullptr, *d_radius = nullptr, *d_cov = nullptr, *d_vinv = nullptr;
     uint8_t *d_oob = nullptr;
     int32_t *d_hcnt = nullptr;      // per env: #points with z < thickness/2 (height reward, cloth_env.py:1047-1073)
@@ -306,12 +311,13 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
             h->n_cus = cus;
             // substeps/s of ONE resident cloth at 2 (standard), 3 and 4 cloths per CU, relative to the standard variant's: measured
             // by tools/measure_pick_table.py on the bench workload and written to lean_rates.hpp (its output: profiles/)
-            // r = 2: the EIGHT-WAVE build (512 threads x 2 particles, LEAN arithmetic, window table in LDS) when the flat palette holds, else
-            // the standard variant (256 x 3); r = 3, 4: the LEAN builds with the table streamed from L2
+            // r = 2: the EIGHT-WAVE LEAN build (512 threads x 2 particles, window table in LDS) when the flat palette holds, else the
+            // standard variant; r = 3 .. 6: the four-wave LEAN builds with the table streamed from L2 (168 / 128 / 96 / 80 VGPRs; from
+            // five per CU on without the cell-ordered record copy: 22.6 KB of LDS per cloth)
             const bool lean_able = small_grid && precision == CLOTHHIP_F32;
-            const double rate[3] = {lean_able ? LEAN_RATE_2_PER_CU_8W : 1.0, LEAN_RATE_3_PER_CU, LEAN_RATE_4_PER_CU};
+            const double rate[5] = {lean_able ? LEAN_RATE_2_PER_CU_8W : 1.0, LEAN_RATE_3_PER_CU, LEAN_RATE_4_PER_CU, LEAN_RATE_5_PER_CU, LEAN_RATE_6_PER_CU};
             double best = 0.0; int best_r = 2;
-            for (int r = 2; r <= 4; r++) {
+            for (int r = 2; r <= 6; r++) {
                 const double v = rate[r - 2] / (double)((h->E + r * cus - 1) / (r * cus));
                 if (v > best * 1.02) { best = v; best_r = r; }
             }
@@ -322,10 +328,10 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
             // standard 512 x 5 -> 3.05 LEAN 512 x 5 -> 3.26 LEAN 1024 x 3); the standard variant stays as the fallback (per-env rest tables)
             if (!small_grid && precision == CLOTHHIP_F32) { h->lean = true; h->lean_r = 1; }
         }
-        if (const char *t = getenv("CLOTHHIP_DEBUG_LEAN")) {      // 0: never; 8 (or 2): the eight-wave build; 3 (or 1) / 4: that LEAN build whatever the batch size
+        if (const char *t = getenv("CLOTHHIP_DEBUG_LEAN")) {      // 0: never; 8 (or 2): the eight-wave build; 3 (or 1) / 4 / 5 / 6: the LEAN build for that many cloths per CU, whatever the batch size
             const int v = atoi(t);
             if (v == 0) h->lean = false;
-            else if (small_grid && precision == CLOTHHIP_F32) { h->lean = true; h->lean_r = (v == 8 || v == 2) ? 2 : (v == 4 ? 4 : 3); }
+            else if (small_grid && precision == CLOTHHIP_F32) { h->lean = true; h->lean_r = (v == 8 || v == 2) ? 2 : ((v >= 4 && v <= 6) ? v : 3); }
         }
         if (h->lean) {
             // the arithmetic stencil of the LEAN kernel against the gather table built from the reference's spring list
@@ -353,26 +359,38 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
         h->cell_copy = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, h->tab, 1).total <= budget ? 1 : 0;
         if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) h->cell_copy = h->cell_copy && atoi(t);
         h->lds_bytes = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, h->tab, h->cell_copy).total;
-        h->lay_std = {h->nt, h->ppt, h->tab, h->rest_reg, h->cell_copy, h->lds_bytes};
+        h->lay_std = {h->nt, h->ppt, h->tab, h->rest_reg, h->cell_copy, h->lds_bytes, h->HT, h->ht_bits};
         if (h->lean) {                                   // the lean layout: window table streamed from L2, 33 KB of LDS
             int cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, 1).total <= (160 * 1024) / std::max(h->lean_r, 3) ? 1 : 0;
             if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) cc = cc && atoi(t);
-            h->lay_lean = {256, 3, h->lean_r >= 4 ? 3 - h->lean_r : 0, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, cc).total};   // (r = 3, 4: four waves per cloth)
-            if (h->lean_r == 2) {                        // eight waves per cloth, two cloths per CU: the standard variant's LDS budget
+            h->lay_lean = {256, 3, h->lean_r >= 4 ? 3 - h->lean_r : 0, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, cc).total, h->HT, h->ht_bits};   // (r = 3, 4: four waves per cloth)
+            if (h->lean_r == 2 && small_grid) {          // eight waves per cloth, two cloths per CU: the standard variant's LDS budget
                 cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 1, 1).total <= 80 * 1024 ? 1 : 0;
                 if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) cc = cc && atoi(t);
-                h->lay_lean = {512, 2, 2, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 1, cc).total};
+                h->lay_lean = {512, 2, 2, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 1, cc).total, h->HT, h->ht_bits};
                 if (h->lay_lean.lds_bytes > 80 * 1024 || h->P > 1024) h->lean = false;      // (the table must fit beside a second cloth)
             }
             if (h->lean_r == 1) {                        // the whole CU: same LDS budget as the standard variant of these grids
                 cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, 1).total <= 160 * 1024 ? 1 : 0;
                 if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) cc = cc && atoi(t);
-                h->lay_lean = {1024, h->P <= 3072 ? 3 : 4, 3, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, cc).total};
+                h->lay_lean = {1024, h->P <= 3072 ? 3 : 4, 3, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, cc).total, h->HT, h->ht_bits};
+                // TWO large-grid cloths per CU (eight waves each, 128 VGPRs) when the batch has more cloths than the device has CUs and it
+                // pays by the measured rates: <= 80 KB of LDS per cloth -- no cell-ordered copy, and a hash table of just enough slots
+                // (not a power of two: > P, so that a free slot always exists, and large enough that the in-kernel metrics' scratch fits)
+                int NSb = 1; while (NSb < h->P) NSb <<= 1;
+                int ht2 = (h->P / 64 + 2) * 64;
+                while (LdsLayout(tsz, h->Ppad, h->Spad, ht2, 0, 0).total - LdsLayout(tsz, h->Ppad, h->Spad, ht2, 0, 0).hkey < metrics_scratch_bytes(NSb, h->Ppad + 8, tsz, true)) ht2 += 64;
+                const int lds2 = LdsLayout(tsz, h->Ppad, h->Spad, ht2, 0, 0).total;
+                const int gens1 = (h->E + h->n_cus - 1) / h->n_cus, gens2 = (h->E + 2 * h->n_cus - 1) / (2 * h->n_cus);
+                const bool two = h->P <= 2560 && lds2 <= 80 * 1024 && LEAN_RATE_LARGE_2_PER_CU / gens2 > 1.02 / gens1;
+                int want2 = two ? 1 : 0;
+                if (const char *t = getenv("CLOTHHIP_DEBUG_LARGE2")) want2 = atoi(t) && h->P <= 2560 && lds2 <= 80 * 1024;
+                if (want2) { h->lay_lean = {512, 5, 4, true, 0, lds2, ht2, 0}; h->lean_r = 2; }
             }
             // the in-kernel metrics borrow the region behind the episode state (clothhip_fused_supported): it must hold them here too
             int NS_ = 1; while (NS_ < h->P) NS_ <<= 1;
-            const LdsLayout ll(tsz, h->Ppad, h->Spad, h->HT, 0, cc);
-            if (ll.total - ll.hkey < 2 * NS_ * tsz + (2 * (h->Ppad + 8) + 64) * 8) h->lean = false;
+            const LdsLayout ll(tsz, h->Ppad, h->Spad, h->lay_lean.HT, 0, h->lay_lean.cell_copy);
+            if (ll.total - ll.hkey < metrics_scratch_bytes(NS_, h->Ppad + 8, tsz, v_hull_idx(h->lay_lean.tab))) h->lean = false;
         }
         if (h->lds_bytes > 160 * 1024) { free_handle(h); return fail(CLOTHHIP_EINVAL, "n_side %d needs %d B of LDS (> 160 KiB)", h->N, h->lds_bytes); }
         if (h->lean) {                                   // the lean kernels too (which layout runs is decided per launch)
@@ -688,6 +706,7 @@ static int lean_refresh(clothhip_handle *h) {
     }
     const clothhip_handle::Layout &L = (h->lean_ok && h->rest_stride == 0) ? h->lay_lean : h->lay_std;
     h->nt = L.nt; h->ppt = L.ppt; h->tab = L.tab; h->rest_reg = L.rest_reg; h->cell_copy = L.cell_copy; h->lds_bytes = L.lds_bytes;
+    h->HT = L.HT; h->ht_bits = L.ht_bits;
     return 0;
 }
 
@@ -702,9 +721,9 @@ static int lean_refresh(clothhip_handle *h) {
 #endif
 // the LEAN builds (fp32 only; 25x25 class: three / four cloths per CU, and eight waves per cloth at two per CU; the whole CU for the 512 x 5 grids)
 #ifdef CLOTHHIP_FAST_BUILD
-#define CLOTH_VARIANTS_LEAN(X, T) X(T, 256, 3, 0, true) X(T, 256, 3, -1, true) X(T, 512, 2, 2, true)
+#define CLOTH_VARIANTS_LEAN(X, T) X(T, 256, 3, 0, true) X(T, 256, 3, -1, true) X(T, 256, 3, -2, true) X(T, 256, 3, -3, true) X(T, 512, 2, 2, true)
 #else
-#define CLOTH_VARIANTS_LEAN(X, T) X(T, 256, 3, 0, true) X(T, 256, 3, -1, true) X(T, 512, 2, 2, true) X(T, 1024, 3, 3, true) X(T, 1024, 4, 3, true)
+#define CLOTH_VARIANTS_LEAN(X, T) X(T, 256, 3, 0, true) X(T, 256, 3, -1, true) X(T, 256, 3, -2, true) X(T, 256, 3, -3, true) X(T, 512, 2, 2, true) X(T, 1024, 3, 3, true) X(T, 1024, 4, 3, true) X(T, 512, 5, 4, true)
 #endif
 
 template <typename T, int FUSED> static const void *stepper_fn_t(const clothhip_handle *h) {
@@ -828,7 +847,7 @@ static int grow(void **p, size_t *cap, size_t need) {
 static int fused_scratch(const clothhip_handle *h, int *need_out) {
     int NS = 1; while (NS < h->P) NS <<= 1;
     const int NH = h->Ppad + 8;
-    *need_out = 2 * NS * (int)h->tsz + (2 * NH + 64) * 8;
+    *need_out = metrics_scratch_bytes(NS, NH, (int)h->tsz, v_hull_idx(h->tab));
     const LdsLayout lay((int)h->tsz, h->Ppad, h->Spad, h->HT, v_ldstab(h->tab) ? 1 : 0, h->cell_copy);
     return lay.total - lay.hkey;
 }
@@ -1046,7 +1065,7 @@ extern "C" double clothhip_hull_area(const double *xy, int32_t n) {
 static int launch_metrics(clothhip_handle *h) {
     int NS = 1; while (NS < h->P) NS <<= 1;
     const int NH = h->Ppad + 8;                 // the monotone chain holds at most m + 1 <= P + 1 points
-    const int lds = 2 * NS * (int)h->tsz + (2 * NH + 64) * 8;
+    const int lds = metrics_scratch_bytes(NS, NH, (int)h->tsz);
     const double half_thick = h->prm.thickness / 2.0;                                   // cloth_env.py:604
     if (h->precision == CLOTHHIP_F64) {
         HIPCHECK(hipFuncSetAttribute((const void *)k_metrics<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -31,7 +31,7 @@ def _run(tier, lean, monkeypatch, E=48, T=5):
     return res, var_fused, var_step
 
 
-@pytest.mark.parametrize("tier,build", [("tier1", 3), ("tier3", 3), ("tier1", 4), ("tier1", 8), ("tier3", 8)])
+@pytest.mark.parametrize("tier,build", [("tier1", 3), ("tier3", 3), ("tier1", 4), ("tier1", 5), ("tier1", 6), ("tier1", 8), ("tier3", 8)])
 def test_lean_variant_is_bit_identical_to_the_standard_f32_variant(tier, build, monkeypatch):
     a, va_f, va_s = _run(tier, 0, monkeypatch)
     b, vb_f, vb_s = _run(tier, build, monkeypatch)
@@ -41,7 +41,7 @@ def test_lean_variant_is_bit_identical_to_the_standard_f32_variant(tier, build, 
         if build == 8:                                               # eight waves per cloth, window table in LDS, two cloths per CU
             assert v["lean"] and v["threads"] == 512 and v["particles_per_thread"] == 2 and v["table_mode"] == 2 and v["cloths_per_cu"] >= 2, v
             continue
-        assert v["lean"] and v["threads"] == 256 and v["table_mode"] == (0 if build == 3 else -1), v
+        assert v["lean"] and v["threads"] == 256 and v["table_mode"] == 3 - build, v
         assert v["cloths_per_cu"] >= build, v                        # three / four cloths resident per CU (a build that needs fewer
                                                                      # registers than its cap may fit one more)
     assert va_f["cloths_per_cu"] == 2, va_f

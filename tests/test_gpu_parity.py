@@ -64,8 +64,9 @@ def test_f64_bit_exact_vs_reference_golden(name, oracle_lib):
 # (name, CLOTHHIP_DEBUG_LEAN): 0 = the standard fp32 variant; 3 / 4 = the LEAN variant's builds for three / four cloths per CU, 8 = its
 # eight-wave build (512 threads x 2 particles, window table in LDS: what a batch of <= 512 flat-tier cloths runs), 25x25 only, pinned to the
 # reference's checkpoints DIRECTLY (cloth.pyx:221-237 evaluation order), not only to the standard variant
-# 50x50 (one cloth per CU): -1 = whatever clothhip_create picks, which is the LEAN arithmetic on sixteen waves (1024 threads x 3 particles)
-F32_WINDOW_CASES = [(n, 0) for n in F32_WINDOWS] + [(n, l) for n in F32_WINDOWS if "_50" not in n for l in (3, 4, 8)] + [("g_traj_fold_50.npz", -1)]
+# 50x50: -1 = what clothhip_create picks for a small batch, the LEAN arithmetic on sixteen waves (1024 threads x 3 particles, one cloth
+# per CU); -2 = what it picks for a batch larger than the device's CU count: two cloths per CU, eight waves each
+F32_WINDOW_CASES = [(n, 0) for n in F32_WINDOWS] + [(n, l) for n in F32_WINDOWS if "_50" not in n for l in (3, 4, 6, 8)] + [("g_traj_fold_50.npz", -1), ("g_traj_fold_50.npz", -2)]
 
 
 @pytest.mark.parametrize("name,lean", F32_WINDOW_CASES)
@@ -79,6 +80,7 @@ def test_f32_teacher_forced_windows(name, lean, oracle_lib, monkeypatch):
         monkeypatch.setenv("CLOTHHIP_DEBUG_LEAN", str(lean))
     else:
         monkeypatch.delenv("CLOTHHIP_DEBUG_LEAN", raising=False)
+        monkeypatch.setenv("CLOTHHIP_DEBUG_LARGE2", "1" if lean == -2 else "0")     # -2: the two-cloths-per-CU build of the large grids
     g = oracle_lib.load_golden(name)
     b = ClothBatch(cfg_from_golden(g), n_envs=1, precision="f32")
     rp = BatchReplay(b)
@@ -99,12 +101,14 @@ def test_f32_teacher_forced_windows(name, lean, oracle_lib, monkeypatch):
         oracle_lib.replay_ops(rp, seg)
         var = b.last_variant()
         assert var["lean"] == (lean != 0) and var["precision"] == "f32", var
-        if lean in (3, 4):
-            assert var["table_mode"] == (0 if lean == 3 else -1) and var["threads"] == 256, var
+        if lean in (3, 4, 5, 6):
+            assert var["table_mode"] == 3 - lean and var["threads"] == 256, var
         if lean == 8:
             assert var["table_mode"] == 2 and var["threads"] == 512 and var["particles_per_thread"] == 2, var
-        if lean < 0:
+        if lean == -1:
             assert var["table_mode"] == 3 and var["threads"] == 1024 and var["particles_per_thread"] == 3 and var["cloths_per_cu"] == 1, var
+        if lean == -2:        # 512 threads x 5 particles, 79.7 KB of LDS (hash table of 2880 slots, no cell-ordered copy): two per CU
+            assert var["table_mode"] == 4 and var["threads"] == 512 and var["cloths_per_cu"] == 2 and var["lds_bytes"] <= 80 * 1024, var
         pos = b.positions()[0]
         err = max_abs(pos, g["cp_pos"][k + 1])
         tol = 5e-7 if nsub == 1 else (5e-6 if nsub <= 10 else (1e-4 if nsub <= 60 else 2e-3))
