@@ -104,6 +104,8 @@ struct EpState {
     uint64_t ticks[4];     //   ticks per class (0 action, 1 reset pull incl. its coverage test, 2 reset settling, 3 other),
     uint32_t subs[4];      //   update() calls per class
     double last_cov;       // coverage after the last action / reset of this launch (NaN: none yet)
+    uint64_t t_launch;     // 100 MHz clock when this cloth's workgroup started (the time slice counts from here); LDS, not a register pair:
+                           // held in registers it was spilled, and its reload sat on every substep's path
 };
 
 // An operation cut by the end of a time slice (clothhip_run_actions with a time budget): everything needed to continue it in
@@ -267,6 +269,24 @@ template <typename T> __device__ __forceinline__ uint32_t cell_key(const DevCons
 template <typename T> struct WEnt;
 template <> struct __attribute__((aligned(8))) WEnt<float> { uint32_t ab; float rest; };
 template <> struct __attribute__((aligned(16))) WEnt<double> { uint32_t ab; uint32_t _pad; double rest; };
+
+// The stepper's constants re-read from the kernel-argument block (constant address space: scalar loads) at the head of a phase of the
+// substep loop, through a pointer made opaque there: loaded once at the kernel's entry they would occupy SGPRs for the whole launch --
+// the hot loop has none to spare, they were spilled (to VGPR lanes, some on to scratch) and reloaded all over the loop.
+template <typename T> using KArgsC = const __attribute__((address_space(4))) StepArgs<T>;
+template <typename T> __device__ __forceinline__ DevConsts<T> load_consts(KArgsC<T> *p) {
+    DevConsts<T> k;
+    k.mg = p->k.mg; k.ks_str = p->k.ks_str; k.ks_bend = p->k.ks_bend; k.dsm = p->k.dsm; k.damp = p->k.damp;
+    k.cw = p->k.cw; k.ch = p->k.ch; k.ct = p->k.ct; k.thresh = p->k.thresh; k.sim_steps = p->k.sim_steps;
+    k.min_z = p->k.min_z; k.surf_off = p->k.surf_off; k.one_m_fric = p->k.one_m_fric; k.tear_thresh = p->k.tear_thresh; k.c11 = p->k.c11;
+    return k;
+}
+// (in a phase's scope: shadows the kernel's `k`, `P`, `Ppad`, `HT` by freshly loaded copies)
+#define CLOTH_PHASE_ARGS()                                                        \
+    asm volatile("" : "+s"(Ak_));                                                 \
+    const DevConsts<T> k = load_consts<T>(Ak_);                                   \
+    const int P = Ak_->P, Ppad = Ak_->Ppad, HT = Ak_->HT;                         \
+    (void)k; (void)P; (void)Ppad; (void)HT;
 
 constexpr int EPSTATE_LDS_BYTES = 240;
 static_assert(sizeof(EpState) <= EPSTATE_LDS_BYTES, "EpState outgrew its LDS slot (LdsLayout::eps): the window table / hash region follows it");
@@ -935,10 +955,11 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
         for (int h = tid; h < HT; h += NT) { hkey[h] = KEY_EMPTY; hco[h] = 0; }
         if (tid == 0) { misc[0] = tear_flag; misc[1] = 0; misc[2] = 0; misc[3] = 0; misc[4] = 0; misc[5] = 0; misc[6] = 0; misc[10] = 0x7fffffff; misc[11] = -1; misc[12] = 0; misc[13] = 0; misc[14] = 0; }
     };
+    if (tid == 0) misc[15] = 0;
     init_lds(A.tear[e], A.wt_ent, g_rest);
     __syncthreads();
 
-    int st_sweeps = 0, st_windows = 0, st_passes = 0, st_commits = 0;      // wave 0 only (uniform)
+    int st_windows = 0, st_passes = 0, st_commits = 0;      // wave 0 only (uniform); the number of sweeps run lives in misc[15]
     unsigned long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0, tstart = 0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tstart)::"memory");   // whole-schedule clock of this cloth (stats[15])
 #ifdef CLOTHHIP_PHASE_STAMPS                 // profiling build (make stamps): phase mask bit 32 turns the stamps on
@@ -1016,7 +1037,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
         __syncthreads();
         if (tid == 0 && Fp->resume != nullptr) Fp->resume[e].valid = 0;
     }
-    const uint64_t t_launch = FUSED ? __builtin_amdgcn_s_memrealtime() : 0;   // 100 MHz, constant rate (thread 0's copy is used)
+    if (FUSED) { if (tid == 0) eps->t_launch = __builtin_amdgcn_s_memrealtime(); }   // 100 MHz, constant rate (thread 0 is the only reader)
     int done_nf = 0;                   // executed substeps of the external schedule (not fused)
     for (;;) {
         bool do_run = true;
@@ -1407,7 +1428,12 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
         int done = resumed_run ? resume_done : 0;
         int it_next = -1;                  // >= 0: the time slice ended inside this run, which continues there in the next launch
         {
-        const T dz_up = (T)sc.dz_up, dxp = (T)sc.dx_pull, dyp = (T)sc.dy_pull, dzp = (T)sc.dz_pull;
+        // (wave-uniform by construction: kept in SGPRs -- as four VGPRs they were spilled and reloaded at the head of every substep)
+        auto uni = [](T v) -> T {
+            if constexpr (sizeof(T) == 4) return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)v)));
+            else return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint((double)v)), __builtin_amdgcn_readfirstlane(__double2loint((double)v)));
+        };
+        const T dz_up = uni((T)sc.dz_up), dxp = uni((T)sc.dx_pull), dyp = uni((T)sc.dy_pull), dzp = uni((T)sc.dz_pull);
         const bool sliced = FUSED && Fp->budget_ticks != 0 && Fp->resume != nullptr;
     const int tid_outer_ = tid;
 #ifdef CLOTHHIP_CELL_COUNTERS
@@ -1419,6 +1445,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
         int tid = tid_outer_;
         if (LEAN || sizeof(T) == 8 || NT >= 512) asm volatile("" : "+v"(tid));     // (fp64: 65 -> 0 spilled registers; 50x50: +3 %)
         const int lane = tid & 63;
+        KArgsC<T> *Ak_ = (KArgsC<T> *)__builtin_amdgcn_kernarg_segment_ptr();
 
         // ---- ClothEnv._pull (cloth_env.py:352-367): adjust / nothing / release -------------------
         int mode = 0; T ax = 0, ay = 0, az = 0;
@@ -1460,6 +1487,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
         TSTAMP(0)
         // ---- gravity + Hooke gather + Verlet (cloth.pyx:216-256) ----------------------------------
         if (pm & PH_HOOKE) {
+            CLOTH_PHASE_ARGS()
             // Per particle: f = (0,0,m*g) + sum over its incident springs in ascending list index of fm * (nbr - self).
             // (For the spring's ptB the reference adds -(fm * (self - nbr)), which is the same IEEE value.)
             // Branch-free: absent slots (grid border) and pinned particles are computed and discarded.
@@ -1479,7 +1507,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
                     if (LEAN) asm volatile("" : "+v"(iq_), "+v"(vq_));     // opaque: the stencil is recomputed every substep, not hoisted and held
 #pragma unroll
                     for (int sl = 0; sl < HK_SLOTS; sl++)
-                        gl[sl] = LEAN ? lean_entry(iq_, vq_, sl) : (GT_REG ? gt[GT_REG ? q : 0][sl] : A.gather[sl * Ppad + tid + q * NT]);
+                        gl[sl] = LEAN ? lean_entry(iq_, vq_, sl) : (GT_REG ? gt[GT_REG ? q : 0][sl] : Ak_->gather[sl * Ppad + tid + q * NT]);
                     // software pipeline: the neighbour records of the next springs are in flight while spring sl is
                     // evaluated (left to itself the scheduler, which minimises live registers at this kernel's pressure, issues
                     // each 16-byte read right before its use and waits out the whole LDS latency 12 times per particle)
@@ -1530,6 +1558,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
         // ---- spatial map (cloth.pyx:298-311): hash table in LDS keyed by the exact cell key + a list of the occupied
         // slots; members of a cell are stored contiguously (CSR); ascending point index is restored by the sweep.
         if (pm & PH_COLLIDE) {
+            CLOTH_PHASE_ARGS()
             uint32_t ch[PPT], rank[PPT];
             {
                 uint32_t ckey[PPT];
@@ -1542,7 +1571,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
                     ckey[q] = cell_key<T>(k, c.x, c.y, c.z);
                     // (ht_bits 0: a table whose size is not a power of two -- the two-per-CU layout of the large grids -- is indexed by the
                     //  high half of hash x size; which slot a cell gets never shows in the results)
-                    ch[q] = A.ht_bits ? (ckey[q] * 2654435761u) >> (32 - A.ht_bits) : __umulhi(ckey[q] * 2654435761u, (uint32_t)HT);
+                    ch[q] = Ak_->ht_bits ? (ckey[q] * 2654435761u) >> (32 - Ak_->ht_bits) : __umulhi(ckey[q] * 2654435761u, (uint32_t)HT);
                     pend[q] = i < P; made[q] = false; anyp |= pend[q];
                 }
                 // linear probing; the table has >= 1.5 P slots, so a free one always exists -- the probe bound only
@@ -1604,7 +1633,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
                 cstart[q] = (int)(co >> 16);
                 if (i < P) {
                     memb[cstart[q] + (int)rank[q]] = (uint16_t)i;
-                    if (A.cell_copy) cpos[cstart[q] + (int)rank[q]] = Pt<T>{cme[q].x, cme[q].y, cme[q].z, w_make<T>((uint32_t)i)};
+                    if (Ak_->cell_copy) cpos[cstart[q] + (int)rank[q]] = Pt<T>{cme[q].x, cme[q].y, cme[q].z, w_make<T>((uint32_t)i)};
                 }
                 const bool use = i < P && w_cnt(cme[q].w) == 0;
                 cn[q] = use ? (int)(co & 0xFFFFu) : 0;
@@ -1638,7 +1667,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
                             const Pt<T> me_ = cur[iq_ < P ? iq_ : 0];
                             const int cs_ = cstart[q], cn_ = cn[q];
                             bool h_ = false;
-                            if (A.cell_copy) {
+                            if (Ak_->cell_copy) {
                                 // a read past the cell's range (another cell's record or the padding behind the array) is masked out
                                 // by the member count; the trip base is clamped so that no read leaves the padded array
 #pragma unroll 1
@@ -1665,7 +1694,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
                         }
                     }
                 } else {
-                    if (A.cell_copy) {
+                    if (Ak_->cell_copy) {
                         constexpr int CU = 2;
                         // a read past the cell's range (another cell's record or the padding behind the array) is masked out
                         // by the member count; the trip base is clamped so that no read leaves the padded array
@@ -1808,6 +1837,8 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
 
         // ---- plane (cloth.pyx:345-370), by the owner (it holds the previous position) --------------------
         if (pm & PH_PLANE) {
+            CLOTH_PHASE_ARGS()
+            const T k_min_z = k.min_z, k_surf_off = k.surf_off, k_one_m_fric = k.one_m_fric;
             Pt<T> mq[PPT];
 #pragma unroll
             for (int q = 0; q < PPT; q++) mq[q] = cur[tid + q * NT < P ? tid + q * NT : 0];     // batched: one LDS latency, not PPT
@@ -1817,21 +1848,20 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
                 if (i >= P) continue;
                 const Pt<T> me = mq[q];
 #ifdef CLOTHHIP_CELL_COUNTERS
-                if (!w_cnt(me.w) && me.z >= k.min_z) atomicOr(&misc[12], 1);     // census: an unpinned particle the plane did not restore
+                if (!w_cnt(me.w) && me.z >= k_min_z) atomicOr(&misc[12], 1);     // census: an unpinned particle the plane did not restore
 #endif
-                if (w_cnt(me.w) || me.z >= k.min_z) continue;
+                if (w_cnt(me.w) || me.z >= k_min_z) continue;
                 const T px = pvx[q], py = pvy[q], pz = pvz[q];
-                const T t = (k.min_z - pz) * (T)1.0;
+                const T t = (k_min_z - pz) * (T)1.0;
                 const T tgx = px + t * (T)(-0.0), tgy = py + t * (T)(-0.0), tgz = pz + t * (T)(-1.0);
-                const T gx = tgx + k.surf_off * (T)0.0, gy = tgy + k.surf_off * (T)0.0, gz = tgz + k.surf_off * (T)1.0;
+                const T gx = tgx + k_surf_off * (T)0.0, gy = tgy + k_surf_off * (T)0.0, gz = tgz + k_surf_off * (T)1.0;
                 const T cx = gx - px, cy = gy - py, cz = gz - pz;
-                cur[i] = Pt<T>{mad<T>(cx, k.one_m_fric, px), mad<T>(cy, k.one_m_fric, py), mad<T>(cz, k.one_m_fric, pz), me.w};
+                cur[i] = Pt<T>{mad<T>(cx, k_one_m_fric, px), mad<T>(cy, k_one_m_fric, py), mad<T>(cz, k_one_m_fric, pz), me.w};
             }
         }
         if (FUSED && sliced) {             // thread 0 looks at the clock here, between two barriers that every thread passes in
                                            // every substep; everyone reads its verdict at the end of the substep
-            const bool over = __builtin_amdgcn_s_memrealtime() - t_launch >= Fp->budget_ticks;
-            if (tid == 0) misc[7] = over ? 1 : 0;
+            if (tid == 0) misc[7] = (__builtin_amdgcn_s_memrealtime() - eps->t_launch >= Fp->budget_ticks) ? 1 : 0;
         }
         __syncthreads();
 
@@ -1843,6 +1873,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
         //     reaches it. No spring flagged: the sweep is skipped (a cloth at rest).
         // (2) wave 0 walks the windows in between (strain_sweep above).
         if (pm & PH_STRAIN) {
+            CLOTH_PHASE_ARGS()
             {
                 // Every spring is tested once, by the owner of its ptB (the particle the reference appended it for):
                 // the owner holds the spring's gather entry (neighbour = ptA, table slot) and, with
@@ -1858,7 +1889,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
                         if (LEAN) asm volatile("" : "+v"(iq_), "+v"(vq_));
 #pragma unroll
                         for (int sl = 0; sl < HK_SLOTS / 2; sl++)
-                            gl[sl] = LEAN ? lean_entry(iq_, vq_, sl) : (GT_REG ? gt[GT_REG ? q : 0][sl] : A.gather[sl * Ppad + tid + q * NT]);
+                            gl[sl] = LEAN ? lean_entry(iq_, vq_, sl) : (GT_REG ? gt[GT_REG ? q : 0][sl] : Ak_->gather[sl * Ppad + tid + q * NT]);
                         // software pipeline, as in the Hooke phase: two neighbour reads in flight ahead of the test
                         constexpr int PP_AHEAD = 2;
                         Pt<T> nbq[PP_AHEAD];
@@ -1905,7 +1936,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
                                 if (cand & (1u << sl)) {
                                     // (LEAN: the spring's table slot is read from the gather table only now that it is needed: the table
                                     //  is compacted, the sl-th stencil position is the particle's popcount(valid below sl)-th entry)
-                                    const uint32_t pos_ = ((LEAN ? A.gather[__popc(vq_ & ((1u << sl) - 1u)) * Ppad + iq_] : gl[sl])      // (the opaque copies: nothing of this is hoisted out of the substep loop and held)
+                                    const uint32_t pos_ = ((LEAN ? Ak_->gather[__popc(vq_ & ((1u << sl) - 1u)) * Ppad + iq_] : gl[sl])      // (the opaque copies: nothing of this is hoisted out of the substep loop and held)
                                                            >> HK_POS_SHIFT) & HK_POS_MASK;
                                     T r = LEAN ? lean_rest(sl) : (REST_R ? rr[REST_R ? q : 0][sl] : rest_at(pos_));
                                     asm volatile("" : "+v"(r));
@@ -1938,8 +1969,8 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
                 __builtin_amdgcn_s_setprio(3);            // the serial sweep is the critical path of the whole cloth
                 const bool all_ = (pm & PH_NOSKIP) != 0;
                 const int w0 = __builtin_amdgcn_readfirstlane(all_ ? 0 : (misc[10] >> 6));
-                const int w1 = __builtin_amdgcn_readfirstlane(all_ ? A.nW - 1 : (misc[11] >> 6));
-                st_sweeps++;
+                const int w1 = __builtin_amdgcn_readfirstlane(all_ ? Ak_->nW - 1 : (misc[11] >> 6));
+                if (lane == 0) misc[15]++;               // sweeps run (clothhip_debug_stats): in LDS -- as a register it was spilled, reloaded and stored by every sweep
                 // tear_thresh >= 1.1 (every shipped configuration): only a stretching spring can tear, the test sits in the commit
                 const bool tic = __builtin_amdgcn_readfirstlane(!(k.tear_thresh < k.c11) ? 1 : 0) != 0;
 #ifdef CLOTHHIP_CELL_COUNTERS
@@ -1948,9 +1979,9 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
 #else
                 const unsigned long long fmask_ = 0ull;
 #endif
-                const int tear = tic ? strain_sweep<T, v_ldstab(TAB), SWEEP_TIMED, SWEEP_STATS, true>(cur, wtab, A.wt_ent, g_rest, A.wt_dep, w0, w1, A.nW, A.wt_rshift, k,
+                const int tear = tic ? strain_sweep<T, v_ldstab(TAB), SWEEP_TIMED, SWEEP_STATS, true>(cur, wtab, Ak_->wt_ent, g_rest, Ak_->wt_dep, w0, w1, Ak_->nW, Ak_->wt_rshift, k,
                                                                                                  lane, st_windows, st_passes, st_commits, tph, fmask_)
-                                     : strain_sweep<T, v_ldstab(TAB), SWEEP_TIMED, SWEEP_STATS, false>(cur, wtab, A.wt_ent, g_rest, A.wt_dep, w0, w1, A.nW, A.wt_rshift, k,
+                                     : strain_sweep<T, v_ldstab(TAB), SWEEP_TIMED, SWEEP_STATS, false>(cur, wtab, Ak_->wt_ent, g_rest, Ak_->wt_dep, w0, w1, Ak_->nW, Ak_->wt_rshift, k,
                                                                                                   lane, st_windows, st_passes, st_commits, tph, fmask_);
                 if (__any(tear) && lane == 0) misc[0] = 1;
                 if (lane == 0) { misc[1] = 0; misc[10] = 0x7fffffff; misc[11] = -1; }
@@ -2023,7 +2054,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
                 for (int i = tid; i < P; i += NT) { const Pt<T> c = cur[i]; o_[3 * i] = (float)c.x; o_[3 * i + 1] = (float)c.y; o_[3 * i + 2] = (float)c.z; }
             }
             if (tid == 0) {
-                if (F.budget_ticks != 0 && __builtin_amdgcn_s_memrealtime() - t_launch >= F.budget_ticks) eps->stop = 1;
+                if (F.budget_ticks != 0 && __builtin_amdgcn_s_memrealtime() - eps->t_launch >= F.budget_ticks) eps->stop = 1;
                 eps->done_total += done - (resumed_run ? resume_done : 0);
                 account(op, done - (resumed_run ? resume_done : 0));
                 if (op == OP_ACTION) {
@@ -2105,7 +2136,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
         if (tid == 0) {
             A.tear[e] = misc[0]; A.executed[e] = done;
             if (A.stats) {
-                A.stats[16 * e] = st_sweeps; A.stats[16 * e + 1] = st_windows; A.stats[16 * e + 2] = st_passes; A.stats[16 * e + 3] = st_commits;
+                A.stats[16 * e] = misc[15]; A.stats[16 * e + 1] = st_windows; A.stats[16 * e + 2] = st_passes; A.stats[16 * e + 3] = st_commits;
                 for (int q = 0; q < 12; q++) A.stats[16 * e + 4 + q] = (int)(tph[q] >> 6);
 #ifndef CLOTHHIP_PHASE_STAMPS
                 unsigned long long tend;
