@@ -294,13 +294,16 @@ static_assert(WT_IDX_BITS == 12 && HK_NBR_MASK == WT_IDX_MASK, "point indices ar
 // LDS carve-up (dynamic shared memory), all offsets in bytes, 16-byte aligned.
 // tab: 0 = the window table stays in global memory (L2), 1 = table + rest lengths resident in LDS
 struct LdsLayout {
-    int cur, eps, wtab, hkey, hco, memb, slot, misc, alist, olist, cpos, total;
+    int cur, eps, wtab, pslot, hkey, hco, memb, slot, misc, alist, olist, cpos, total;
+    // tab 2 (the eight-wave LEAN build): like 1, plus the table slots of every particle's six own springs (u16 [6][Ppad]): the strain
+    // pre-pass of the LEAN arithmetic needs the slot of a flagged spring, and read it from the L2-resident gather table otherwise
     __host__ __device__ LdsLayout(int tsz, int Ppad, int Spad, int HT, int tab, int cp) {
         int o = 0;
         auto take = [&](int bytes) { int r = o; o += (bytes + 15) / 16 * 16; return r; };
         cur = take(4 * Ppad * tsz);
         eps = take(EPSTATE_LDS_BYTES);   // EpState (fused episodes)
         wtab = take(tab >= 1 ? Spad * (tsz == 8 ? 16 : 8) : 0);   // WEnt<T>[Spad]
+        pslot = take(tab == 2 ? (HK_SLOTS / 2) * Ppad * 2 : 0);
         hkey = take(HT * 4);         // everything from here on doubles as scratch of the in-kernel metrics and is rebuilt afterwards
         hco = take(HT * 4);          // (fill cursor << 16) | member count
         memb = take(Ppad * 2);
@@ -889,7 +892,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
         sc.dz_up = sc.dx_pull = sc.dy_pull = sc.dz_pull = 0.0;
     }
     const int P = A.P, Ppad = A.Ppad, HT = A.HT;
-    const LdsLayout lay((int)sizeof(T), Ppad, A.Spad, HT, v_ldstab(TAB) ? 1 : 0, A.cell_copy);
+    const LdsLayout lay((int)sizeof(T), Ppad, A.Spad, HT, TAB == 2 ? 2 : (v_ldstab(TAB) ? 1 : 0), A.cell_copy);
     Pt<T> *cur = reinterpret_cast<Pt<T> *>(smem + lay.cur);
     uint32_t *hkey = reinterpret_cast<uint32_t *>(smem + lay.hkey);
     uint32_t *hco = reinterpret_cast<uint32_t *>(smem + lay.hco);
@@ -957,6 +960,16 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
     };
     if (tid == 0) misc[15] = 0;
     init_lds(A.tear[e], A.wt_ent, g_rest);
+    uint16_t *pslot = reinterpret_cast<uint16_t *>(smem + lay.pslot);       // TAB 2 only
+    if (TAB == 2) {
+        for (int i = tid; i < Ppad; i += NT) {
+            const int r_ = i / A.N;
+            const uint32_t vmi = i < P ? lean_valid_mask(r_, i - r_ * A.N, A.N) : 0u;
+#pragma unroll
+            for (int sl = 0; sl < HK_SLOTS / 2; sl++)      // the sl-th stencil position = the popcount(valid below sl)-th entry of the compacted table
+                pslot[sl * Ppad + i] = ((vmi >> sl) & 1u) ? (uint16_t)((A.gather[__popc(vmi & ((1u << sl) - 1u)) * Ppad + i] >> HK_POS_SHIFT) & HK_POS_MASK) : (uint16_t)0;
+        }
+    }
     __syncthreads();
 
     int st_windows = 0, st_passes = 0, st_commits = 0;      // wave 0 only (uniform); the number of sweeps run lives in misc[15]
@@ -1936,7 +1949,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
                                 if (cand & (1u << sl)) {
                                     // (LEAN: the spring's table slot is read from the gather table only now that it is needed: the table
                                     //  is compacted, the sl-th stencil position is the particle's popcount(valid below sl)-th entry)
-                                    const uint32_t pos_ = ((LEAN ? Ak_->gather[__popc(vq_ & ((1u << sl) - 1u)) * Ppad + iq_] : gl[sl])      // (the opaque copies: nothing of this is hoisted out of the substep loop and held)
+                                    const uint32_t pos_ = TAB == 2 ? (uint32_t)pslot[sl * Ppad + iq_] : ((LEAN ? Ak_->gather[__popc(vq_ & ((1u << sl) - 1u)) * Ppad + iq_] : gl[sl])      // (the opaque copies: nothing of this is hoisted out of the substep loop and held)
                                                            >> HK_POS_SHIFT) & HK_POS_MASK;
                                     T r = LEAN ? lean_rest(sl) : (REST_R ? rr[REST_R ? q : 0][sl] : rest_at(pos_));
                                     asm volatile("" : "+v"(r));

@@ -365,9 +365,9 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
             if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) cc = cc && atoi(t);
             h->lay_lean = {256, 3, h->lean_r >= 4 ? 3 - h->lean_r : 0, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, cc).total, h->HT, h->ht_bits};   // (r = 3, 4: four waves per cloth)
             if (h->lean_r == 2 && small_grid) {          // eight waves per cloth, two cloths per CU: the standard variant's LDS budget
-                cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 1, 1).total <= 80 * 1024 ? 1 : 0;
+                cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 2, 1).total <= 80 * 1024 ? 1 : 0;
                 if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) cc = cc && atoi(t);
-                h->lay_lean = {512, 2, 2, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 1, cc).total, h->HT, h->ht_bits};
+                h->lay_lean = {512, 2, 2, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 2, cc).total, h->HT, h->ht_bits};
                 if (h->lay_lean.lds_bytes > 80 * 1024 || h->P > 1024) h->lean = false;      // (the table must fit beside a second cloth)
             }
             if (h->lean_r == 1) {                        // the whole CU: same LDS budget as the standard variant of these grids
@@ -848,7 +848,7 @@ static int fused_scratch(const clothhip_handle *h, int *need_out) {
     int NS = 1; while (NS < h->P) NS <<= 1;
     const int NH = h->Ppad + 8;
     *need_out = metrics_scratch_bytes(NS, NH, (int)h->tsz, v_hull_idx(h->tab));
-    const LdsLayout lay((int)h->tsz, h->Ppad, h->Spad, h->HT, v_ldstab(h->tab) ? 1 : 0, h->cell_copy);
+    const LdsLayout lay((int)h->tsz, h->Ppad, h->Spad, h->HT, h->tab == 2 ? 2 : (v_ldstab(h->tab) ? 1 : 0), h->cell_copy);
     return lay.total - lay.hkey;
 }
 
