@@ -1,15 +1,19 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence that profiles/ summarises (run on the GPU box from the repo root, e.g. through
 # gpurun). One rocprofv3 run per counter group: --pmc is never combined with tracing. Outputs under gpurun_out/.
-#   bash tools/collect_profiles.sh r03          then, anywhere:  python tools/summarize_profiles.py gpurun_out/prof_r03 profiles/r03
+#   bash tools/collect_profiles.sh r04          then, anywhere:  python tools/summarize_profiles.py gpurun_out/prof_r04 profiles/r04
 set -u
 OUT=gpurun_out/prof_${1:-final}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-T="timeout 900"
+T="timeout -k 10 900"                      # (-k: a python child that ignores the signal is killed, not left holding the GPU)
 HEAD="--no-extra --no-cpu-baseline"        # the headline configuration only (512 cloths, fp32, fused time slices)
-# STAGES="trace traffic writerep sq phases action n50 ablation" selects stages (default: all)
+# STAGES="bench trace traffic writerep l2 sq phases census action n50 ablation" selects stages (default: all)
 want() { [[ -z "${STAGES:-}" || " $STAGES " == *" $1 "* ]]; }
+if want bench; then
+# 0. the full default bench line (what the driver runs), untraced
+$T python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.log"
+fi
 if want trace; then
 # 1. kernel trace + stats of the headline bench command
 $T rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o run -- python3 bench.py $HEAD > "$OUT/bench_traced.json" 2> "$OUT/trace.log"
@@ -35,8 +39,12 @@ fi
 if want traffic; then
 for C in FETCH_SIZE WRITE_SIZE; do
   $T rocprofv3 --pmc $C -d "$OUT/t2pmc_$C" -o run -- python3 bench.py $HEAD --init tier2 --steps 10 > "$OUT/t2pmc_$C.out" 2> "$OUT/t2pmc_$C.log"
-  $T rocprofv3 --pmc $C -d "$OUT/n50pmc_$C" -o run -- python3 bench.py $HEAD --n-side 50 --envs 1024 --steps 5 --warmup 0 --fuse 5 --step-ms 2400 > "$OUT/n50pmc_$C.out" 2> "$OUT/n50pmc_$C.log"
+  $T rocprofv3 --pmc $C -d "$OUT/n50pmc_$C" -o run -- python3 bench.py $HEAD --n-side 50 --envs 1024 --steps 5 --warmup 0 --fuse 5 --step-ms 250 > "$OUT/n50pmc_$C.out" 2> "$OUT/n50pmc_$C.log"
 done
+fi
+if want l2; then
+# 2b. L2 hits / misses beside the fetch counter over the headline command (the counter bursts of rounds 2 and 3: profiles/README.md)
+$T rocprofv3 --pmc FETCH_SIZE TCC_HIT_sum TCC_MISS_sum -d "$OUT/pmcl2_FETCH_SIZE_TCC" -o run -- python3 bench.py $HEAD > "$OUT/pmcl2.out" 2> "$OUT/pmcl2.log"
 fi
 if want sq; then
 # 3. instruction mix / wait counters over the headline command
@@ -53,6 +61,12 @@ if [ -f gym_cloth_amd/libclothhip_stamps.so ]; then
   CLOTHHIP_LIB=$PWD/gym_cloth_amd/libclothhip_stamps.so CLOTHHIP_DEBUG_PHASES=47 PREC=f64 SLICE_MS=1500 LAUNCHES=2 $T python3 tools/fused_profile.py > "$OUT/fused_phases_f64.txt" 2>&1
 fi
 fi
+if want census; then
+# 4b. census of the bench workload (counter build): active collision cells, frozen substeps, skippable windows, hits per visit
+if [ -f gym_cloth_amd/libclothhip_cnt.so ]; then
+  CLOTHHIP_LIB=$PWD/gym_cloth_amd/libclothhip_cnt.so $T python3 tools/cell_counters.py > "$OUT/census.txt" 2>&1
+fi
+fi
 if want action; then
 # 5. one real pick-and-place (the reference's oracle action) phase by phase, fp32 and fp64; the sweep's passes (sweep-stamps build)
 $T python3 tools/phase_profile.py > "$OUT/phase_f32.txt" 2>&1
@@ -63,7 +77,7 @@ fi
 fi
 if want n50; then
 # 6. rocprofv3 trace of the 50x50 companion (configs[4]) alone
-$T rocprofv3 --kernel-trace --stats -d "$OUT/trace50" -o run -- python3 bench.py $HEAD --n-side 50 --envs 1024 --steps 5 --warmup 0 --fuse 5 --step-ms 2400 > "$OUT/bench50_traced.json" 2> "$OUT/trace50.log"
+$T rocprofv3 --kernel-trace --stats -d "$OUT/trace50" -o run -- python3 bench.py $HEAD --n-side 50 --envs 1024 --steps 5 --warmup 0 --fuse 5 --step-ms 250 > "$OUT/bench50_traced.json" 2> "$OUT/trace50.log"
 fi
 if want ablation; then
 # 7. phase ablation on harvested reference states (settled / rest / pull / lift): all phases, without the strain limit, without

@@ -32,6 +32,16 @@ def main():
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
         for r in rows:
             w.writerow([r[0], r[1], int(r[2]), "%.1f" % r[3], "%.4f" % (100.0 * r[2] / tot), int(r[4]), int(r[5])])
+        # the stepper's dispatches of a bench run are: one short calibration launch, the warm-up launch(es), the TIMED launches (the
+        # last `roofline.launches` of them): a row for the timed ones alone, which is what bench.py's kernel_ms_avg averages
+        try:
+            tb_ = json.loads([l for l in open(os.path.join(src, "bench_traced.json")).read().splitlines() if l.startswith("{")][-1])
+            nl_ = int(tb_["roofline"]["launches"])
+            dd_ = [r[0] for r in c.execute("select duration from kernels where name like '%k_run_schedule%' order by start").fetchall()][-nl_:]
+            w.writerow(["k_run_schedule: the %d TIMED dispatches only (bench.py roofline.kernel_ms_avg = %.3f ms)" % (nl_, tb_["roofline"]["kernel_ms_avg"]),
+                        len(dd_), int(sum(dd_)), "%.1f" % (sum(dd_) / len(dd_)), "", int(min(dd_)), int(max(dd_))])
+        except (OSError, ValueError, KeyError, IndexError):
+            pass
     disp = c.execute("select name, duration, grid_x, workgroup_x, lds_size, vgpr_count, scratch_size from kernels "
                      "where name like '%k_run_schedule%' order by start").fetchall()
     out = {"command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-extra --no-cpu-baseline",
@@ -119,13 +129,21 @@ def main():
                         "fetch_size_bytes_per_launch_raw": fetch, "fetch_size_kb_of_the_timed_launches": f_all, "fetch_outliers_kb": f_out,
                         "write_size_bytes_per_launch": write, "write_size_kb_of_the_timed_launches": w_all, "write_outliers_kb": w_out,
                         "estimator": "lower median over the timed launches of all passes of the counter", "hbm_bytes_per_launch": 2.0 * fetch + write, "command": command,
+                        "substeps_per_launch": tb["roofline"]["substeps_per_launch"],
+                        "hbm_bytes_per_substep": (2.0 * fetch + write) / tb["roofline"]["substeps_per_launch"],
+                        "variant": cfg.get("variant"),
                         "algorithmic_bytes_per_launch": tb["roofline"]["substeps_per_launch"] * tb["roofline"]["alg_bytes_per_substep"]})
     traffic_record("pmc_", "pmc_FETCH_SIZE.out", "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) -- python3 bench.py --no-extra --no-cpu-baseline")
     traffic_record("t2pmc_", "t2pmc_FETCH_SIZE.out", "... -- python3 bench.py --no-extra --no-cpu-baseline --init tier2 --steps 10")
-    traffic_record("n50pmc_", "n50pmc_FETCH_SIZE.out", "... -- python3 bench.py --no-extra --no-cpu-baseline --n-side 50 --envs 1024 --steps 5 --warmup 0 --fuse 5 --step-ms 2400")
+    traffic_record("n50pmc_", "n50pmc_FETCH_SIZE.out", "... -- python3 bench.py --no-extra --no-cpu-baseline --n-side 50 --envs 1024 --steps 5 --warmup 0 --fuse 5 --step-ms 250")
     if records:
         json.dump({"records": records}, open(os.path.join(os.path.dirname(dst) or ".", os.path.basename(dst).split("_")[0] + "_traffic.json"), "w"), indent=1)
-    for nm, to in (("phase_f32.txt", "_phase_profile_f32.txt"), ("phase_f64.txt", "_phase_profile_f64.txt"),
+    # L2 hit / miss pass
+    l2 = per_dispatch(os.path.join(src, "pmcl2_FETCH_SIZE_TCC"))
+    if l2:
+        pmc["per_dispatch"]["same_pass_FETCH_SIZE_KB_TCC_HIT_TCC_MISS"] = {k_: [round(x, 1) for x in v_] for k_, v_ in l2.items()}
+        json.dump(pmc, open(dst + "_pmc_summary.json", "w"), indent=1)
+    for nm, to in (("census.txt", "_census.txt"), ("phase_f32.txt", "_phase_profile_f32.txt"), ("phase_f64.txt", "_phase_profile_f64.txt"),
                    ("fused_balance.txt", "_fused_balance.txt"), ("fused_phases.txt", "_fused_phases.txt"),
                    ("fused_phases_f64.txt", "_fused_phases_f64.txt"), ("sweepstamps_f32.txt", "_sweepstamps_f32.txt"),
                    ("ablation.txt", "_phase_ablation.txt")):
