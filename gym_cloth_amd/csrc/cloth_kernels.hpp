@@ -308,7 +308,7 @@ struct LdsLayout {
         hco = take(HT * 4);          // (fill cursor << 16) | member count
         memb = take(Ppad * 2);
         slot = take(Ppad * 2);
-        misc = take(128);            // flags and scan scratch
+        misc = take(256);            // flags and scan scratch (32 ints); behind them the profiling builds' twelve 64-bit accumulators
         olist = take(2 * Ppad);       // u16 hash slots: occupied cells from the front, cells with a seed from the back
         alist = olist;                //   (an active cell has >= 2 members, so #occupied + #active <= P)
         cpos = take(cp ? 4 * (Ppad + 32) * tsz : 0);   // particle records in cell (CSR) order for the pre-check; the
@@ -316,6 +316,24 @@ struct LdsLayout {
         total = o;
     }
 };
+
+// Accumulators of the profiling / census builds (per-phase cycles, counters): in LDS, written by thread 0 alone -- as twelve 64-bit
+// registers per wave they cost the VGPR-capped variants two dozen SGPRs and turned the profile into one of the spills they caused.
+struct TphRef {
+    unsigned long long *a; bool w;
+    __device__ __forceinline__ void operator+=(unsigned long long v) const { if (w) *a += v; }
+    __device__ __forceinline__ operator unsigned long long() const { return *a; }
+};
+struct TphLds {
+    unsigned long long *base; bool w;
+    __device__ __forceinline__ TphRef operator[](int i) const { return TphRef{base + i, w}; }
+};
+#if defined(CLOTHHIP_PHASE_STAMPS) || defined(CLOTHHIP_CELL_COUNTERS) || defined(CLOTHHIP_SWEEP_STAMPS)
+#define CLOTHHIP_TPH_LDS 1
+typedef TphLds TphT;
+#else
+typedef unsigned long long *TphT;
+#endif
 
 // Strain limit + tear (cloth.pyx:258-296) by ONE wave, exactly in the reference's order.
 //
@@ -337,7 +355,7 @@ template <typename T, bool LDS_TAB, bool TIMED, bool STATS, bool TIC>
 __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const uint32_t *g_ent, const T *g_rest,
                                             const unsigned long long *g_dep, int w0, int w_end,
                                             int nW, int rshift, const DevConsts<T> &k, int lane, int &st_windows, int &st_passes, int &st_commits,
-                                            unsigned long long *tph, unsigned long long fmask = 0ull) {
+                                            TphT tph, unsigned long long fmask = 0ull) {
     constexpr int PF = LDS_TAB ? 1 : 3;          // entry stream: windows read ahead
     constexpr int PD = sizeof(T) == 4 ? 3 : 2;   // dependency words (always from L2 / L1: one table for all cloths)
     static_assert(PF + 1 <= WT_PAD_WINDOWS && PD + 1 <= WT_PAD_WINDOWS, "the table is padded by the read-ahead distance");
@@ -973,7 +991,13 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
     __syncthreads();
 
     int st_windows = 0, st_passes = 0, st_commits = 0;      // wave 0 only (uniform); the number of sweeps run lives in misc[15]
+#ifdef CLOTHHIP_TPH_LDS
+    const TphLds tph{reinterpret_cast<unsigned long long *>(smem + lay.misc + 128), tid == 0};
+    if (tid < 12) tph.base[tid] = 0ull;
+    unsigned long long tlast = 0, tstart = 0;
+#else
     unsigned long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0, tstart = 0;
+#endif
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tstart)::"memory");   // whole-schedule clock of this cloth (stats[15])
 #ifdef CLOTHHIP_PHASE_STAMPS                 // profiling build (make stamps): phase mask bit 32 turns the stamps on
     const bool timing = (pm & PH_TIME) != 0;
@@ -2150,7 +2174,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
             A.tear[e] = misc[0]; A.executed[e] = done;
             if (A.stats) {
                 A.stats[16 * e] = misc[15]; A.stats[16 * e + 1] = st_windows; A.stats[16 * e + 2] = st_passes; A.stats[16 * e + 3] = st_commits;
-                for (int q = 0; q < 12; q++) A.stats[16 * e + 4 + q] = (int)(tph[q] >> 6);
+                for (int q = 0; q < 12; q++) A.stats[16 * e + 4 + q] = (int)((unsigned long long)tph[q] >> 6);
 #ifndef CLOTHHIP_PHASE_STAMPS
                 unsigned long long tend;
                 asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tend)::"memory");
