@@ -293,7 +293,12 @@ static_assert(sizeof(EpState) <= EPSTATE_LDS_BYTES, "EpState outgrew its LDS slo
 static_assert(WT_IDX_BITS == 12 && HK_NBR_MASK == WT_IDX_MASK, "point indices are 12 bits in the gather entries and in the window table alike");
 // LDS carve-up (dynamic shared memory), all offsets in bytes, 16-byte aligned.
 // tab: 0 = the window table stays in global memory (L2), 1 = table + rest lengths resident in LDS
+#if defined(CLOTHHIP_PHASE_STAMPS) || defined(CLOTHHIP_CELL_COUNTERS) || defined(CLOTHHIP_SWEEP_STAMPS)
+#define CLOTHHIP_TPH_LDS 1
+#endif
 struct LdsLayout {
+    int lkey;        // census build: every particle's cell key of the previous substep
+    int tphs;        // profiling / census builds: their twelve 64-bit accumulators (in front of the region the in-kernel metrics borrow)
     int cur, eps, wtab, pslot, hkey, hco, memb, slot, misc, alist, olist, cpos, total;
     // tab 2 (the eight-wave LEAN build): like 1, plus the table slots of every particle's six own springs (u16 [6][Ppad]): the strain
     // pre-pass of the LEAN arithmetic needs the slot of a flagged spring, and read it from the L2-resident gather table otherwise
@@ -304,11 +309,21 @@ struct LdsLayout {
         eps = take(EPSTATE_LDS_BYTES);   // EpState (fused episodes)
         wtab = take(tab >= 1 ? Spad * (tsz == 8 ? 16 : 8) : 0);   // WEnt<T>[Spad]
         pslot = take(tab == 2 ? (HK_SLOTS / 2) * Ppad * 2 : 0);
+#ifdef CLOTHHIP_TPH_LDS
+        tphs = take(96);
+#else
+        tphs = 0;
+#endif
+#ifdef CLOTHHIP_CELL_COUNTERS
+        lkey = take(4 * Ppad);
+#else
+        lkey = 0;
+#endif
         hkey = take(HT * 4);         // everything from here on doubles as scratch of the in-kernel metrics and is rebuilt afterwards
         hco = take(HT * 4);          // (fill cursor << 16) | member count
         memb = take(Ppad * 2);
         slot = take(Ppad * 2);
-        misc = take(256);            // flags and scan scratch (32 ints); behind them the profiling builds' twelve 64-bit accumulators
+        misc = take(256);            // flags and scan scratch (32 ints)
         olist = take(2 * Ppad);       // u16 hash slots: occupied cells from the front, cells with a seed from the back
         alist = olist;                //   (an active cell has >= 2 members, so #occupied + #active <= P)
         cpos = take(cp ? 4 * (Ppad + 32) * tsz : 0);   // particle records in cell (CSR) order for the pre-check; the
@@ -328,8 +343,7 @@ struct TphLds {
     unsigned long long *base; bool w;
     __device__ __forceinline__ TphRef operator[](int i) const { return TphRef{base + i, w}; }
 };
-#if defined(CLOTHHIP_PHASE_STAMPS) || defined(CLOTHHIP_CELL_COUNTERS) || defined(CLOTHHIP_SWEEP_STAMPS)
-#define CLOTHHIP_TPH_LDS 1
+#ifdef CLOTHHIP_TPH_LDS
 typedef TphLds TphT;
 #else
 typedef unsigned long long *TphT;
@@ -416,6 +430,11 @@ __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const
         const T tlim = ((ca != 0) & (cb != 0)) ? INF_ : t11;
         const uint32_t dlo = (uint32_t)dep, dhi = (uint32_t)(dep >> 32);
         bool pl = true;                                             // this lane's spring is not finished
+        // fp32: a finished spring's limit becomes +inf, so that the compare alone yields the wave's mask of over-stretched UNFINISHED
+        // springs (the ballot of a conjunction costs a select and a compare more per pass); the unfinished lanes as a scalar mask
+        constexpr bool V1 = sizeof(T) == 4;
+        T tl = tlim;
+        unsigned long long plm = ~0ull;
         if (STATS) st_windows++;
 #ifdef CLOTHHIP_CELL_COUNTERS
         if (w > corr_end_ && !((fmask >> (w & 63)) & 1ull)) tph[3] += 64;   // census: no flagged spring, beyond every correction's reach
@@ -430,7 +449,7 @@ __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const
             T len;
             if constexpr (sizeof(T) == 4) {      // one v_sqrt: cheaper than a branch around it
                 len = dev_sqrt<T>(len2);                                        // :270
-                trig = len > tlim;                                              // :275
+                trig = len > (V1 ? tl : tlim);                                  // :275
             } else {
                 trig = false; len = (T)0;
                 if (len2 > tlim * tlim * ((T)1 - filt_slack<T>())) {
@@ -439,7 +458,7 @@ __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const
                 }
             }
             // the over-stretched unfinished springs of the window, as this state shows them
-            const unsigned long long tb = ballot64(trig & pl);
+            const unsigned long long tb = V1 ? ballot64(trig) : ballot64(trig & pl);
             if (STATS) st_passes++;
             // A spring is VALID when none of its (transitive) predecessors in the window is over-stretched now: then every
             // predecessor that shares a particle with it leaves the particle alone, and the spring sees what the sequential sweep
@@ -462,7 +481,7 @@ __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const
 #endif
                 dirty = true;
                 if (STATS) st_commits++;
-                if (trig & pl & !bad) {
+                if (V1 ? (trig & !bad) : (trig & pl & !bad)) {
                     if (tic && len > rest * kl.tear_thresh) tear = 1;               // :272
                     const T ux = dev_div<T>(dx, len), uy = dev_div<T>(dy, len), uz = dev_div<T>(dz, len);   // :276-278
                     const T extra = len - t11;                                      // :279
@@ -478,7 +497,8 @@ __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const
                     *pb = P3{mad<T>(ux, eb, bx), mad<T>(uy, eb, by), mad<T>(uz, eb, bz)};
                 }
                 pl = pl & bad;
-                more = ballot64(pl) != 0ull;
+                if (V1) { tl = pl ? tl : INF_; plm &= ballot64(bad); more = plm != 0ull; }
+                else more = ballot64(pl) != 0ull;
                 if (TIMED) { unsigned long long td1; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(td1)::"memory"); tph[11] += td1 - td0; }
                 if (more) {
                     // same-wave LDS operations execute in program order: the reads below see the writes above without waiting
@@ -992,7 +1012,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
 
     int st_windows = 0, st_passes = 0, st_commits = 0;      // wave 0 only (uniform); the number of sweeps run lives in misc[15]
 #ifdef CLOTHHIP_TPH_LDS
-    const TphLds tph{reinterpret_cast<unsigned long long *>(smem + lay.misc + 128), tid == 0};
+    const TphLds tph{reinterpret_cast<unsigned long long *>(smem + lay.tphs), tid == 0};
     if (tid < 12) tph.base[tid] = 0ull;
     unsigned long long tlast = 0, tstart = 0;
 #else
@@ -1606,6 +1626,13 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
                     const int i = tid + q * NT;
                     const Pt<T> c = cur[i < P ? i : 0];                                           // own slot: no hazard
                     ckey[q] = cell_key<T>(k, c.x, c.y, c.z);
+#ifdef CLOTHHIP_CELL_COUNTERS
+                    if (i < P) {      // census: did any particle change its cell since the previous substep?
+                        uint32_t *lk_ = reinterpret_cast<uint32_t *>(smem + lay.lkey);
+                        if (lk_[i] != ckey[q]) atomicOr(&misc[16], 1);
+                        lk_[i] = ckey[q];
+                    }
+#endif
                     // (ht_bits 0: a table whose size is not a power of two -- the two-per-CU layout of the large grids -- is indexed by the
                     //  high half of hash x size; which slot a cell gets never shows in the results)
                     ch[q] = Ak_->ht_bits ? (ckey[q] * 2654435761u) >> (32 - Ak_->ht_bits) : __umulhi(ckey[q] * 2654435761u, (uint32_t)HT);
@@ -2037,11 +2064,11 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
             // tph[2] those whose predecessor was one too (state(t+1) == state(t): a fixed point)
             if (tid < 64) {
                 const bool frozen_ = mode != 1 && misc[12] == 0 && !swept_ && k.one_m_fric == (T)0;
-                tph[1] += frozen_ ? 64 : 0; tph[2] += (frozen_ && frozen_prev_) ? 64 : 0;
+                tph[1] += frozen_ ? 64 : 0; tph[2] += misc[16] == 0 ? 64 : 0;     // [2]: no particle changed its collision cell in this substep
                 frozen_prev_ = frozen_;
             }
             __syncthreads();
-            if (tid == 0) misc[12] = 0;
+            if (tid == 0) { misc[12] = 0; misc[16] = 0; }
 #endif
         }
         if (timing) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory"); }

@@ -29,8 +29,8 @@ for it in range(6):
 big, nmem, vis, trips, smt, na, nocc = (tot[4 + q] for q in (4, 5, 6, 7, 8, 9, 10))
 noseed, frozen, fixed, skipw, hits = (tot[4 + q] for q in (0, 1, 2, 3, 11))
 print("census, fraction of all cloth-substeps: no active collision cell %.3f | no strain sweep %.3f | frozen (no adjust, every "
-      "unpinned particle restored by the plane, no over-stretched spring) %.3f | frozen and the substep before it too (a fixed "
-      "point) %.3f" % (noseed / nsub, 1.0 - tot[0] / nsub, frozen / nsub, fixed / nsub))
+      "unpinned particle restored by the plane, no over-stretched spring) %.3f | no particle changed its collision cell since "
+      "the substep before %.3f" % (noseed / nsub, 1.0 - tot[0] / nsub, frozen / nsub, fixed / nsub))
 print("strain sweep per cloth-substep: windows walked %.1f, passes %.1f, correcting %.1f | windows without a flagged spring and beyond "
       "every correction's reach (skippable) %.1f" % (tot[1] / nsub, tot[2] / nsub, tot[3] / nsub, skipw / nsub))
 print("big cells: hits per visit %.2f" % (hits / max(vis, 1)))
