@@ -216,8 +216,10 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xF, 0xF, true));
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xF, 0xF, true));
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xF, 0xF, true));
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, true));     // lane 15 of rows 0,2 -> rows 1,3
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, true));     // lane 31 -> rows 2,3
+    // (all rows enabled in the two broadcast steps: only lane 63's value is used, and it comes out with the same association as with
+    //  the rows masked -- (R3 + R2) + (R1 + R0) -- while the unmasked form fuses into one v_add_f32_dpp per step)
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xF, 0xF, true));     // lane 15 of every row -> the next row
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xF, 0xF, true));     // lane 31 -> rows 2,3
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float row_allsum_f32(float v) {
@@ -525,12 +527,15 @@ __device__ __forceinline__ int collide_cell_wave(Pt<T> *cur, uint16_t *m, const 
     const bool in = lane < n;
     const int mine = in ? (int)m[lane] : 0x7fff;
     int rank = 0;
-    for (int t = 0; t < n; t++) rank += (__builtin_amdgcn_readlane(mine, t) < mine) ? 1 : 0;
-    if (in) m[rank] = (uint16_t)mine;                 // every lane has read its entry before any lane writes
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int i = in ? (int)m[lane] : 0;
+    // (four members per trip: the lanes behind the last member hold 0x7fff, which is below nobody; n <= 64)
+    for (int t = 0; t < n; t += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) rank += (__builtin_amdgcn_readlane(mine, t + u) < mine) ? 1 : 0;
+    }
+    // lane r takes the member of rank r: one pass through the LDS crossbar (the list in LDS stays as the fill left it: nobody
+    // reads it after the sweeps)
+    const int srt_ = __builtin_amdgcn_ds_permute((in ? rank : lane) << 2, mine);
+    const int i = in ? srt_ : 0;
     const Pt<T> me = cur[i];
     T x = me.x, y = me.y, z = me.z;
     // Members to visit, in ascending order: the SEEDS (unpinned members that have a hit at the positions the phase
@@ -544,6 +549,43 @@ __device__ __forceinline__ int collide_cell_wave(Pt<T> *cur, uint16_t *m, const 
     const T cfac = (T)1 + (T)2 / k.sim_steps;
     const T thr2c = thr2 * cfac * cfac;
     bool moved = false;
+#ifndef CLOTHHIP_SERIAL_HITSUM
+    if constexpr (sizeof(T) == 4) {
+        // fp32: the lane predicates of a visit as wave masks in scalar registers (one compare each; the conjunctions, "not the visited
+        // member", "later than it" are scalar bit operations), the exact test without a branch around it (a big cell nearly always
+        // has a candidate), the selects straight from the masks. Same arithmetic per lane, same visiting order.
+        const unsigned long long inm = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+        const unsigned long long freem = ballot64(free_);
+        unsigned long long movedm = 0ull;
+        while (todo) {
+            const int a = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+            todo &= todo - 1ull;
+            visits_++;
+            const T xa = bcast(x, a), ya = bcast(y, a), za = bcast(z, a);
+            const T dx = xa - x, dy = ya - y, dz = za - z;
+            const T d2 = sumsq<T>(dx, dy, dz);
+            const unsigned long long hm0 = ballot64(!(d2 > thr2)) & inm & ~(1ull << a);
+            if (!hm0) continue;
+            const T dist = dev_sqrt<T>(d2);                                             // :327
+            const unsigned long long hm = ballot64(dist <= k.thresh) & hm0;             // :330
+            if (!hm) continue;
+            const T factor = __builtin_amdgcn_inverse_ballot_w64(hm) ? dev_div<T>(k.thresh - dist, dist) : (T)0;   // :331
+            const T tx = wave_sum_f32(dx * factor), ty = wave_sum_f32(dy * factor), tz = wave_sum_f32(dz * factor);
+            const int nh = __builtin_popcount((uint32_t)hm) + __builtin_popcount((uint32_t)(hm >> 32));    // (two 32-bit counts: the 64-bit
+                                                                         // one reached the float conversion as a 64-bit integer, seven instructions)
+            hits_ += nh;
+            const T nf = (T)nh;                                                         // :336-343
+            const T nxa = xa + dev_div<T>(dev_div<T>(tx, nf), k.sim_steps);
+            const T nya = ya + dev_div<T>(dev_div<T>(ty, nf), k.sim_steps);
+            const T nza = za + dev_div<T>(dev_div<T>(tz, nf), k.sim_steps);
+            if (__builtin_amdgcn_inverse_ballot_w64(1ull << a)) { x = nxa; y = nya; z = nza; }
+            movedm |= 1ull << a;
+            todo |= ballot64(!(d2 > thr2c)) & freem & ~((2ull << a) - 1ull);            // a moved: later neighbours must look
+        }
+        moved = __builtin_amdgcn_inverse_ballot_w64(movedm);
+    } else
+#endif
+    {
     while (todo) {
         const int a = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
         todo &= todo - 1ull;
@@ -568,7 +610,8 @@ __device__ __forceinline__ int collide_cell_wave(Pt<T> *cur, uint16_t *m, const 
             // fp32 (parity is a tolerance): the hits' contributions (zero in the other lanes) summed by a DPP tree instead of one by
             // one in ascending order -- the Gauss-Seidel visiting order is untouched, only the association of this one sum differs
             tx = wave_sum_f32(fx); ty = wave_sum_f32(fy); tz = wave_sum_f32(fz);
-            nh = (int)__popcll(hm);
+            nh = __builtin_popcount((uint32_t)hm) + __builtin_popcount((uint32_t)(hm >> 32));    // (two 32-bit counts: the 64-bit one reached
+                                                                                                   //  the float conversion as a 64-bit integer, seven instructions)
         } else
 #endif
         while (hm) {                                                                    // ascending candidate order
@@ -584,6 +627,7 @@ __device__ __forceinline__ int collide_cell_wave(Pt<T> *cur, uint16_t *m, const 
         const T nza = za + dev_div<T>(dev_div<T>(tz, nf), k.sim_steps);
         if (lane == a) { x = nxa; y = nya; z = nza; moved = true; }
         todo |= ballot64(free_ && lane > a && !(d2 > thr2c));                           // a moved: later neighbours must look
+    }
     }
     if (moved) cur[i] = Pt<T>{x, y, z, me.w};
     return visits_ | (hits_ << 16);
