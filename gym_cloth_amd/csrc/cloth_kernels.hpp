@@ -432,10 +432,11 @@ __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const
         const T tlim = ((ca != 0) & (cb != 0)) ? INF_ : t11;
         const uint32_t dlo = (uint32_t)dep, dhi = (uint32_t)(dep >> 32);
         bool pl = true;                                             // this lane's spring is not finished
-        // fp32: a finished spring's limit becomes +inf, so that the compare alone yields the wave's mask of over-stretched UNFINISHED
+        // a finished spring's limit becomes +inf, so that the compare alone yields the wave's mask of over-stretched UNFINISHED
         // springs (the ballot of a conjunction costs a select and a compare more per pass); the unfinished lanes as a scalar mask
-        constexpr bool V1 = sizeof(T) == 4;
+        constexpr bool V1 = true;
         T tl = tlim;
+        T tl2 = tlim * tlim * ((T)1 - filt_slack<T>());           // fp64: the squared pre-filter of the limit
         unsigned long long plm = ~0ull;
         if (STATS) st_windows++;
 #ifdef CLOTHHIP_CELL_COUNTERS
@@ -454,9 +455,9 @@ __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const
                 trig = len > (V1 ? tl : tlim);                                  // :275
             } else {
                 trig = false; len = (T)0;
-                if (len2 > tlim * tlim * ((T)1 - filt_slack<T>())) {
+                if (len2 > (V1 ? tl2 : tlim * tlim * ((T)1 - filt_slack<T>()))) {
                     len = dev_sqrt<T>(len2);
-                    trig = len > tlim;
+                    trig = len > (V1 ? tl : tlim);
                 }
             }
             // the over-stretched unfinished springs of the window, as this state shows them
@@ -499,7 +500,7 @@ __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const
                     *pb = P3{mad<T>(ux, eb, bx), mad<T>(uy, eb, by), mad<T>(uz, eb, bz)};
                 }
                 pl = pl & bad;
-                if (V1) { tl = pl ? tl : INF_; plm &= ballot64(bad); more = plm != 0ull; }
+                if (V1) { tl = pl ? tl : INF_; if (sizeof(T) == 8) tl2 = pl ? tl2 : INF_; plm &= ballot64(bad); more = plm != 0ull; }
                 else more = ballot64(pl) != 0ull;
                 if (TIMED) { unsigned long long td1; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(td1)::"memory"); tph[11] += td1 - td0; }
                 if (more) {
