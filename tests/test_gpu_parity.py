@@ -223,11 +223,12 @@ def test_grid_too_large_for_lds_is_rejected():
         ClothBatch(g_cfg, n_envs=1, precision="f64")        # 64x64 doubles do not fit the CU's 160 KiB LDS
 
 
-@pytest.mark.parametrize("scale,lift", [(0.07, 0.5), (0.22, 0.3), (0.45, 0.1), (0.9, 0.02)])
+@pytest.mark.parametrize("scale,lift", [(0.07, 0.5), (0.22, 0.3), (0.38, 0.1), (0.45, 0.1), (0.9, 0.02)])
 def test_crowded_cells_selfcollision_f64(scale, lift, oracle_lib):
     """Self-collision stress: the whole 25x25 cloth squeezed into a fraction of its size, so the spatial cells hold
     from a dozen up to several hundred particles (max occupancy 468 / 138 at scales 0.07 / 0.22 -> the single-lane
-    path for cells over 64 members; 49 at 0.45 -> the whole-wave path; 14 at 0.9 -> four cells per wave in 16-lane
+    path for cells over 64 members; 49 at 0.45 and FOUR CELLS OF EXACTLY 64 at 0.38 -> the whole-wave path, every lane a member;
+    14 at 0.9 -> four cells per wave in 16-lane
     groups) and nearly every particle is moved by the collision pass. Every sweep path (seeds, wake-on-move, tickets)
     must reproduce the reference order exactly: fp64 bit-identical to the oracle after each of 4 substeps, with one
     pinned corner."""
@@ -263,10 +264,11 @@ def test_crowded_cells_selfcollision_f64(scale, lift, oracle_lib):
     b.close()
 
 
-@pytest.mark.parametrize("scale,lift", [(0.22, 0.3), (0.45, 0.1), (0.9, 0.02)])
+@pytest.mark.parametrize("scale,lift", [(0.22, 0.3), (0.38, 0.1), (0.45, 0.1), (0.9, 0.02)])
 def test_crowded_cells_selfcollision_f32(scale, lift, oracle_lib):
     """The same stress for the fp32 stepper, whose big-cell sweep is a path of its own (lane predicates as wave masks in scalar
-    registers, the hits summed by a DPP tree over all four rows of the wave: a cell of 49 members at scale 0.45 fills lanes 0..48,
+    registers, the hits summed by a DPP tree over all four rows of the wave: a cell of 49 members at scale 0.45 fills lanes 0..48, four cells of
+    exactly 64 at 0.38 every lane,
     the single-lane path takes the cells over 64 at 0.22, the 16-lane groups the small cells at 0.9): same visiting order as the
     reference, fp32 arithmetic -- within 5e-5 of the fp64 oracle after each of 4 substeps in which nearly every particle is moved by
     the collision pass (positions are O(1); the association of one sum per visit differs by design)."""
