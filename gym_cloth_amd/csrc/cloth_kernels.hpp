@@ -426,6 +426,19 @@ __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const
         ca = w_cnt(NA.w); cb = w_cnt(NB.w);                         // pins do not change during a sweep
         an = (int)(eab[0] & WT_IDX_MASK); bn = (int)__builtin_amdgcn_ubfe(eab[0], WT_IDX_BITS, WT_IDX_BITS);
         if (NEXT_AHEAD) { NA = cur[an]; NB = cur[bn]; }
+#ifdef CLOTHHIP_WINDOW_STAMPS          // dev measurement (sweep-stamps build): how long the read-ahead's two 16-byte reads take when waited for
+        if (TIMED) {                   // at once ([1], count [2]) against two stamps back to back ([3]): the LDS latency the sweep sees
+            unsigned long long s0_, s1_, s2_;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s0_)::"memory");
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s1_)::"memory");
+            const Pt<T> xa_ = cur[an], xb_ = cur[bn];
+            asm volatile("s_memtime %0" : "=s"(s2_)::"memory");
+            T keep_ = xa_.x + xb_.x; asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(keep_)::"memory");
+            unsigned long long s3_;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s3_)::"memory");
+            tph[3] += s1_ - s0_; tph[1] += s3_ - s1_; tph[2] += 64;
+        }
+#endif
         bool dirty = !NEXT_AHEAD;
         const T t11 = rest * kl.c11;
         // both ends pinned: skipped by the reference (:268) -- by a limit no length exceeds: ONE compare per pass then

@@ -49,6 +49,11 @@ def main():
             nq, nc = max(raw[4 + 9] / 64, 1), max(raw[3] / 64, 1)
             print("      window sweep: %.1f quiet passes/substep at %.0f cycles, %.1f correcting at %.0f" %
                   (nq / n, raw[4 + 10] / nq, nc / n, raw[4 + 11] / nc))
+        if os.environ.get("CLOTH_WINDOW_STAMPS"):      # dev build -DCLOTHHIP_WINDOW_STAMPS (with the sweep stamps): the LDS latency the sweep sees
+            raw = b.debug_stats()[0].astype(float) * 64
+            nwin = max(raw[4 + 2] / 64, 1)
+            print("      read-ahead of a window (two 16-byte LDS reads, waited for at once): %.0f cycles incl. one stamp; two stamps back "
+                  "to back: %.0f cycles  (%.1f windows/substep)" % (raw[4 + 1] / nwin, raw[4 + 3] / nwin, nwin / n))
     nsub = sum(p[1] for p in phases)
     print("total %d substeps %.2f ms -> %.2f us/substep -> %.2f M substeps/s at E=%d" %
           (nsub, tot_ms, tot_ms * 1e3 / nsub, E * nsub / tot_ms / 1e3, E))
