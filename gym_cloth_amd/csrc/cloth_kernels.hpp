@@ -378,6 +378,10 @@ __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const
     constexpr int PD = sizeof(T) == 4 ? 1 : 2;
     static_assert(PF + 1 <= WT_PAD_WINDOWS && PD + 1 <= WT_PAD_WINDOWS, "the table is padded by the read-ahead distance");
     int tear = 0;
+#ifdef CLOTHHIP_SWEEP_OUTER
+    unsigned long long so0_, so1_, so2_;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(so0_)::"memory");
+#endif
     DevConsts<T> kl = k;                         // spring-test constants pinned in VGPRs
     asm volatile("" : "+v"(kl.c11), "+v"(kl.tear_thresh));
     constexpr bool tic = TIC;                    // tear_thresh >= 1.1: tear implies stretch (the usual case; the caller tests it once)
@@ -408,6 +412,9 @@ __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const
     Pt<T> NA, NB;
     int an = (int)(eab[0] & WT_IDX_MASK), bn = (int)__builtin_amdgcn_ubfe(eab[0], WT_IDX_BITS, WT_IDX_BITS);
     NA = cur[an]; NB = cur[bn];
+#ifdef CLOTHHIP_SWEEP_OUTER
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(so1_)::"memory");
+#endif
     do {
         const uint32_t ab = eab[0];
         const T rest = erest[0];
@@ -528,6 +535,10 @@ __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const
         w++;
         if (dirty) { NA = cur[an]; NB = cur[bn]; }
     } while (w <= w_end);
+#ifdef CLOTHHIP_SWEEP_OUTER
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(so2_)::"memory");
+    tph[10] += so1_ - so0_; tph[11] += so2_ - so1_;
+#endif
     return tear;
 }
 
