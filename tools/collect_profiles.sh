@@ -8,7 +8,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 T="timeout -k 10 900"                      # (-k: a python child that ignores the signal is killed, not left holding the GPU)
 HEAD="--no-extra --no-cpu-baseline"        # the headline configuration only (512 cloths, fp32, fused time slices)
-# STAGES="bench trace traffic writerep l2 sq phases census action n50 ablation" selects stages (default: all)
+# STAGES="bench trace traffic writerep l2 sq sq2 phases census action n50 ablation" selects stages (default: all)
 want() { [[ -z "${STAGES:-}" || " $STAGES " == *" $1 "* ]]; }
 if want bench; then
 # 0. the full default bench line (what the driver runs), untraced
@@ -49,6 +49,13 @@ fi
 if want sq; then
 # 3. instruction mix / wait counters over the headline command
 for C in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS"; do
+  N=$(echo $C | tr ' ' '_')
+  $T rocprofv3 --pmc $C -d "$OUT/sq_$N" -o run -- python3 bench.py $HEAD --steps 10 > "$OUT/sq_$N.out" 2> "$OUT/sq_$N.log"
+done
+fi
+if want sq2; then
+# 3b. latencies as the sequencer sees them: instruction fetch (LEVEL / count), vector memory, LDS; branches; cycles waiting for an instruction
+for C in "SQ_IFETCH SQ_IFETCH_LEVEL SQ_INSTS_BRANCH" "SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM SQ_WAIT_INST_ANY" "SQ_INST_LEVEL_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS" "SQ_INSTS_SMEM SQ_INST_LEVEL_SMEM SQ_ACTIVE_INST_ANY"; do
   N=$(echo $C | tr ' ' '_')
   $T rocprofv3 --pmc $C -d "$OUT/sq_$N" -o run -- python3 bench.py $HEAD --steps 10 > "$OUT/sq_$N.out" 2> "$OUT/sq_$N.log"
 done
