@@ -542,6 +542,154 @@ __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const
     return tear;
 }
 
+// The same sweep by ALL NW waves of the cloth (round 5): speculative look-ahead over the next NW windows.
+//
+// Invariant at the head of a ROUND: every window before `wb` is finished and the particle state is the sequential sweep's state
+// at that point. Wave j holds the one window w of [wb, wb + NW) with w == j (mod NW) and evaluates its FIRST pass against that
+// state; whether the window holds an over-stretched spring goes to an LDS flag at position w - wb. After the workgroup barrier
+// every wave knows f, the first flagged window of the round. The windows before it are QUIET at the very state the sequential
+// sweep shows them (nothing before them in the round moved anything): they are finished -- no correction, and, a tear implying
+// a stretch (TIC), no tear. Window wb + f is then run to completion by its wave, exactly as strain_sweep's pass loop does
+// (its first pass is the one already evaluated: the state has not changed since), while the others wait at a second barrier;
+// it also publishes the end of the walk its corrections pushed out. The windows behind f were evaluated against a state that
+// f's corrections have since changed: their waves KEEP them (entry decoded, pins read) and evaluate them again in the next
+// round, wb' = wb + f + 1; the waves whose windows were finished move on to w + NW, whose table entry they read a round ahead.
+// A round without a flagged window finishes NW windows for one barrier. The pass rule inside a window, the reach rule and the
+// arithmetic are strain_sweep's; only WHO evaluates a window's first pass, and when, differs -- never against which state a
+// finished window was evaluated. tests/test_sweep_rule.py models the rounds on the CPU against the sequential loop.
+// `sw`: LDS ints, [0, 2 NW) the round's flags (double-buffered: a round's writes cannot meet the previous round's readers),
+// [2 NW] the end of the walk as the correcting wave left it.
+template <typename T, bool LDS_TAB, int NW, bool STATS, bool TIC>
+__device__ __forceinline__ int strain_sweep_mw(Pt<T> *cur, const WEnt<T> *wt, const uint32_t *g_ent, const T *g_rest,
+                                               const unsigned long long *g_dep, int w0, int w_end, int w_last, int rshift,
+                                               const DevConsts<T> &k, int lane, int wave, int *sw, int *st) {
+    static_assert((NW & (NW - 1)) == 0 && NW >= 2 && NW <= 16, "waves per cloth: a power of two");
+    int tear = 0;
+    DevConsts<T> kl = k;                         // spring-test constants pinned in VGPRs
+    asm volatile("" : "+v"(kl.c11), "+v"(kl.tear_thresh));
+    const T INF_ = sizeof(T) == 4 ? (T)__builtin_huge_valf() : (T)__builtin_huge_val();
+    struct __attribute__((aligned(16))) P3 { T x, y, z; };
+    // (windows past the table's padding are never active: a clamped read gives them an empty window's entries)
+    auto load = [&](int wi, uint32_t &ab_, T &r_, unsigned long long &d_) {
+        const uint32_t ix = (uint32_t)((wi < w_last ? wi : w_last) * 64 + lane);
+        if (LDS_TAB) { const WEnt<T> e_ = wt[ix]; ab_ = e_.ab; r_ = e_.rest; }
+        else { ab_ = g_ent[ix]; r_ = g_rest[ix]; }
+        d_ = g_dep[ix];
+    };
+    // LDS traffic of this wave visible to the others, then the workgroup barrier; the table stream's global loads stay in flight
+    auto wg_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    int wb = w0;
+    int w = wb + ((wave - wb) & (NW - 1));
+    uint32_t ab, abn; T rest, restn; unsigned long long dep, depn;
+    load(w, ab, rest, dep);
+    load(w + NW, abn, restn, depn);
+    int bank = 0;
+    while (wb <= w_end) {
+        const int a = (int)(ab & WT_IDX_MASK), b = (int)__builtin_amdgcn_ubfe(ab, WT_IDX_BITS, WT_IDX_BITS);
+        const Pt<T> RA = cur[a], RB = cur[b];
+        P3 *const pa = reinterpret_cast<P3 *>(cur + a), *const pb = reinterpret_cast<P3 *>(cur + b);
+        T ax = RA.x, ay = RA.y, az = RA.z, bx = RB.x, by = RB.y, bz = RB.z;
+        const uint32_t ca = w_cnt(RA.w), cb = w_cnt(RB.w);          // pins do not change during a sweep
+        const bool both = (ca != 0) & (cb != 0);
+        const T t11 = rest * kl.c11;
+        // both ends pinned: skipped by the reference (:268) -- by a limit no length exceeds: ONE compare per pass then
+        T tl = both ? INF_ : t11;
+        T tl2 = tl * tl * ((T)1 - filt_slack<T>());                 // fp64: the squared pre-filter of the limit
+        T dx = ax - bx, dy = ay - by, dz = az - bz;
+        T len2 = sumsq<T>(dx, dy, dz);
+        T len; bool trig;
+        auto test = [&]() {
+            if constexpr (sizeof(T) == 4) {      // one v_sqrt: cheaper than a branch around it
+                len = dev_sqrt<T>(len2);                                        // :270
+                trig = len > tl;                                                // :275
+            } else {
+                trig = false; len = (T)0;
+                if (len2 > tl2) { len = dev_sqrt<T>(len2); trig = len > tl; }
+            }
+        };
+        test();
+        unsigned long long tb = ballot64(trig);
+        const int rel = w - wb;                                     // wave-uniform, in [0, NW)
+        const bool hot = (w <= w_end) & (tb != 0ull);
+        if (lane == 0) sw[bank + rel] = hot ? 1 : 0;
+        wg_barrier();
+        const int fv = sw[bank + (lane & (NW - 1))];
+        const uint32_t fm = (uint32_t)ballot64(fv != 0) & ((1u << NW) - 1u);
+        bank ^= NW;
+        // tear_thresh < 1.1: a spring can tear without stretching, so every finished spring is tested (:272)
+        auto tear_test = [&](bool mine) { if (mine && !both && dev_sqrt<T>(len2) > rest * kl.tear_thresh) tear = 1; };
+        int adv = NW;                                               // windows this round finishes
+        if (fm != 0u) {
+            const int f = __builtin_ctz(fm);
+            adv = f + 1;
+            if (!TIC && rel < f && w <= w_end) tear_test(true);
+            if (rel == f) {
+                const uint32_t dlo = (uint32_t)dep, dhi = (uint32_t)(dep >> 32);
+                bool pl = true;                                     // this lane's spring is not finished
+                unsigned long long plm = ~0ull;
+                // every correction of the window may move particles whose springs sit as far as the window's reach
+                const int reach = w + ((int)((uint32_t)__builtin_amdgcn_readfirstlane((int)ab) >> WT_REACH_SHIFT) << rshift);
+                w_end = reach > w_end ? reach : w_end;
+                if (lane == 0) sw[2 * NW] = w_end;
+                for (;;) {
+                    // A spring is VALID when none of its (transitive) predecessors in the window is over-stretched now (see
+                    // strain_sweep): all valid springs are finished by this pass, the over-stretched ones corrected at once
+                    const bool bad = ((dlo & (uint32_t)tb) | (dhi & (uint32_t)(tb >> 32))) != 0u;
+                    if (!TIC) tear_test(pl & !bad);
+                    if (STATS && lane == 0) { atomicAdd(&st[0], 1); atomicAdd(&st[1], 1); }
+                    if (trig & !bad) {
+                        if (TIC && len > rest * kl.tear_thresh) tear = 1;               // :272
+                        const T ux = dev_div<T>(dx, len), uy = dev_div<T>(dy, len), uz = dev_div<T>(dz, len);   // :276-278
+                        const T extra = len - t11;                                      // :279
+                        // A pinned: B += dir*extra ; B pinned: A -= dir*extra ; else A -= dir*(extra*0.5), B += dir*(extra*0.5)
+                        // (extra * 1.0 == extra exactly, so one weighted form covers the three reference branches, :281-296)
+                        const T wa = ca != 0 ? (T)0 : (cb != 0 ? (T)1 : (T)0.5);
+                        const T wb_ = cb != 0 ? (T)0 : (ca != 0 ? (T)1 : (T)0.5);
+                        const T ea = extra * wa, eb = extra * wb_;
+                        // branch-free: a pinned end has weight 0 and x - u*0 == x exactly (see strain_sweep)
+                        *pa = P3{mad<T>(-ux, ea, ax), mad<T>(-uy, ea, ay), mad<T>(-uz, ea, az)};
+                        *pb = P3{mad<T>(ux, eb, bx), mad<T>(uy, eb, by), mad<T>(uz, eb, bz)};
+                    }
+                    pl = pl & bad;
+                    tl = pl ? tl : INF_; if (sizeof(T) == 8) tl2 = pl ? tl2 : INF_;
+                    plm &= ballot64(bad);
+                    if (plm == 0ull) break;
+                    // same-wave LDS operations execute in program order: the reads below see the writes above
+                    __builtin_amdgcn_wave_barrier();
+                    const P3 na = *pa, nb = *pb;
+                    ax = na.x; ay = na.y; az = na.z; bx = nb.x; by = nb.y; bz = nb.z;
+                    dx = ax - bx; dy = ay - by; dz = az - bz;
+                    len2 = sumsq<T>(dx, dy, dz);
+                    test();
+                    tb = ballot64(trig);
+                    if (tb == 0ull) {                                // a quiet pass ends the window
+                        if (!TIC) tear_test(pl);
+                        if (STATS && lane == 0) atomicAdd(&st[0], 1);
+                        break;
+                    }
+                }
+            }
+            wg_barrier();
+            w_end = __builtin_amdgcn_readfirstlane(sw[2 * NW]);
+        } else if (!TIC) {
+            tear_test(w <= w_end);
+        }
+        if (STATS && lane == 0 && wave == 0) {                      // windows walked; first passes of the quiet ones among them
+            const int nw_ = fm != 0u ? adv : (w_end - wb + 1 < NW ? w_end - wb + 1 : NW);
+            atomicAdd(&st[2], nw_); atomicAdd(&st[0], fm != 0u ? nw_ - 1 : nw_);
+#ifdef CLOTHHIP_MW_ROUNDS               // dev measurement: rounds instead of windows, correcting rounds instead of correcting passes
+            atomicAdd(&st[2], 1 - nw_); atomicAdd(&st[3], fm != 0u ? 1 : 0);
+#endif
+        }
+        wb += adv;
+        if (rel < adv) {
+            w += NW; ab = abn; rest = restn; dep = depn;
+            load(w + NW, abn, restn, depn);
+        }
+    }
+    return tear;
+}
+
 // Self-collision of ONE spatial cell (cloth.pyx:313-343) by a whole wave, exact Gauss-Seidel order:
 // lane b holds the cell's b-th member in ascending point index; members are visited serially in that order
 // each against all lanes in parallel; the hits are summed in ascending member order. n <= 64.
@@ -1063,7 +1211,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
             for (int i = tid; i < A.Spad; i += NT) { WEnt<T> w_; w_.ab = s_ent[i]; w_.rest = s_rest[i]; d0[i] = w_; }
         }
         for (int h = tid; h < HT; h += NT) { hkey[h] = KEY_EMPTY; hco[h] = 0; }
-        if (tid == 0) { misc[0] = tear_flag; misc[1] = 0; misc[2] = 0; misc[3] = 0; misc[4] = 0; misc[5] = 0; misc[6] = 0; misc[10] = 0x7fffffff; misc[11] = -1; misc[12] = 0; misc[13] = 0; misc[14] = 0; }
+        if (tid == 0) { misc[0] = tear_flag; misc[1] = 0; misc[2] = 0; misc[3] = 0; misc[4] = 0; misc[5] = 0; misc[6] = 0; misc[10] = 0x7fffffff; misc[11] = -1; misc[12] = 0; misc[13] = 0; misc[14] = 0; misc[20] = 0; misc[21] = 0; misc[22] = 0; misc[23] = 0; }
     };
     if (tid == 0) misc[15] = 0;
     init_lds(A.tear[e], A.wt_ent, g_rest);
@@ -1097,6 +1245,12 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
     constexpr bool SWEEP_TIMED = true;
 #else
     constexpr bool SWEEP_TIMED = false;
+#endif
+#if defined(CLOTHHIP_SWEEP_MW) && !defined(CLOTHHIP_SWEEP_STAMPS) && !defined(CLOTHHIP_SWEEP_OUTER)
+    constexpr bool SWEEP_MW = true;     // A/B build (round 5): every wave of the cloth looks ahead one window each (strain_sweep_mw);
+                                        // bit-identical, measured -8 % on the headline workload: not the production path
+#else
+    constexpr bool SWEEP_MW = false;    // the one-wave walk (strain_sweep)
 #endif
 #if defined(CLOTHHIP_PHASE_STAMPS) || defined(CLOTHHIP_CELL_COUNTERS)   // the sweep's window / pass / correction counters cost its loop three instructions per pass:
     constexpr bool SWEEP_STATS = true;  // profiling builds only (the production build counts sweeps)
@@ -2098,6 +2252,41 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
 #ifdef CLOTHHIP_CELL_COUNTERS
             int swept_ = 0;
 #endif
+            if (SWEEP_MW) {
+                // every wave of the cloth takes part (strain_sweep_mw): the decision and the walk's bounds are read by all of them
+                // before the sweep's first barrier and reset by wave 0 behind its last
+                if (misc[1] || (pm & PH_NOSKIP)) {
+                    const bool all_ = (pm & PH_NOSKIP) != 0;
+                    const int w0 = __builtin_amdgcn_readfirstlane(all_ ? 0 : (misc[10] >> 6));
+                    const int w1 = __builtin_amdgcn_readfirstlane(all_ ? Ak_->nW - 1 : (misc[11] >> 6));
+                    const bool tic = __builtin_amdgcn_readfirstlane(!(k.tear_thresh < k.c11) ? 1 : 0) != 0;
+                    const int wave_ = __builtin_amdgcn_readfirstlane(tid >> 6);
+                    const int wl_ = (Ak_->Spad >> 6) - 1;                   // the table's last (padding, empty) window
+                    int *const sw_ = misc + 24, *const st_ = misc + 20;
+#ifdef CLOTHHIP_MW_PRIO
+                    __builtin_amdgcn_s_setprio(CLOTHHIP_MW_PRIO);
+#endif
+                    const int tear = tic ? strain_sweep_mw<T, v_ldstab(TAB), NT / 64, SWEEP_STATS, true>(cur, wtab, Ak_->wt_ent, g_rest, Ak_->wt_dep, w0, w1, wl_, Ak_->wt_rshift, k, lane, wave_, sw_, st_)
+                                         : strain_sweep_mw<T, v_ldstab(TAB), NT / 64, SWEEP_STATS, false>(cur, wtab, Ak_->wt_ent, g_rest, Ak_->wt_dep, w0, w1, wl_, Ak_->wt_rshift, k, lane, wave_, sw_, st_);
+#ifdef CLOTHHIP_MW_PRIO
+                    __builtin_amdgcn_s_setprio(0);
+#endif
+                    if (__any(tear) && lane == 0) misc[0] = 1;
+#ifdef CLOTHHIP_CELL_COUNTERS
+                    swept_ = 1;
+#endif
+                    if (tid == 0) {
+                        misc[15]++; misc[1] = 0; misc[10] = 0x7fffffff; misc[11] = -1;
+                        if (SWEEP_STATS) {
+                            st_passes += st_[0]; st_commits += st_[1]; st_windows += st_[2];
+#ifdef CLOTHHIP_MW_ROUNDS
+                            st_commits += st_[3] - st_[1]; st_[3] = 0;
+#endif
+                            st_[0] = 0; st_[1] = 0; st_[2] = 0;
+                        }
+                    }
+                }
+            } else
             if (tid < 64 && (misc[1] || (pm & PH_NOSKIP))) {
                 __builtin_amdgcn_s_setprio(3);            // the serial sweep is the critical path of the whole cloth
                 const bool all_ = (pm & PH_NOSKIP) != 0;

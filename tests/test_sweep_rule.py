@@ -177,6 +177,89 @@ def _window_walk(pos0, pin, rest, W, tear_thresh):
     return pos, tear, passes, windows
 
 
+def _window_walk_mw(pos0, pin, rest, W, tear_thresh, NW):
+    """The kernel's walk by all NW waves of a cloth (csrc/cloth_kernels.hpp::strain_sweep_mw): per ROUND the first pass of the next
+    NW windows is evaluated against ONE state; the windows before the first flagged one are finished as evaluated, the flagged one
+    is run to completion by the pass rule, everything behind it is evaluated again in the next round."""
+    A, B, sa = W["A"], W["B"], W["spring_at"]
+    pos = pos0.copy()
+    tear = False
+    valid = np.nonzero(sa >= 0)[0]
+    ss = sa[valid].astype(np.int64)
+    d = pos[A[ss]] - pos[B[ss]]
+    ln = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2])
+    both = (pin[A[ss]] != 0) & (pin[B[ss]] != 0)
+    fl = valid[(~both) & ((ln > rest[ss] * C11) | (ln > rest[ss] * tear_thresh))]
+    rounds = barriers = 0
+    if len(fl) == 0:
+        return pos, tear, rounds, barriers
+    wb, w_end = int(fl.min()) >> 6, int(fl.max()) >> 6
+    w_last = W["n_slots"] // 64 - 1
+
+    def first_pass(w, state):
+        lanes = np.nonzero(sa[w * 64:(w + 1) * 64] >= 0)[0]
+        sw = sa[w * 64 + lanes].astype(np.int64)
+        a, b = A[sw], B[sw]
+        bothw = (pin[a] != 0) & (pin[b] != 0)
+        d = state[a] - state[b]
+        ln = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2])
+        return lanes, sw, a, b, bothw, d, ln
+
+    while wb <= w_end:
+        rounds += 1; barriers += 1
+        snap = pos.copy()                                         # every wave evaluates against the state at the round's head
+        hot, tears = [], []
+        for rel in range(NW):
+            w = min(wb + rel, w_last)
+            lanes, sw, a, b, bothw, d, ln = first_pass(w, snap)
+            hot.append(wb + rel <= w_end and bool(((ln > rest[sw] * C11) & ~bothw).any()))
+            tears.append(bool(((ln > rest[sw] * tear_thresh) & ~bothw).any()))
+        if not any(hot):
+            for rel in range(NW):
+                if wb + rel <= w_end and tears[rel]:
+                    tear = True
+            wb += NW
+            continue
+        f = hot.index(True)
+        for rel in range(f):                                      # quiet at the very state the sequential sweep shows them
+            if tears[rel]:
+                tear = True
+        w = wb + f
+        barriers += 1
+        lanes, sw, a, b, bothw, d, ln = first_pass(w, pos)
+        dep = [int(x) for x in W["dep"][w * 64 + lanes]]
+        pend = np.ones(len(lanes), dtype=bool)
+        w_end = max(w_end, w + ((int(W["ent"][w * 64]) >> 28) << W["rshift"]))
+        while True:
+            trig = (ln > rest[sw] * C11) & ~bothw & pend
+            tb = 0
+            for l in lanes[trig]:
+                tb |= 1 << int(l)
+            bad = np.array([(dep[i] & tb) != 0 for i in range(len(lanes))], dtype=bool) & pend
+            fin = pend & ~bad
+            if ((ln > rest[sw] * tear_thresh) & fin & ~bothw).any():
+                tear = True
+            if tb == 0:
+                break
+            for i in np.nonzero(trig & ~bad)[0]:
+                u = d[i] / ln[i]
+                e = ln[i] - rest[sw[i]] * C11
+                if pin[a[i]]:
+                    pos[b[i]] = pos[b[i]] + u * e
+                elif pin[b[i]]:
+                    pos[a[i]] = pos[a[i]] - u * e
+                else:
+                    pos[a[i]] = pos[a[i]] - u * (e * 0.5)
+                    pos[b[i]] = pos[b[i]] + u * (e * 0.5)
+            pend = bad
+            if not pend.any():
+                break
+            d = pos[a] - pos[b]
+            ln = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2])
+        wb += f + 1
+    return pos, tear, rounds, barriers
+
+
 def test_pass_rule_equals_sequential_sweep(lib):
     """Stretched states (golden checkpoints of the lift-and-pull and fold trajectories blown up about their centroid, pulled at
     their pins, jittered; incl. a torn one and springs with both ends pinned): the window walk over the library's tables gives
@@ -213,6 +296,11 @@ def test_pass_rule_equals_sequential_sweep(lib):
                 p_win, t_win, passes, windows = _window_walk(pos, pin, rest, W, tt)
                 assert np.array_equal(p_seq, p_win), (name, cp, variant, float(np.abs(p_seq - p_win).max()))
                 assert t_seq == t_win, (name, cp, variant)
+                for nw in (4, 8, 16):                              # the same walk by all waves of a cloth, a window each per round
+                    p_mw, t_mw, rounds, barriers = _window_walk_mw(pos, pin, rest, W, tt, nw)
+                    assert np.array_equal(p_seq, p_mw), (name, cp, variant, nw, float(np.abs(p_seq - p_mw).max()))
+                    assert t_seq == t_mw, (name, cp, variant, nw)
+                    assert rounds <= max(windows, 1)
                 moved = int((p_seq != pos).any(axis=1).sum())
                 stats.append((moved, passes, windows))
                 cases += 1
