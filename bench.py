@@ -19,8 +19,13 @@ Two execution modes (both reported; `value` is the fused one unless --mode step)
          many). The result of an action does not depend on which launch executes it.
   step   ClothVecEnv.step: one launch sequence per step (grab, schedule kernel, metrics), the clock is STOPPED around the
          host-driven episode resets between steps (SURVEY 8d excludes reset from the timed region).
-value = executed Cloth.update()-equivalents of all envs and ranks / timed wall time. State is resident in HBM; the timed
-region contains no state upload.
+value = SURVEY.md 8d's metric: Cloth.update()-equivalents executed by ACTIONS (grab, substep loop, release, metrics), all envs and
+ranks, / the part of the timed wall time the envs spent in actions. 8d excludes create / reset from the timed region; in the fused
+mode the episode resets run inside the same launches (an env resets and goes on while the others step), so the kernel accounts
+every env's launch time to {actions, reset pulls, reset settling, other} with the 100 MHz s_memrealtime clock and the wall time is
+split by those shares (config.action_time_frac; config.timed_region_s is the whole wall time). The blended figure -- ALL executed
+update() calls, reset pulls and settling included, / the whole wall time -- is config.blended_substeps_per_s (rounds 1-4 printed it
+as `value`). State is resident in HBM; the timed region contains no state upload.
 
 Multi-GPU: one process per GPU (launched by the driver with torch.distributed.run, or by this script itself with
 --gpus N when no launcher environment is present); env blocks are sharded, rank 0's action table is broadcast and the
@@ -111,7 +116,7 @@ def cpu_baseline(cfg, acts0, states, budget_s=15.0):
             "single_core_samples": singles}
 
 
-TRAFFIC_FILES = ("r04_traffic.json", "r03_traffic.json")       # the newest committed PMC record wins
+TRAFFIC_FILES = ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json")       # the newest committed PMC record wins
 
 
 def load_traffic(mode, E, n_side, precision, init, substeps_per_launch, b_alg=None):
@@ -131,11 +136,11 @@ def load_traffic(mode, E, n_side, precision, init, substeps_per_launch, b_alg=No
                         if per_sub is None and r.get("algorithmic_bytes_per_launch") and b_alg:
                             per_sub = r["hbm_bytes_per_launch"] / (r["algorithmic_bytes_per_launch"] / b_alg)
                         if per_sub is None:
-                            return r["hbm_bytes_per_launch"]             # (old records: bytes of THAT run's launches)
-                        return per_sub * substeps_per_launch
+                            return r["hbm_bytes_per_launch"], "profiles/" + name     # (old records: bytes of THAT run's launches)
+                        return per_sub * substeps_per_launch, "profiles/" + name
         except (OSError, ValueError, KeyError):
             pass
-    return None
+    return None, None
 
 
 def run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, rank, world, local_rank, thickness=None,
@@ -303,11 +308,22 @@ def run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, rank
     n_sub_all = xch.sum_over_ranks(stat["sub"])
     n_act_all = xch.sum_over_ranks(stat["act_sub"])
     n_env_steps = xch.sum_over_ranks(stat["ran"])
+    # the share of the envs' launch time spent in actions (all ranks): the kernel's own per-env accounting. Step mode runs its
+    # resets outside the clock (and keeps no such accounting): everything timed there is an action
+    tk_act_all = xch.sum_over_ranks(float(stat["op_ticks"][0]))
+    tk_all = xch.sum_over_ranks(float(np.sum(stat["op_ticks"])))
+    act_frac = tk_act_all / tk_all if (mode == "fused" and tk_all > 0) else 1.0
     rec = None
     if rank == 0:
         b_alg32 = 49 * P                                      # algorithmic bytes per cloth-substep (fp32 state)
         b_alg = b_alg32 if precision == "f32" else 97 * P     # the same accounting at the f64 instantiation's state width
-        ach = (stat["sub"] * b_alg / 1e9) / (stat["kms"] / 1e3) if stat["kms"] > 0 else 0.0
+        # the dominant kernel's rate on the metric's definition: action substeps of this rank / the kernel time its envs spent in actions
+        tk_r, kms_act = stat["op_ticks"], 0.0
+        if stat["kms"] > 0:
+            kms_act = stat["kms"] * (float(tk_r[0]) / float(np.sum(tk_r)) if (mode == "fused" and np.sum(tk_r) > 0) else 1.0)
+        ach = (stat["act_sub"] * b_alg / 1e9) / (kms_act / 1e3) if kms_act > 0 else 0.0
+        ach_blended = (stat["sub"] * b_alg / 1e9) / (stat["kms"] / 1e3) if stat["kms"] > 0 else 0.0
+        traffic, traffic_src = load_traffic(mode, E, n_side, precision, init, stat["sub"] / max(stat["launches"], 1), b_alg)
         # SURVEY 8d's metric proper (reset excluded): action substeps / time spent in actions. The kernel accounts every env's
         # launch time to {actions, reset pulls, reset settling, rest}; with n_conc cloths stepping concurrently on the GPU the
         # rate of an actions-only workload is n_conc * sum(action substeps) / sum(env-seconds in actions).
@@ -316,13 +332,16 @@ def run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, rank
         n_conc = min(E, max(1, variant["cloths_per_cu"]) * max(1, variant["n_cus"]))
         act_only = n_conc * sb[0] / (tk[0] / 1e8) if tk[0] > 0 else None
         reset_only = n_conc * (sb[1] + sb[2]) / ((tk[1] + tk[2]) / 1e8) if (tk[1] + tk[2]) > 0 else None
+        steps_eq = max(n_env_steps / (world * E), 1e-9)
         rec = {
-            "value": n_sub_all / dt, "ms_per_step": dt / max(n_env_steps / (world * E), 1e-9) * 1e3, "dtype": precision,
+            # action substeps / the wall time spent in actions; ms_per_step on the same footing (one env step's action)
+            "value": n_act_all / (dt * act_frac), "ms_per_step": dt * act_frac / steps_eq * 1e3, "dtype": precision,
             "config": {"workload": "%d batched %dx%d cloths per GPU, %s start, random pick-and-place actions, episodes "
                                    "reset as in the reference's loop (BASELINE configs[2]; configs[3] = 8 x this)"
                                    % (E, n_side, n_side, init.replace("tier", "tier-")),
                        "mode": ("fused: %d launches, each a %.0f ms time slice of back-to-back actions and episode resets per env "
-                                "(reset substeps counted)" % (stat["launches"], slice_ms))
+                                "(value: the actions' substeps over the actions' share of the time; resets excluded, SURVEY 8d)"
+                                % (stat["launches"], slice_ms))
                                if mode == "fused" else "step: one launch sequence per step, clock stopped around host-driven resets",
                        "envs_per_gpu": E, "n_side": n_side, "init": init, "exact_order": True, "transport": transport_name,
                        "rccl_nranks": rccl_nranks,                                      # ncclCommCount of the communicator that ran (None: no RCCL)
@@ -330,7 +349,13 @@ def run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, rank
                        "slice_calibration": calib,                                      # fused: how the time slices were sized, in this run
                        "env_steps_executed": n_env_steps, "steps_equivalent": n_env_steps / (world * E),
                        "env_steps_per_s": n_env_steps / dt,
+                       # the timed region: whole wall time (max over ranks), the share of it the envs spent in actions (in-kernel
+                       # accounting, all ranks), and what rounds 1-4 printed as `value`: ALL update() calls / the whole wall time
+                       "timed_region_s": dt, "action_time_frac": act_frac,
+                       "wall_ms_per_env_step_incl_resets": dt / steps_eq * 1e3,
+                       "blended_substeps_per_s": n_sub_all / dt,
                        "substeps_per_env_step": n_sub_all / max(n_env_steps, 1),
+                       "action_substeps_per_env_step": n_act_all / max(n_env_steps, 1),
                        "action_substeps_per_s": n_act_all / dt,                         # action substeps / WHOLE time: a lower bound
                        # SURVEY 8d's definition (reset excluded), this rank: action substeps / time the envs spent in actions
                        "action_only_substeps_per_s": act_only, "reset_only_substeps_per_s": reset_only,
@@ -344,13 +369,21 @@ def run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, rank
                        # of action slots; step: it executed its action slot)
                        "active_env_frac": 1.0 - stat["out_of_slots"] / max(E * stat["launches"], 1) if mode == "fused" else 1.0,
                        "episode_resets_in_timed_region": stat["resets"]},
+            # achieved = algorithmic bytes of the ACTION substeps / the kernel time spent in actions (HIP events on the handle's stream x
+            # the in-kernel share), i.e. the same numerator as `value`; *_blended: every substep of the launch / the whole kernel time
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS,
-                         "traffic": load_traffic(mode, E, n_side, precision, init, stat["sub"] / max(stat["launches"], 1), b_alg),
+                         "traffic": traffic,
+                         "traffic_source": ("%s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same command "
+                                            "(tools/collect_profiles.sh), bytes per substep scaled by this run's substeps per launch; "
+                                            "NOT measured in this run" % traffic_src) if traffic is not None else None,
                          "kernel": "k_run_schedule", "kernel_ms_avg": stat["kms"] / max(stat["launches"], 1),
+                         "kernel_ms_in_actions_avg": kms_act / max(stat["launches"], 1),
                          "launches": stat["launches"], "alg_bytes_per_substep": b_alg,
-                         "frac_on_fp32_bytes": (stat["sub"] * b_alg32 / 1e9) / (stat["kms"] / 1e3) / HBM_PEAK_GBS if stat["kms"] > 0 else 0.0,
-                         "substeps_per_launch": stat["sub"] / max(stat["launches"], 1)},
+                         "frac_on_fp32_bytes": (stat["act_sub"] * b_alg32 / 1e9) / (kms_act / 1e3) / HBM_PEAK_GBS if kms_act > 0 else 0.0,
+                         "achieved_blended": ach_blended, "frac_blended": ach_blended / HBM_PEAK_GBS,
+                         "substeps_per_launch": stat["sub"] / max(stat["launches"], 1),
+                         "action_substeps_per_launch": stat["act_sub"] / max(stat["launches"], 1)},
         }
         if want_cpu and cpu_states is not None:
             rec["cpu_baseline"] = cpu_baseline(cfg, (cpu_acts if cpu_acts is not None else acts_all[warmup])[:len(cpu_states[0])],

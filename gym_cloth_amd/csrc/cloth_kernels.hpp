@@ -742,8 +742,11 @@ __device__ __forceinline__ int collide_cell_wave(Pt<T> *cur, uint16_t *m, const 
             const T dist = dev_sqrt<T>(d2);                                             // :327
             const unsigned long long hm = ballot64(dist <= k.thresh) & hm0;             // :330
             if (!hm) continue;
-            const T factor = __builtin_amdgcn_inverse_ballot_w64(hm) ? dev_div<T>(k.thresh - dist, dist) : (T)0;   // :331
-            const T tx = wave_sum_f32(dx * factor), ty = wave_sum_f32(dy * factor), tz = wave_sum_f32(dz * factor);
+            // (the PRODUCT is selected, not the factor: a member that is no hit may hold a non-finite coordinate -- a blown-up particle --
+            //  and inf * 0 would carry it into the visited particle's sum; the reference reads the hits only, :330-334)
+            const bool hl = __builtin_amdgcn_inverse_ballot_w64(hm);
+            const T factor = dev_div<T>(k.thresh - dist, dist);                                                   // :331
+            const T tx = wave_sum_f32(hl ? dx * factor : (T)0), ty = wave_sum_f32(hl ? dy * factor : (T)0), tz = wave_sum_f32(hl ? dz * factor : (T)0);
             const int nh = __builtin_popcount((uint32_t)hm) + __builtin_popcount((uint32_t)(hm >> 32));    // (two 32-bit counts: the 64-bit
                                                                          // one reached the float conversion as a 64-bit integer, seven instructions)
             hits_ += nh;
@@ -1157,7 +1160,8 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
     uint16_t *olist = reinterpret_cast<uint16_t *>(smem + lay.olist);
     uint16_t *alist_end = olist + (Ppad - 1);            // active list grows downwards: entry k = alist_end[-k]
     Pt<T> *cpos = reinterpret_cast<Pt<T> *>(smem + lay.cpos);
-    const DevConsts<T> &k = A.k;
+    const DevConsts<T> &k = A.k;                         // (every phase of the substep loop shadows this by its own freshly loaded copy: CLOTH_PHASE_ARGS)
+    (void)k;
     const T *g_rest = A.rest + (size_t)e * A.rest_stride;
     const WEnt<T> *wtab = reinterpret_cast<const WEnt<T> *>(smem + lay.wtab);    // TAB >= 1 only
     // rest length of the spring in window-table slot i (Hooke, pre-pass; the sweep streams its own)

@@ -73,7 +73,9 @@ struct clothhip_handle {
     int32_t last_variant[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // what the last launch ran (clothhip_last_variant)
     bool have_variant = false;
     int n_cus = 0;
-    struct Layout { int nt, ppt, tab; bool rest_reg; int cell_copy; int lds_bytes; int HT, ht_bits; } lay_std = {256, 3, 0, false, 0, 0, 0, 0}, lay_lean = {256, 3, 0, true, 0, 0, 0, 0};
+    // (scratch_have / scratch_need: the LDS behind the hash table that the in-kernel metrics of the episode launches borrow, and what they need)
+    struct Layout { int nt, ppt, tab; bool rest_reg; int cell_copy; int lds_bytes; int HT, ht_bits; int scratch_have, scratch_need; } lay_std = {256, 3, 0, false, 0, 0, 0, 0, 0, 0}, lay_lean = {256, 3, 0, true, 0, 0, 0, 0, 0, 0};
+    struct OccKey { const void *fn; int lds; int occ; } occ_cache[8] = {};   // hipOccupancyMaxActiveBlocksPerMultiprocessor per (kernel, LDS bytes)
     double *d_levels = nullptr, *d_xy = nullptr, *d_radius = nullptr, *d_cov = nullptr, *d_vinv = nullptr;
     uint8_t *d_oob = nullptr;
     int32_t *d_hcnt = nullptr;      // per env: #points with z < thickness/2 (height reward, cloth_env.py:1047-1073)
@@ -208,6 +210,150 @@ static void free_handle(clothhip_handle *h) {
 
 static const void *stepper_fn(const clothhip_handle *h, int fused);
 
+// The LDS a layout leaves the in-kernel metrics (from the hash table to the end of the allocation) against what they need; the
+// allocation is padded behind the layout's end when that fits the budget (the kernel addresses LDS by the layout's offsets: bytes
+// behind `total` are free). False: the episode launches cannot run on this layout.
+static bool fit_scratch(clothhip_handle::Layout &L, int tsz, int Ppad, int Spad, int P, int budget) {
+    int NS = 1; while (NS < P) NS <<= 1;
+    const LdsLayout lay(tsz, Ppad, Spad, L.HT, L.tab == 2 ? 2 : (v_ldstab(L.tab) ? 1 : 0), L.cell_copy);
+    L.scratch_need = metrics_scratch_bytes(NS, Ppad + 8, tsz, v_hull_idx(L.tab));
+    if (L.lds_bytes < lay.total) L.lds_bytes = lay.total;
+    if (L.lds_bytes - lay.hkey < L.scratch_need && lay.hkey + L.scratch_need <= budget) L.lds_bytes = (lay.hkey + L.scratch_need + 15) / 16 * 16;
+    L.scratch_have = L.lds_bytes - lay.hkey;
+    return L.scratch_have >= L.scratch_need;
+}
+
+// Which stepper variant and which LDS layout a handle runs: pure host logic (no HIP call), so that the CPU test suite can sweep it
+// over grid sizes and precisions (clothhip_selftest_layout). Fills nt / ppt / HT / tab / rest_reg / cell_copy / lds_bytes, the
+// standard layout lay_std and, where the LEAN arithmetic applies, lay_lean + lean_r.
+static void plan_layouts(clothhip_handle *h, int cus, const std::vector<uint32_t> &gather) {
+    // threads per cloth x particles per thread (compile-time variants of the stepper)
+    // P <= 768 (the 25x25 class, two cloths per CU): EIGHT waves per cloth -- 512 threads x 2 particles, compiled for 128 VGPRs: the cell
+    // sweeps have eight ticket takers and the parallel phases two waves per SIMD to hide their LDS latency (+4 % fp32 standard
+    // arithmetic, +9 % fp64, +13 % tier 2 over the four-wave 256 x 3 variants, bit-identical; CLOTHHIP_DEBUG_W8=0 selects those)
+    const bool small_grid = h->P <= 768;
+    const bool w8 = !(getenv("CLOTHHIP_DEBUG_W8") && atoi(getenv("CLOTHHIP_DEBUG_W8")) == 0);
+    if (small_grid) { h->nt = w8 ? 512 : 256; h->ppt = w8 ? 2 : 3; }
+    else if (h->P <= 2560 && !getenv("CLOTHHIP_DEBUG_NT1024")) { h->nt = 512; h->ppt = 5; }
+    else if (h->P <= 3072) { h->nt = 1024; h->ppt = 3; } else { h->nt = 1024; h->ppt = 4; }
+    h->HT = 64; h->ht_bits = 0;
+    while (h->HT <= h->P + h->P / 2) h->HT <<= 1;
+    while ((1 << h->ht_bits) < h->HT) h->ht_bits++;
+    // large dynamic LDS (up to the CU's 160 KiB) for the stepper kernels. The static tables ride in LDS too
+    // as long as TWO cloths still fit per CU (512 cloths = 2 per CU on the 256 CUs of an MI355X).
+    {
+        const int tsz = (int)h->tsz;
+        const int precision = h->precision;
+        // 256-thread variants: two cloths per CU (<= 80 KiB each); the larger ones own the CU (<= 160 KiB)
+        const int budget = small_grid ? 80 * 1024 : 160 * 1024;
+        const int tmax = h->nt <= 512 ? 1 : 0;
+        h->tab = (tmax >= 1 && LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 1, 0).total <= budget) ? 1 : 0;
+        if (const char *t = getenv("CLOTHHIP_DEBUG_TAB_LDS")) h->tab = std::min(h->tab, atoi(t));
+        h->rest_reg = (h->nt == 256 && precision == CLOTHHIP_F32 && h->tab == 1);
+        if (const char *t = getenv("CLOTHHIP_DEBUG_REST_REG")) h->rest_reg = h->rest_reg && atoi(t);
+        // LEAN variants: three to six cloths per CU instead of two, each stepping at a lower rate (lean_rates.hpp, measured by
+        // tools/measure_pick_table.py). A launch runs its cloths in generations of what is resident, so the batch size decides:
+        // the largest rate_r / ceil(E / (r * CUs)) wins.
+        {
+            h->n_cus = cus;
+            // substeps/s of ONE resident cloth at 2 (standard), 3 and 4 cloths per CU, relative to the standard variant's: measured
+            // by tools/measure_pick_table.py on the bench workload and written to lean_rates.hpp (its output: profiles/)
+            // r = 2: the EIGHT-WAVE LEAN build (512 threads x 2 particles, window table in LDS) when the flat palette holds, else the
+            // standard variant; r = 3 .. 6: the four-wave LEAN builds with the table streamed from L2 (168 / 128 / 96 / 80 VGPRs; from
+            // five per CU on without the cell-ordered record copy: 22.6 KB of LDS per cloth)
+            const bool lean_able = small_grid && precision == CLOTHHIP_F32;
+            const double rate[5] = {lean_able ? LEAN_RATE_2_PER_CU_8W : 1.0, LEAN_RATE_3_PER_CU, LEAN_RATE_4_PER_CU, LEAN_RATE_5_PER_CU, LEAN_RATE_6_PER_CU};
+            double best = 0.0; int best_r = 2;
+            for (int r = 2; r <= 6; r++) {
+                // (r >= 3: the four-wave LEAN layout, table streamed, must fit r times in the CU's LDS -- 27x27 does not at five per CU)
+                if (r >= 3 && (!lean_able || (long)LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, 0).total * r > 160 * 1024)) continue;
+                const double v = rate[r - 2] / (double)((h->E + r * cus - 1) / (r * cus));
+                if (v > best * 1.02) { best = v; best_r = r; }
+            }
+            h->lean = lean_able;
+            h->lean_r = best_r;
+            // the large grids (one cloth per CU): the LEAN arithmetic frees the registers of the gather entries and takes the rest lengths
+            // off the L2 path, which lets SIXTEEN waves step a cloth at 128 VGPRs (1024 threads x 3 or 4 particles; 50x50: 2.90 M/s
+            // standard 512 x 5 -> 3.05 LEAN 512 x 5 -> 3.26 LEAN 1024 x 3); the standard variant stays as the fallback (per-env rest tables)
+            if (!small_grid && precision == CLOTHHIP_F32) { h->lean = true; h->lean_r = 1; }
+        }
+        if (const char *t = getenv("CLOTHHIP_DEBUG_LEAN")) {      // 0: never; 8 (or 2): the eight-wave build; 3 (or 1) / 4 / 5 / 6: the LEAN build for that many cloths per CU, whatever the batch size
+            const int v = atoi(t);
+            if (v == 0) h->lean = false;
+            else if (small_grid && precision == CLOTHHIP_F32) { h->lean = true; h->lean_r = (v == 8 || v == 2) ? 2 : ((v >= 4 && v <= 6) ? v : 3); }
+        }
+        if (h->lean) {
+            // the arithmetic stencil of the LEAN kernel against the gather table built from the reference's spring list
+            h->lean_stencil_ok = true;
+            for (int i = 0; i < h->P && h->lean_stencil_ok; i++) {
+                const uint32_t vm = lean_valid_mask(i / h->N, i % h->N, h->N);
+                int slot = 0;
+                for (int k = 0; k < HK_SLOTS; k++) {
+                    if (!((vm >> k) & 1u)) continue;
+                    const int off[12] = {-h->N, -1, -h->N - 1, -h->N + 1, -2 * h->N, -2, 1, 2, h->N - 1, h->N, h->N + 1, 2 * h->N};
+                    const uint32_t want = (uint32_t)(i + off[k]) | HK_VALID | (k < HK_SLOTS / 2 ? HK_ASB : 0u) | (lean_bend(k) ? HK_BEND : 0u);
+                    const uint32_t g = gather[(size_t)slot * h->Ppad + i];
+                    const uint32_t have = g & (HK_NBR_MASK | HK_VALID | HK_ASB | HK_BEND);
+                    const int sp = h->wt.spring_at[(g >> HK_POS_SHIFT) & HK_POS_MASK];
+                    const int ty = sp >= 0 ? h->topo.type[sp] : -1;
+                    const int want_ty = lean_bend(k) ? SPRING_BENDING : (lean_shear(k) ? SPRING_SHEARING : SPRING_STRUCTURAL);
+                    if (have != want || ty != want_ty) h->lean_stencil_ok = false;
+                    slot++;
+                }
+                if (slot < HK_SLOTS && h->lean_stencil_ok && (gather[(size_t)slot * h->Ppad + i] & HK_VALID)) h->lean_stencil_ok = false;
+            }
+            if (!h->lean_stencil_ok) h->lean = false;
+        }
+        // the cell-ordered record copy for the collision pre-check is taken only if it does not cost the table its place
+        h->cell_copy = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, h->tab, 1).total <= budget ? 1 : 0;
+        if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) h->cell_copy = h->cell_copy && atoi(t);
+        h->lds_bytes = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, h->tab, h->cell_copy).total;
+        h->lay_std = {h->nt, h->ppt, h->tab, h->rest_reg, h->cell_copy, h->lds_bytes, h->HT, h->ht_bits, 0, 0};
+        // the in-kernel metrics of the episode launches borrow the LDS from the hash table on (the window table in front of it stays
+        // resident). With the table in LDS but no room for the cell-ordered copy that region can be too small (fp64 21, 22, 30-32;
+        // fp32 41-43): the allocation is then padded behind the layout's end, or, if the budget forbids that, the table leaves LDS
+        if (!fit_scratch(h->lay_std, tsz, h->Ppad, h->Spad, h->P, budget) && h->tab == 1) {
+            h->tab = 0; h->rest_reg = false;
+            h->cell_copy = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, 1).total <= budget ? 1 : 0;
+            if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) h->cell_copy = h->cell_copy && atoi(t);
+            h->lay_std = {h->nt, h->ppt, 0, false, h->cell_copy, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, h->cell_copy).total, h->HT, h->ht_bits, 0, 0};
+            fit_scratch(h->lay_std, tsz, h->Ppad, h->Spad, h->P, budget);
+        }
+        h->lds_bytes = h->lay_std.lds_bytes;
+        if (h->lean) {                                   // the lean layout: window table streamed from L2, 33 KB of LDS
+            int cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, 1).total <= (160 * 1024) / std::max(h->lean_r, 3) ? 1 : 0;
+            if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) cc = cc && atoi(t);
+            h->lay_lean = {256, 3, h->lean_r >= 4 ? 3 - h->lean_r : 0, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, cc).total, h->HT, h->ht_bits};   // (r = 3, 4: four waves per cloth)
+            if (h->lean_r == 2 && small_grid) {          // eight waves per cloth, two cloths per CU: the standard variant's LDS budget
+                cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 2, 1).total <= 80 * 1024 ? 1 : 0;
+                if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) cc = cc && atoi(t);
+                h->lay_lean = {512, 2, 2, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 2, cc).total, h->HT, h->ht_bits};
+                if (h->lay_lean.lds_bytes > 80 * 1024 || h->P > 1024) h->lean = false;      // (the table must fit beside a second cloth)
+            }
+            if (h->lean_r == 1) {                        // the whole CU: same LDS budget as the standard variant of these grids
+                cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, 1).total <= 160 * 1024 ? 1 : 0;
+                if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) cc = cc && atoi(t);
+                h->lay_lean = {1024, h->P <= 3072 ? 3 : 4, 3, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, cc).total, h->HT, h->ht_bits};
+                // TWO large-grid cloths per CU (eight waves each, 128 VGPRs) when the batch has more cloths than the device has CUs and it
+                // pays by the measured rates: <= 80 KB of LDS per cloth -- no cell-ordered copy, and a hash table of just enough slots
+                // (not a power of two: > P, so that a free slot always exists, and large enough that the in-kernel metrics' scratch fits)
+                int NSb = 1; while (NSb < h->P) NSb <<= 1;
+                int ht2 = (h->P / 64 + 2) * 64;
+                while (LdsLayout(tsz, h->Ppad, h->Spad, ht2, 0, 0).total - LdsLayout(tsz, h->Ppad, h->Spad, ht2, 0, 0).hkey < metrics_scratch_bytes(NSb, h->Ppad + 8, tsz, true)) ht2 += 64;
+                const int lds2 = LdsLayout(tsz, h->Ppad, h->Spad, ht2, 0, 0).total;
+                const int gens1 = (h->E + h->n_cus - 1) / h->n_cus, gens2 = (h->E + 2 * h->n_cus - 1) / (2 * h->n_cus);
+                const bool two = h->P <= 2560 && lds2 <= 80 * 1024 && LEAN_RATE_LARGE_2_PER_CU / gens2 > 1.02 / gens1;
+                int want2 = two ? 1 : 0;
+                if (const char *t = getenv("CLOTHHIP_DEBUG_LARGE2")) want2 = atoi(t) && h->P <= 2560 && lds2 <= 80 * 1024;
+                if (want2) { h->lay_lean = {512, 5, 4, true, 0, lds2, ht2, 0}; h->lean_r = 2; }
+            }
+            // the in-kernel metrics borrow the region behind the hash table (clothhip_fused_supported): it must hold them here too
+            const int lean_budget = h->lean_r == 1 ? 160 * 1024 : (h->lean_r == 2 ? 80 * 1024 : (160 * 1024) / h->lean_r);
+            if (!fit_scratch(h->lay_lean, tsz, h->Ppad, h->Spad, h->P, lean_budget)) h->lean = false;
+        }
+    }
+}
+
 extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_t device, int32_t precision,
                                clothhip_handle **out) {
     if (!out) return fail(CLOTHHIP_EINVAL, "out is NULL");
@@ -227,18 +373,6 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
     h->topo = build_topology(h->N);
     h->wt = build_windows(h->topo, build_levels(h->topo));
     h->S = h->topo.S; h->Spad = h->wt.n_slots;               // rest-length arrays are kept in window-table slot order
-    // threads per cloth x particles per thread (compile-time variants of the stepper)
-    // P <= 768 (the 25x25 class, two cloths per CU): EIGHT waves per cloth -- 512 threads x 2 particles, compiled for 128 VGPRs: the cell
-    // sweeps have eight ticket takers and the parallel phases two waves per SIMD to hide their LDS latency (+4 % fp32 standard
-    // arithmetic, +9 % fp64, +13 % tier 2 over the four-wave 256 x 3 variants, bit-identical; CLOTHHIP_DEBUG_W8=0 selects those)
-    const bool small_grid = h->P <= 768;
-    const bool w8 = !(getenv("CLOTHHIP_DEBUG_W8") && atoi(getenv("CLOTHHIP_DEBUG_W8")) == 0);
-    if (small_grid) { h->nt = w8 ? 512 : 256; h->ppt = w8 ? 2 : 3; }
-    else if (h->P <= 2560 && !getenv("CLOTHHIP_DEBUG_NT1024")) { h->nt = 512; h->ppt = 5; }
-    else if (h->P <= 3072) { h->nt = 1024; h->ppt = 3; } else { h->nt = 1024; h->ppt = 4; }
-    h->HT = 64; h->ht_bits = 0;
-    while (h->HT <= h->P + h->P / 2) h->HT <<= 1;
-    while ((1 << h->ht_bits) < h->HT) h->ht_bits++;
     if (const char *pmk = getenv("CLOTHHIP_DEBUG_PHASES")) h->phase_mask = atoi(pmk);
     std::vector<uint32_t> gather = build_gather(h->topo, h->wt, h->Ppad);
     std::vector<double> levels = build_grab_levels(params->height, params->thickness);
@@ -290,108 +424,12 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
     HC(hipMemset(h->d_rest, 0, E * h->Spad * h->tsz));
     if (!levels.empty()) HC(hipMemcpy(h->d_levels, levels.data(), levels.size() * 8, hipMemcpyHostToDevice));
     HC(hipMemset(h->d_exec, 0, E * 4));
-    // large dynamic LDS (up to the CU's 160 KiB) for the stepper kernels. The static tables ride in LDS too
-    // as long as TWO cloths still fit per CU (512 cloths = 2 per CU on the 256 CUs of an MI355X).
+    // large dynamic LDS (up to the CU's 160 KiB) for the stepper kernels: which variant, which layout (plan_layouts)
     {
-        const int tsz = (int)h->tsz;
-        // 256-thread variants: two cloths per CU (<= 80 KiB each); the larger ones own the CU (<= 160 KiB)
-        const int budget = small_grid ? 80 * 1024 : 160 * 1024;
-        const int tmax = h->nt <= 512 ? 1 : 0;
-        h->tab = (tmax >= 1 && LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 1, 0).total <= budget) ? 1 : 0;
-        if (const char *t = getenv("CLOTHHIP_DEBUG_TAB_LDS")) h->tab = std::min(h->tab, atoi(t));
-        h->rest_reg = (h->nt == 256 && precision == CLOTHHIP_F32 && h->tab == 1);
-        if (const char *t = getenv("CLOTHHIP_DEBUG_REST_REG")) h->rest_reg = h->rest_reg && atoi(t);
-        // LEAN variant: three or four cloths per CU instead of two, each stepping at 85 % / 72 % of the standard variant's rate
-        // (measured: 31.1 k, 26.4 k, 22.4 k substeps/s per resident cloth). A launch runs its cloths in generations of what is
-        // resident, so the batch size decides: the largest rate_r / ceil(E / (r * CUs)) wins.
-        {
-            hipDeviceProp_t dp;
-            int cus = 256;
-            if (hipGetDeviceProperties(&dp, device) == hipSuccess && dp.multiProcessorCount > 0) cus = dp.multiProcessorCount;
-            h->n_cus = cus;
-            // substeps/s of ONE resident cloth at 2 (standard), 3 and 4 cloths per CU, relative to the standard variant's: measured
-            // by tools/measure_pick_table.py on the bench workload and written to lean_rates.hpp (its output: profiles/)
-            // r = 2: the EIGHT-WAVE LEAN build (512 threads x 2 particles, window table in LDS) when the flat palette holds, else the
-            // standard variant; r = 3 .. 6: the four-wave LEAN builds with the table streamed from L2 (168 / 128 / 96 / 80 VGPRs; from
-            // five per CU on without the cell-ordered record copy: 22.6 KB of LDS per cloth)
-            const bool lean_able = small_grid && precision == CLOTHHIP_F32;
-            const double rate[5] = {lean_able ? LEAN_RATE_2_PER_CU_8W : 1.0, LEAN_RATE_3_PER_CU, LEAN_RATE_4_PER_CU, LEAN_RATE_5_PER_CU, LEAN_RATE_6_PER_CU};
-            double best = 0.0; int best_r = 2;
-            for (int r = 2; r <= 6; r++) {
-                const double v = rate[r - 2] / (double)((h->E + r * cus - 1) / (r * cus));
-                if (v > best * 1.02) { best = v; best_r = r; }
-            }
-            h->lean = lean_able;
-            h->lean_r = best_r;
-            // the large grids (one cloth per CU): the LEAN arithmetic frees the registers of the gather entries and takes the rest lengths
-            // off the L2 path, which lets SIXTEEN waves step a cloth at 128 VGPRs (1024 threads x 3 or 4 particles; 50x50: 2.90 M/s
-            // standard 512 x 5 -> 3.05 LEAN 512 x 5 -> 3.26 LEAN 1024 x 3); the standard variant stays as the fallback (per-env rest tables)
-            if (!small_grid && precision == CLOTHHIP_F32) { h->lean = true; h->lean_r = 1; }
-        }
-        if (const char *t = getenv("CLOTHHIP_DEBUG_LEAN")) {      // 0: never; 8 (or 2): the eight-wave build; 3 (or 1) / 4 / 5 / 6: the LEAN build for that many cloths per CU, whatever the batch size
-            const int v = atoi(t);
-            if (v == 0) h->lean = false;
-            else if (small_grid && precision == CLOTHHIP_F32) { h->lean = true; h->lean_r = (v == 8 || v == 2) ? 2 : ((v >= 4 && v <= 6) ? v : 3); }
-        }
-        if (h->lean) {
-            // the arithmetic stencil of the LEAN kernel against the gather table built from the reference's spring list
-            h->lean_stencil_ok = true;
-            for (int i = 0; i < h->P && h->lean_stencil_ok; i++) {
-                const uint32_t vm = lean_valid_mask(i / h->N, i % h->N, h->N);
-                int slot = 0;
-                for (int k = 0; k < HK_SLOTS; k++) {
-                    if (!((vm >> k) & 1u)) continue;
-                    const int off[12] = {-h->N, -1, -h->N - 1, -h->N + 1, -2 * h->N, -2, 1, 2, h->N - 1, h->N, h->N + 1, 2 * h->N};
-                    const uint32_t want = (uint32_t)(i + off[k]) | HK_VALID | (k < HK_SLOTS / 2 ? HK_ASB : 0u) | (lean_bend(k) ? HK_BEND : 0u);
-                    const uint32_t g = gather[(size_t)slot * h->Ppad + i];
-                    const uint32_t have = g & (HK_NBR_MASK | HK_VALID | HK_ASB | HK_BEND);
-                    const int sp = h->wt.spring_at[(g >> HK_POS_SHIFT) & HK_POS_MASK];
-                    const int ty = sp >= 0 ? h->topo.type[sp] : -1;
-                    const int want_ty = lean_bend(k) ? SPRING_BENDING : (lean_shear(k) ? SPRING_SHEARING : SPRING_STRUCTURAL);
-                    if (have != want || ty != want_ty) h->lean_stencil_ok = false;
-                    slot++;
-                }
-                if (slot < HK_SLOTS && h->lean_stencil_ok && (gather[(size_t)slot * h->Ppad + i] & HK_VALID)) h->lean_stencil_ok = false;
-            }
-            if (!h->lean_stencil_ok) h->lean = false;
-        }
-        // the cell-ordered record copy for the collision pre-check is taken only if it does not cost the table its place
-        h->cell_copy = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, h->tab, 1).total <= budget ? 1 : 0;
-        if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) h->cell_copy = h->cell_copy && atoi(t);
-        h->lds_bytes = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, h->tab, h->cell_copy).total;
-        h->lay_std = {h->nt, h->ppt, h->tab, h->rest_reg, h->cell_copy, h->lds_bytes, h->HT, h->ht_bits};
-        if (h->lean) {                                   // the lean layout: window table streamed from L2, 33 KB of LDS
-            int cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, 1).total <= (160 * 1024) / std::max(h->lean_r, 3) ? 1 : 0;
-            if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) cc = cc && atoi(t);
-            h->lay_lean = {256, 3, h->lean_r >= 4 ? 3 - h->lean_r : 0, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, cc).total, h->HT, h->ht_bits};   // (r = 3, 4: four waves per cloth)
-            if (h->lean_r == 2 && small_grid) {          // eight waves per cloth, two cloths per CU: the standard variant's LDS budget
-                cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 2, 1).total <= 80 * 1024 ? 1 : 0;
-                if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) cc = cc && atoi(t);
-                h->lay_lean = {512, 2, 2, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 2, cc).total, h->HT, h->ht_bits};
-                if (h->lay_lean.lds_bytes > 80 * 1024 || h->P > 1024) h->lean = false;      // (the table must fit beside a second cloth)
-            }
-            if (h->lean_r == 1) {                        // the whole CU: same LDS budget as the standard variant of these grids
-                cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, 1).total <= 160 * 1024 ? 1 : 0;
-                if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) cc = cc && atoi(t);
-                h->lay_lean = {1024, h->P <= 3072 ? 3 : 4, 3, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, cc).total, h->HT, h->ht_bits};
-                // TWO large-grid cloths per CU (eight waves each, 128 VGPRs) when the batch has more cloths than the device has CUs and it
-                // pays by the measured rates: <= 80 KB of LDS per cloth -- no cell-ordered copy, and a hash table of just enough slots
-                // (not a power of two: > P, so that a free slot always exists, and large enough that the in-kernel metrics' scratch fits)
-                int NSb = 1; while (NSb < h->P) NSb <<= 1;
-                int ht2 = (h->P / 64 + 2) * 64;
-                while (LdsLayout(tsz, h->Ppad, h->Spad, ht2, 0, 0).total - LdsLayout(tsz, h->Ppad, h->Spad, ht2, 0, 0).hkey < metrics_scratch_bytes(NSb, h->Ppad + 8, tsz, true)) ht2 += 64;
-                const int lds2 = LdsLayout(tsz, h->Ppad, h->Spad, ht2, 0, 0).total;
-                const int gens1 = (h->E + h->n_cus - 1) / h->n_cus, gens2 = (h->E + 2 * h->n_cus - 1) / (2 * h->n_cus);
-                const bool two = h->P <= 2560 && lds2 <= 80 * 1024 && LEAN_RATE_LARGE_2_PER_CU / gens2 > 1.02 / gens1;
-                int want2 = two ? 1 : 0;
-                if (const char *t = getenv("CLOTHHIP_DEBUG_LARGE2")) want2 = atoi(t) && h->P <= 2560 && lds2 <= 80 * 1024;
-                if (want2) { h->lay_lean = {512, 5, 4, true, 0, lds2, ht2, 0}; h->lean_r = 2; }
-            }
-            // the in-kernel metrics borrow the region behind the episode state (clothhip_fused_supported): it must hold them here too
-            int NS_ = 1; while (NS_ < h->P) NS_ <<= 1;
-            const LdsLayout ll(tsz, h->Ppad, h->Spad, h->lay_lean.HT, 0, h->lay_lean.cell_copy);
-            if (ll.total - ll.hkey < metrics_scratch_bytes(NS_, h->Ppad + 8, tsz, v_hull_idx(h->lay_lean.tab))) h->lean = false;
-        }
+        hipDeviceProp_t dp;
+        int cus = 256;
+        if (hipGetDeviceProperties(&dp, device) == hipSuccess && dp.multiProcessorCount > 0) cus = dp.multiProcessorCount;
+        plan_layouts(h, cus, gather);
         if (h->lds_bytes > 160 * 1024) { free_handle(h); return fail(CLOTHHIP_EINVAL, "n_side %d needs %d B of LDS (> 160 KiB)", h->N, h->lds_bytes); }
         if (h->lean) {                                   // the lean kernels too (which layout runs is decided per launch)
             const clothhip_handle::Layout keep = {h->nt, h->ppt, h->tab, h->rest_reg, h->cell_copy, h->lds_bytes};
@@ -740,6 +778,17 @@ static const void *stepper_fn(const clothhip_handle *h, int fused) {
     return h->precision == CLOTHHIP_F64 ? stepper_fn_t<double, 0>(h) : stepper_fn_t<float, 0>(h);
 }
 
+// resident workgroups per CU of a stepper kernel at the handle's LDS footprint (for clothhip_last_variant): asked once per (kernel,
+// LDS bytes), not on every launch -- the step mode launches once per env step
+static int cached_occupancy(clothhip_handle *h, const void *fn, int nt) {
+    for (auto &c : h->occ_cache) if (c.fn == fn && c.lds == h->lds_bytes) return c.occ;
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, nt, (size_t)h->lds_bytes) != hipSuccess) { (void)hipGetLastError(); occ = 0; }
+    for (auto &c : h->occ_cache) if (c.fn == nullptr) { c = {fn, h->lds_bytes, occ}; return occ; }
+    h->occ_cache[0] = {fn, h->lds_bytes, occ};
+    return occ;
+}
+
 // (the caller has run lean_refresh(h) -- which of the handle's two layouts may run now -- BEFORE recording its start event)
 template <typename T, int FUSED> static void launch_run(clothhip_handle *h, const ClothSchedule *d_sched, const void *d_fz) {
     StepArgs<T> a = make_args<T>(h, d_sched);
@@ -747,8 +796,7 @@ template <typename T, int FUSED> static void launch_run(clothhip_handle *h, cons
 #define X(T_, NT, PPT, TAB, RR)                                                                         \
     if (h->nt == NT && h->ppt == PPT && h->tab == TAB && h->rest_reg == RR) {                           \
         hipLaunchKernelGGL((k_run_schedule<T_, NT, PPT, TAB, RR, FUSED>), dim3(h->E), dim3(NT), h->lds_bytes, h->stream, a); \
-        int occ_ = 0;                                                                                   \
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_, (const void *)k_run_schedule<T_, NT, PPT, TAB, RR, FUSED>, NT, (size_t)h->lds_bytes) != hipSuccess) { (void)hipGetLastError(); occ_ = 0; } \
+        const int occ_ = cached_occupancy(h, (const void *)k_run_schedule<T_, NT, PPT, TAB, RR, FUSED>, NT);    \
         const int32_t v_[10] = {NT, PPT, TAB, RR ? 1 : 0, v_lean(TAB, RR, (int)sizeof(T_)) ? 1 : 0, FUSED, h->lds_bytes, occ_, h->n_cus, sizeof(T_) == 4 ? 1 : 0}; \
         memcpy(h->last_variant, v_, sizeof(v_)); h->have_variant = true;                                \
         return;                                                                                         \
@@ -844,18 +892,47 @@ static int grow(void **p, size_t *cap, size_t need) {
     return 0;
 }
 
+// (of the layout the handle's fields describe NOW: call lean_refresh first -- the LEAN and the standard layout differ in hash-table
+//  size, cell copy and hull-stack format)
 static int fused_scratch(const clothhip_handle *h, int *need_out) {
     int NS = 1; while (NS < h->P) NS <<= 1;
     const int NH = h->Ppad + 8;
     *need_out = metrics_scratch_bytes(NS, NH, (int)h->tsz, v_hull_idx(h->tab));
     const LdsLayout lay((int)h->tsz, h->Ppad, h->Spad, h->HT, h->tab == 2 ? 2 : (v_ldstab(h->tab) ? 1 : 0), h->cell_copy);
-    return lay.total - lay.hkey;
+    return h->lds_bytes - lay.hkey;
 }
 
+// Every layout the handle may run (the standard one always; the LEAN one while its palette holds) was sized in clothhip_create
 extern "C" int clothhip_fused_supported(const clothhip_handle *h) {
     if (!h) return fail(CLOTHHIP_EINVAL, "handle is NULL");
-    int need = 0;
-    return fused_scratch(h, &need) >= need ? 1 : 0;
+    const bool std_ok = h->lay_std.scratch_have >= h->lay_std.scratch_need;
+    const bool lean_ok = !h->lean || h->lay_lean.scratch_have >= h->lay_lean.scratch_need;
+    return std_ok && lean_ok ? 1 : 0;
+}
+
+extern "C" int clothhip_selftest_layout(const ClothParams *p, int32_t precision, int32_t n_envs, int32_t n_cus, int32_t *out, int32_t capacity) {
+    if (int rc = check_params(p)) return rc;
+    if (!out || capacity < 24) return fail(CLOTHHIP_EINVAL, "out needs 24 entries");
+    if (precision != CLOTHHIP_F64 && precision != CLOTHHIP_F32) return fail(CLOTHHIP_EINVAL, "precision must be 0 (f64) or 1 (f32)");
+    if (n_envs < 1 || n_cus < 1) return fail(CLOTHHIP_EINVAL, "n_envs and n_cus must be >= 1");
+    clothhip_handle h;                                       // host fields only: nothing here touches a device
+    h.prm = *p; h.E = n_envs; h.precision = precision;
+    h.N = p->n_side; h.P = h.N * h.N; h.Ppad = (h.P + 63) / 64 * 64;
+    h.tsz = precision == CLOTHHIP_F64 ? 8 : 4;
+    h.topo = build_topology(h.N);
+    h.wt = build_windows(h.topo, build_levels(h.topo));
+    h.S = h.topo.S; h.Spad = h.wt.n_slots;
+    plan_layouts(&h, n_cus, build_gather(h.topo, h.wt, h.Ppad));
+    auto put = [&](int o, const clothhip_handle::Layout &L) {
+        out[o] = L.nt; out[o + 1] = L.ppt; out[o + 2] = L.tab; out[o + 3] = L.rest_reg ? 1 : 0; out[o + 4] = L.cell_copy;
+        out[o + 5] = L.lds_bytes; out[o + 6] = L.HT; out[o + 7] = L.scratch_have; out[o + 8] = L.scratch_need;
+        out[o + 9] = L.scratch_have >= L.scratch_need ? 1 : 0;
+    };
+    put(0, h.lay_std);
+    out[10] = h.lean ? 1 : 0; out[11] = h.lean_r;
+    put(12, h.lay_lean);
+    out[22] = clothhip_fused_supported(&h); out[23] = h.lds_bytes <= 160 * 1024 ? 1 : 0;
+    return 0;
 }
 
 extern "C" int clothhip_run_actions_begin(clothhip_handle *h, const ClothEpisodeParams *ep, int32_t T_, int32_t policy,
@@ -888,11 +965,14 @@ extern "C" int clothhip_run_actions_begin(clothhip_handle *h, const ClothEpisode
     if (!(ep->reduce_factor > 0) || ep->max_actions < 1) return fail(CLOTHHIP_EINVAL, "bad episode parameters");
     int NS = 1; while (NS < h->P) NS <<= 1;
     const int NH = h->Ppad + 8;
+    HIPCHECK(hipSetDevice(h->device));
+    // which of the handle's two layouts runs now (may synchronise and read the rest table back: long before the timed events) -- the
+    // scratch check below is against THAT layout, not the previous launch's
+    if (int rc = lean_refresh(h)) return rc;
     int need = 0;
     const int have = fused_scratch(h, &need);
     if (have < need)
         return fail(CLOTHHIP_ESTATE, "n_side %d: the in-kernel metrics need %d B of LDS scratch, this variant has %d", h->N, need, have);
-    HIPCHECK(hipSetDevice(h->device));
     HIPCHECK(hipStreamSynchronize(h->stream));
     const size_t E = h->E, nrec = (size_t)T_ * E;
     if (!h->d_fz) {
@@ -947,7 +1027,6 @@ extern "C" int clothhip_run_actions_begin(clothhip_handle *h, const ClothEpisode
                            rng_states != nullptr, rng_tier, domrand_words, NS, NH);
     HIPCHECK(hipMemcpyAsync(h->d_fz, fzbuf, 1024, hipMemcpyHostToDevice, h->stream));
     HIPCHECK(hipStreamSynchronize(h->stream));          // fzbuf is on this stack frame
-    if (int rc = lean_refresh(h)) return rc;
     HIPCHECK(hipEventRecord(h->ev0, h->stream));
     if (tier2 || policy == CLOTHHIP_POLICY_HIGHEST_POINT) {   // the variant that also carries the tier-2 reset code and the cold policies
         if (h->precision == CLOTHHIP_F64) launch_run<double, 2>(h, h->d_sched, h->d_fz);

@@ -110,17 +110,21 @@ def _nonce(path, world):
     return hashlib.sha256(("%s|%s|%d|%d" % (base, path, int(world), gen)).encode()).digest()[:16]
 
 
-def exchange_unique_id(rank, world, path=None, timeout_s=300.0):
+def exchange_unique_id(rank, world, path=None, timeout_s=300.0, make_id=None):
     """rank 0 creates the id and publishes it atomically (exclusive temp file + rename) behind a header of
     (magic, nonce, world); the others poll for a file that carries THEIR nonce -- a file left by a crashed run or by the previous
-    communicator on the same path is ignored (and replaced by rank 0)."""
-    L = load()
+    communicator on the same path is ignored (and replaced by rank 0).
+    `make_id(uid)`: fills the ncclUniqueId structure on rank 0 (default: ncclGetUniqueId, which needs a GPU); the CPU test suite
+    passes a stand-in so that BOTH ranks' real code paths -- structure, header, file protocol, polling -- run in two processes."""
     path = path or rendezvous_path()
     nonce = _nonce(path, world)
     head = _MAGIC + nonce + int(world).to_bytes(4, "little")
     uid = _UniqueId()
     if rank == 0:
-        _check(L.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        if make_id is None:
+            _check(load().ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        else:
+            make_id(uid)
         try:
             os.remove(path)                                   # whatever an earlier run left there
         except OSError:

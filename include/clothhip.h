@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CLOTHHIP_ABI_VERSION 5
+#define CLOTHHIP_ABI_VERSION 6
 
 enum {
     CLOTHHIP_OK = 0,
@@ -387,6 +387,13 @@ int clothhip_debug_stats(clothhip_handle *h, int32_t *stats);
  * when that is too small (n_slots is set either way). Any array may be NULL. */
 int clothhip_selftest_windows(const ClothParams *params, int32_t *n_windows, int32_t *n_slots, int32_t *reach_shift,
                               int32_t *spring_at, uint32_t *ent, uint64_t *dep, int32_t capacity);
+
+/* Host-side view of the variant / LDS-layout decisions clothhip_create takes for (params, precision, n_envs) on a device of n_cus
+ * compute units -- no device needed (ABI 6). out[24]: [0..9] the standard layout {threads per cloth, particles per thread, table mode,
+ * rest lengths in registers, cell-ordered copy, LDS bytes, hash-table slots, LDS the in-kernel metrics of clothhip_run_actions can
+ * borrow, LDS they need, 1 if that fits}; [10] 1 if a LEAN layout exists beside it, [11] the cloths per CU it is built for;
+ * [12..21] the LEAN layout, same fields; [22] what clothhip_fused_supported would return; [23] 1 if the layout fits the CU's LDS. */
+int clothhip_selftest_layout(const ClothParams *params, int32_t precision, int32_t n_envs, int32_t n_cus, int32_t *out, int32_t capacity);
 
 /* Host-side self-test of csrc/cloth_rng.hpp (the same functions the kernel runs): n draws of kind 0 next32, 1 rand(),
  * 2 uniform(a, b), 3 randint((uint32)a), 4 _randval_minabs(a, b, minabs = c) into out[n]; kind 5 skips (uint64)a words.

@@ -183,3 +183,52 @@ def test_rendezvous_reader_takes_only_a_regular_file_of_this_user(tmp_path, monk
     os.chmod(d, 0o755)
     with pytest.raises(rccl.RcclError):                      # somebody else could write there: refused
         rccl.rendezvous_path()
+
+
+# a stand-in for ncclGetUniqueId's output with what made round 4's bug: binary, NUL bytes early on (a real id starts with the
+# little-endian magic / port words of a socket address: b"\x02\x00..." )
+_FAKE_ID = bytes([2, 0, 0xb0, 0x9d, 0, 0, 0, 0, 10, 0, 0, 7]) + bytes((37 * i + 11) & 0xFF for i in range(116))
+
+
+def _uid_worker(rank, world, path, nonce, q, timeout_s):
+    sys.path.insert(0, ROOT)
+    os.environ["CLOTHHIP_RDZV_NONCE"] = nonce
+    import ctypes as C
+    from gym_cloth_amd import rccl
+    try:
+        uid, p = rccl.exchange_unique_id(rank, world, path, timeout_s=timeout_s,
+                                         make_id=lambda u: C.memmove(C.byref(u), _FAKE_ID, rccl.NCCL_UNIQUE_ID_BYTES))
+        q.put((rank, C.string_at(C.byref(uid), rccl.NCCL_UNIQUE_ID_BYTES), p))
+    except rccl.RcclError as exc:
+        q.put((rank, None, str(exc)))
+
+
+def test_unique_id_rendezvous_two_processes(tmp_path):
+    """Rank 0's and rank 1's REAL exchange_unique_id code paths in two processes against one rendezvous file (the id itself is a
+    stand-in: ncclGetUniqueId needs a GPU): rank 1 starts first and polls; a stale file of another communicator lies in the way and is
+    ignored; the id arrives whole -- 128 bytes, NULs and all (round 4 found rank 0 writing it cut at its first NUL, so that no world > 1
+    could ever have come up). A rank whose rank 0 never shows up gives up with an error after its timeout instead of hanging."""
+    assert len(_FAKE_ID) == 128 and _FAKE_ID.index(0) == 1
+    path = str(tmp_path / "pair.id")
+    with open(path, "wb") as fh:                              # left by some earlier communicator: other nonce, full length
+        fh.write(b"CLTHRCCL" + bytes(16) + (2).to_bytes(4, "little") + bytes(128))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p1 = ctx.Process(target=_uid_worker, args=(1, 2, path, "nonce-a", q, 60.0))
+    p1.start()
+    import time
+    time.sleep(0.5)                                           # rank 1 is polling the stale file by now
+    p0 = ctx.Process(target=_uid_worker, args=(0, 2, path, "nonce-a", q, 60.0))
+    p0.start()
+    got = dict((r, (raw, info)) for r, raw, info in (q.get(timeout=120) for _ in range(2)))
+    for p in (p0, p1):
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert got[0][0] == _FAKE_ID and got[1][0] == _FAKE_ID, (got[0][0], got[1][0])
+    assert os.path.getsize(path) == 8 + 16 + 4 + 128
+    # nobody publishes for this nonce: the poller must time out, with an error that names the path
+    p2 = ctx.Process(target=_uid_worker, args=(1, 2, path, "nonce-b", q, 1.0))
+    p2.start()
+    r, raw, info = q.get(timeout=60)
+    p2.join(timeout=30)
+    assert r == 1 and raw is None and "no RCCL unique id" in info and path in info

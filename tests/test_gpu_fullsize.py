@@ -1,0 +1,132 @@
+"""Full-size parity, inside the driver-run suite: the very handles bench.py times -- 512 x 25x25 tier 1 (BASELINE configs[2]), 512 x
+25x25 tier 2 (configs[3]'s per-GPU shape), 1 024 x 50x50 (configs[4]) and the 1 536 / 2 048-cloth companions -- are created WITHOUT
+any CLOTHHIP_DEBUG_* override, so that clothhip_create's own batch-size pick decides the stepper variant, and
+
+  * fp32 (what the bench's `value` runs): clothhip_last_variant must name the variant the bench record names (config.variant), and an
+    episode launch with in-kernel resets over the whole batch -- several generations of workgroups where the batch exceeds what is
+    resident -- must equal the STANDARD fp32 variant's launch bit for bit (records, observations, particles); the standard variant
+    is pinned to the reference by tests/test_gpu_parity.py;
+  * fp64 (the reference's arithmetic): one whole bench step of the full batch through the episode launch, then a seeded random sample
+    of 64 envs replayed by the CPU oracle from their pre-step states: positions, previous positions and update() counts bit for bit.
+
+Reference loop matched: ClothEnv.step (cloth_env.py:472-515) over Cloth.update (cloth.pyx:169-214)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+DEBUG_VARS = ("CLOTHHIP_DEBUG_LEAN", "CLOTHHIP_DEBUG_W8", "CLOTHHIP_DEBUG_LARGE2", "CLOTHHIP_DEBUG_TAB_LDS", "CLOTHHIP_DEBUG_CELL_COPY",
+              "CLOTHHIP_DEBUG_REST_REG", "CLOTHHIP_DEBUG_NT1024", "CLOTHHIP_DEBUG_PHASES")
+
+
+def _bench_env(E, n_side, tier, prec):
+    import bench
+    from gym_cloth_amd.envs import ClothVecEnv
+    cfg = bench.bench_cfg(n_side, 0.02 if n_side <= 25 else 0.0095, tier)
+    env = ClothVecEnv(cfg, n_envs=E, precision=prec, consume_domrand_draws=False)
+    for e in range(E):
+        env.np_randoms[e] = np.random.RandomState(1000 + e)          # bench.py's reset streams
+    env.reset()
+    return cfg, env
+
+
+def _bench_actions(E, T):
+    return np.ascontiguousarray(np.stack([np.random.RandomState(2000 + e).uniform(-1, 1, size=(T, 4)) for e in range(E)], axis=1))
+
+
+# (E, grid, tier) -> what clothhip_create must pick by itself for the fp32 handle on a 256-CU device: threads per cloth, particles per
+# thread, table mode, LEAN arithmetic, cloths per CU at least -- the variants BENCH_r04.json / profiles/r0x_bench.json name
+PICKS = [
+    (512, 25, "tier1", dict(threads=512, particles_per_thread=2, table_mode=2, lean=True, cloths_per_cu=2)),     # the headline
+    (512, 25, "tier2", dict(threads=512, particles_per_thread=2, table_mode=1, lean=False, cloths_per_cu=2)),    # per-env rest tables
+    (1024, 50, "tier1", dict(threads=512, particles_per_thread=5, table_mode=4, lean=True, cloths_per_cu=2)),    # configs[4], two per CU
+    (1536, 25, "tier1", dict(threads=256, particles_per_thread=3, table_mode=-3, lean=True, cloths_per_cu=6)),   # six per CU, one generation
+    (2048, 25, "tier1", dict(threads=256, particles_per_thread=3, table_mode=-1, lean=True, cloths_per_cu=4)),   # four per CU, two generations
+]
+
+
+@pytest.mark.parametrize("E,n_side,tier,want", PICKS, ids=["512x25-tier1", "512x25-tier2", "1024x50", "1536x25", "2048x25"])
+def test_picked_f32_variant_is_the_benched_one_and_equals_the_standard_variant(E, n_side, tier, want, monkeypatch):
+    for v in DEBUG_VARS:
+        monkeypatch.delenv(v, raising=False)
+    T = 1 if n_side == 50 else 2
+    acts = _bench_actions(E, T)
+    runs = []
+    for standard in (False, True):
+        if standard:                                                 # the standard arithmetic at its own layout (one large-grid cloth per CU)
+            monkeypatch.setenv("CLOTHHIP_DEBUG_LEAN", "0")
+            monkeypatch.setenv("CLOTHHIP_DEBUG_LARGE2", "0")
+        cfg, env = _bench_env(E, n_side, tier, "f32")
+        out = env.step_many(acts, auto_reset=True)                   # actions, terminal tests and episode resets in the kernel
+        var = env.batch.last_variant()
+        runs.append((var, out["rew"].copy(), out["executed"].copy(), out["done"].copy(), out["actual_coverage"].copy(), out["obs"].copy(),
+                     out["reset_before"].copy(), [x.copy() for x in env.batch.get_state()]))
+        env.close()
+    (vp, *a), (vs, *b) = runs
+    if vp["n_cus"] == 256:                                           # (the pick depends on the device's CU count: MI355X)
+        for k, v in want.items():
+            assert (vp[k] >= v) if k == "cloths_per_cu" else (vp[k] == v), (k, vp)
+        assert vp["fused"] == (2 if tier == "tier2" else 1) and vp["precision"] == "f32", vp
+        generations = -(-E // (vp["cloths_per_cu"] * vp["n_cus"]))
+        assert generations == (2 if E in (2048, 1024) else 1), (generations, vp)
+    assert not vs["lean"], vs
+    assert a[1].sum() > 200 * E                                      # the launch did real work: > 200 update() calls per env on average
+    for x, y in zip(a[:6], b[:6]):
+        assert np.array_equal(x, y, equal_nan=True)
+    for x, y in zip(a[6], b[6]):
+        assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("E,n_side,tier", [(512, 25, "tier1"), (512, 25, "tier2"), (1024, 50, "tier1")],
+                         ids=["512x25-tier1", "512x25-tier2", "1024x50"])
+def test_full_batch_bench_step_f64_sample_matches_oracle(E, n_side, tier, oracle_lib, monkeypatch):
+    for v in DEBUG_VARS:
+        monkeypatch.delenv(v, raising=False)
+    from gym_cloth_amd.envs import decode_actions
+    cfg, env = _bench_env(E, n_side, tier, "f64")
+    ev, c = cfg["env"], cfg["cloth"]
+    ocfg = {"n_side": n_side, "width": c["width"], "height": c["height"], "density": c["density"], "ks": c["ks"],
+            "damping": c["damping"], "thickness": c["thickness"], "plane_friction": c["plane_friction"],
+            "tear_thresh": c["tear_thresh"], "frames_per_sec": cfg["frames_per_sec"], "simulation_steps": cfg["simulation_steps"],
+            "gravity": -9.8, "minimum_z": 0.0, "grip_radius": ev["grip_radius"]}
+    acts = _bench_actions(E, 1)
+    pos0, prev0, pin0 = env.batch.get_state()
+    tear0 = np.array(env.batch.tear).copy()
+    rest = env.batch.get_rest() if tier == "tier2" else None
+    if env.batch.fused_supported:
+        out = env.step_many(acts, auto_reset=False)                  # ONE bench step of the whole batch, episode-launch kernel
+        ex = out["executed"][0]
+        assert out["ran"][0].all()
+    else:                                                            # fp64 50x50: the in-kernel metrics' fp64 sort buffers do not fit in
+        env.step(acts[0], auto_reset=False)                          # LDS -- bench.py runs this configuration in its step mode too
+        ex = env.last_executed.copy()
+    var = env.batch.last_variant()
+    assert var["precision"] == "f64" and not var["lean"] and (var["fused"] >= 1) == bool(env.batch.fused_supported), var
+    if var["n_cus"] == 256:
+        assert var["threads"] == 512 and var["particles_per_thread"] == (2 if n_side == 25 else 5), var
+    pos1, prev1, _ = env.batch.get_state()
+    assert ex.sum() > 300 * E
+    d = decode_actions(acts[0], [-1.] * 4, [1.] * 4, True, True, ev["reduce_factor"], ev["iters_up"], ev["iters_up_rest"],
+                       ev["iters_pull_max"], ev["iters_grip_rest"], ev["iters_rest"])
+    sample = np.sort(np.random.RandomState(20251004 + E + n_side).choice(E, 64, replace=False))
+    cloths, sched, delta = [], np.zeros((64, 5), dtype=np.int32), np.zeros((64, 3))
+    for k, e in enumerate(sample):
+        oc = oracle_lib.OracleCloth(ocfg)
+        oc.set_state(pos0[e], prev0[e], pin0[e], None if rest is None else rest[e])
+        oc.have_tear = bool(tear0[e])
+        ng = oc.grab_top(float(d["x"][e]), float(d["y"][e]))
+        sched[k] = d["bounds"][e] if ng > 0 else 0
+        delta[k] = (0.0025, d["x_dir_r"][e], d["y_dir_r"][e])
+        cloths.append(oc)
+    threads = max(1, min(len(os.sched_getaffinity(0)), oracle_lib.lib().oracle_max_threads(), 64))
+    exo = oracle_lib.batch_run_schedule(cloths, sched, delta, True, threads)
+    busy = 0
+    for k, e in enumerate(sample):
+        op, oq, _ = cloths[k].get_state()
+        assert exo[k] == ex[e], (e, int(exo[k]), int(ex[e]))
+        assert np.array_equal(pos1[e], op) and np.array_equal(prev1[e], oq), (e, float(np.abs(pos1[e] - op).max()))
+        busy += int(ex[e] > 0)
+    assert busy >= 20                                                # a third of the random pick points hit the cloth
+    env.close()

@@ -41,8 +41,60 @@ def test_abi_exports_every_declared_symbol(lib):
     assert declared == bound, (declared ^ bound)
     for name in declared:
         assert getattr(L, name) is not None
-    assert L.clothhip_abi_version() == lib.ABI_VERSION == 5
+    assert L.clothhip_abi_version() == lib.ABI_VERSION == 6
     assert C.sizeof(lib.ClothSchedule) == 64 and C.sizeof(lib.ClothParams) == 104
+
+
+def _layout(lib, n_side, precision, n_envs=512, n_cus=256, thickness=0.02):
+    L = lib.load()
+    p = lib.params_from_cfg({"cloth": {"num_width_points": n_side, "num_height_points": n_side, "width": 1, "height": 1,
+                                       "density": 200.0, "ks": 1e4, "damping": 2.0, "thickness": thickness, "plane_friction": 1.0,
+                                       "tear_thresh": 2.0},
+                             "frames_per_sec": 30, "simulation_steps": 30, "env": {"grip_radius": 0.003}})
+    out = np.zeros(24, dtype=np.int32)
+    lib.check(L.clothhip_selftest_layout(C.byref(p), 0 if precision == "f64" else 1, n_envs, n_cus, lib.i32p(out), 24))
+    keys = ("threads", "ppt", "tab", "rest_reg", "cell_copy", "lds_bytes", "HT", "scratch_have", "scratch_need", "fused_ok")
+    return {"std": dict(zip(keys, out[0:10].tolist())), "lean": bool(out[10]), "lean_r": int(out[11]),
+            "lean_lay": dict(zip(keys, out[12:22].tolist())), "fused_supported": bool(out[22]), "fits": bool(out[23])}
+
+
+def test_layout_sweep_every_grid_keeps_the_episode_launches(lib):
+    """The variant / LDS-layout plan of clothhip_create (pure host logic, clothhip_selftest_layout) over every grid size and both
+    precisions: the layout fits the CU, the LDS the in-kernel metrics borrow is large enough wherever the budget allows it at all --
+    round 4 lost the episode launches for fp64 21, 22, 30-32 and fp32 41-43 when the scratch moved behind the window table (ADVICE
+    r4) -- , two cloths of the 25x25 class stay co-resident, and no residency is picked whose layout does not fit that often."""
+    lost = []
+    for prec in ("f32", "f64"):
+        for n in range(3, 65):
+            lay = _layout(lib, n, prec, thickness=0.02 if n <= 27 else 0.0095)
+            if prec == "f64" and n >= 53:                     # fp64 state + tables beyond the CU's 160 KiB: clothhip_create refuses these
+                assert not lay["fits"]
+                continue
+            assert lay["fits"], (prec, n, lay)
+            s_ = lay["std"]
+            budget = 80 * 1024 if n * n <= 768 else 160 * 1024
+            assert s_["lds_bytes"] <= budget, (prec, n, s_)
+            assert s_["fused_ok"] == (s_["scratch_have"] >= s_["scratch_need"])
+            if lay["lean"]:
+                assert lay["lean_lay"]["fused_ok"], (prec, n, lay)
+                r = lay["lean_r"]
+                assert lay["lean_lay"]["lds_bytes"] * max(r, 1) <= 160 * 1024, (prec, n, lay)
+            if not lay["fused_supported"]:
+                lost.append((prec, n))
+    # the episode launches run on everything up to 63x63 in fp32 and 45x45 in fp64 (beyond: the metrics' sort buffers do not fit)
+    assert lost == [("f32", 64)] + [("f64", n) for n in range(46, 53)], lost
+    for prec, n in (("f64", 21), ("f64", 22), ("f64", 30), ("f64", 31), ("f64", 32), ("f32", 41), ("f32", 42), ("f32", 43)):
+        assert _layout(lib, n, prec, thickness=0.0095 if n > 27 else 0.02)["fused_supported"], (prec, n)
+    # the headline layouts themselves: eight-wave LEAN at two per CU for 512 cloths, four-wave LEAN builds for the larger batches
+    h = _layout(lib, 25, "f32", 512)
+    assert h["lean"] and h["lean_r"] == 2 and h["lean_lay"]["threads"] == 512 and h["lean_lay"]["tab"] == 2 and h["lean_lay"]["lds_bytes"] <= 80 * 1024
+    assert _layout(lib, 25, "f32", 1536)["lean_r"] == 6 and _layout(lib, 25, "f32", 2048)["lean_r"] == 4
+    big = _layout(lib, 50, "f32", 1024, thickness=0.0095)
+    assert big["lean"] and big["lean_lay"]["threads"] == 512 and big["lean_lay"]["tab"] == 4 and big["lean_lay"]["lds_bytes"] <= 80 * 1024
+    # 27x27: the five- and six-per-CU layouts do not fit five / six times (ADVICE r4): the pick must not count on them
+    for E in (1280, 1536, 3072):
+        l27 = _layout(lib, 27, "f32", E)
+        assert l27["lean_lay"]["lds_bytes"] * l27["lean_r"] <= 160 * 1024, (E, l27)
 
 
 def test_no_device_fails_loudly(lib):

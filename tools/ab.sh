@@ -9,7 +9,7 @@ for r in $(seq 1 $REPS); do
     echo "$lib run $r: $(echo "$out" | python3 -c 'import sys,json
 try:
     d=json.loads(sys.stdin.read()); r=d["roofline"]
-    print("value %.3f M/s  kernel-only %.3f M/s  frac %.4f  steps_eq %.1f  act_only %s" % (d["value"]/1e6, r["substeps_per_launch"]/r["kernel_ms_avg"]/1e3, r["frac"], d["config"]["steps_equivalent"], d["config"].get("action_only_substeps_per_s")))
+    print("value (actions only) %.3f M/s  blended %.3f M/s  blended kernel-only %.3f M/s  frac %.4f  steps_eq %.1f" % (d["value"]/1e6, d["config"]["blended_substeps_per_s"]/1e6, r["substeps_per_launch"]/r["kernel_ms_avg"]/1e3, r["frac"], d["config"]["steps_equivalent"]))
 except Exception as e:
     print("FAILED", e)')"
   done

@@ -9,11 +9,11 @@ python3 - $out/bench.json <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
 c = d["config"]
-print("HEAD value %.3f M  ms/step %.2f  frac %.4f  steps_eq %.2f  act_only %s  variant %s" % (d["value"] / 1e6, d["ms_per_step"], d["roofline"]["frac"], c["steps_equivalent"], c.get("action_only_substeps_per_s"), c.get("variant")))
+print("HEAD value (actions only) %.3f M  blended %.3f M  ms/step %.2f  frac %.4f  steps_eq %.2f  variant %s" % (d["value"] / 1e6, c.get("blended_substeps_per_s", 0) / 1e6, d["ms_per_step"], d["roofline"]["frac"], c["steps_equivalent"], c.get("variant")))
 print("  calibration", c.get("slice_calibration"), "traffic", d["roofline"]["traffic"])
 print("  cpu", d.get("cpu_baseline"))
 for r in c.get("extra", []):
     rc = r.get("config") or {}
-    print("  %-62s %s  steps_eq %s  wall %.1f s  act_only %s  %s %s" % (r.get("label", "")[:62], ("%.3f M" % (r["value"] / 1e6)) if "value" in r and r.get("unit", "cloth-substeps/s") == "cloth-substeps/s" else r.get("value"),
-          rc.get("steps_equivalent"), r.get("wall_s", 0), rc.get("action_only_substeps_per_s"), rc.get("variant", ""), r.get("error", "")))
+    print("  %-62s %s  blended %s  steps_eq %s  wall %.1f s  %s %s" % (r.get("label", "")[:62], ("%.3f M" % (r["value"] / 1e6)) if "value" in r and r.get("unit", "cloth-substeps/s") == "cloth-substeps/s" else r.get("value"),
+          ("%.3f M" % (rc["blended_substeps_per_s"] / 1e6)) if rc.get("blended_substeps_per_s") else "-", rc.get("steps_equivalent"), r.get("wall_s", 0), rc.get("variant", ""), r.get("error", "")))
 PY
