@@ -144,8 +144,21 @@ def load_traffic(mode, E, n_side, precision, init, substeps_per_launch, b_alg=No
 
 
 def run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, rank, world, local_rank, thickness=None,
-                 want_cpu=False, step_ms=170.0, slots=0, max_resets=0, allow_tcp_fallback=False):
-    """One bench configuration on this rank's GPU; returns the result record (rank 0) or None."""
+                 want_cpu=False, step_ms=170.0, slots=0, max_resets=0, allow_tcp_fallback=False, relaxed=False):
+    """One bench configuration on this rank's GPU; returns the result record (rank 0) or None.
+    relaxed=True: the relaxed-order companion kernel (self-collision in Jacobi order, strain limit in coloured order: NOT the
+    reference's trajectories, no parity claim) -- what the exact order costs, as a measured figure. Never `value`."""
+    if relaxed:
+        os.environ["CLOTHHIP_RELAXED_ORDER"] = "1"           # read by clothhip_create: this handle's episode launches run the companion kernel
+    try:
+        return _run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, rank, world, local_rank, thickness, want_cpu,
+                             step_ms, slots, max_resets, allow_tcp_fallback, relaxed)
+    finally:
+        os.environ.pop("CLOTHHIP_RELAXED_ORDER", None)
+
+
+def _run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, rank, world, local_rank, thickness, want_cpu,
+                  step_ms, slots, max_resets, allow_tcp_fallback, relaxed):
     from gym_cloth_amd.dist import LocalTransport, RcclTransport, SocketTransport, StepExchange
     from gym_cloth_amd.envs import ClothVecEnv
     thickness = thickness if thickness is not None else (0.02 if n_side <= 25 else 0.0095)
@@ -343,7 +356,10 @@ def run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, rank
                                 "(value: the actions' substeps over the actions' share of the time; resets excluded, SURVEY 8d)"
                                 % (stat["launches"], slice_ms))
                                if mode == "fused" else "step: one launch sequence per step, clock stopped around host-driven resets",
-                       "envs_per_gpu": E, "n_side": n_side, "init": init, "exact_order": True, "transport": transport_name,
+                       "envs_per_gpu": E, "n_side": n_side, "init": init, "exact_order": not relaxed,
+                       "parity": "none (relaxed order: Jacobi self-collision, coloured strain limit -- not the reference's trajectories)" if relaxed
+                                 else "exact order (fp64 bit-exact, fp32 to the stated tolerances: tests/)",
+                       "transport": transport_name,
                        "rccl_nranks": rccl_nranks,                                      # ncclCommCount of the communicator that ran (None: no RCCL)
                        "variant": variant["name"], "resident_cloths": n_conc,          # the kernel the last launch ran (clothhip_last_variant)
                        "slice_calibration": calib,                                      # fused: how the time slices were sized, in this run
@@ -623,6 +639,11 @@ def main():
         companion("same workload, the other execution mode", n_side=args.n_side, E=args.envs, precision=args.precision,
                   init=args.init, mode="step" if args.mode == "fused" else "fused", steps=10, warmup=5, fuse_max=10,
                   step_ms=args.step_ms, **k5)
+        if args.precision == "f32" and args.n_side == 25 and args.envs <= 512 and args.init != "tier2" and args.mode == "fused":
+            companion("RELAXED ORDER, no parity (SURVEY 7-H4): same workload with self-collision in Jacobi order and the strain limit in "
+                      "coloured order -- what the reference's exact order costs; never `value`",
+                      n_side=args.n_side, E=args.envs, precision="f32", init=args.init, mode="fused", steps=10, warmup=5, fuse_max=10,
+                      step_ms=0.5 * args.step_ms, relaxed=True, **k5)
         if args.init != "tier2":
             companion("BASELINE configs[3] shape: tier-2 start and tier-2 episode resets (per-env rest tables), 512 cloths per GPU",
                       n_side=25, E=512, precision=args.precision, init="tier2", mode=args.mode, steps=10, warmup=5, fuse_max=10,
@@ -668,6 +689,12 @@ def main():
             out["cpu_baseline"] = "skipped (world > 1: the CPU port is timed by the 1-GPU run only)"
         if extra:
             out["config"]["extra"] = extra
+            rlx = next((r for r in extra if r.get("config", {}).get("exact_order") is False and "value" in r), None)
+            if rlx:
+                out["relaxed_order"] = {"value": rlx["value"], "frac": rlx["roofline"]["frac"], "exact_order": False, "parity": "none",
+                                        "blended_substeps_per_s": rlx["config"]["blended_substeps_per_s"],
+                                        "note": "companion measurement only (config.extra has the full record): the same workload without the "
+                                                "reference's Gauss-Seidel orders; its trajectories are NOT the reference's"}
             f64 = next((r for r in extra if r.get("dtype") == "f64" and "value" in r), None)
             if f64:
                 out["f64"] = {"value": f64["value"], "ms_per_step": f64["ms_per_step"], "frac": f64["roofline"]["frac"],

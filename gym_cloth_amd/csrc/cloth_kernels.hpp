@@ -325,7 +325,7 @@ struct LdsLayout {
         hco = take(HT * 4);          // (fill cursor << 16) | member count
         memb = take(Ppad * 2);
         slot = take(Ppad * 2);
-        misc = take(256);            // flags and scan scratch (32 ints)
+        misc = take(256);            // flags and scan scratch (64 ints)
         olist = take(2 * Ppad);       // u16 hash slots: occupied cells from the front, cells with a seed from the back
         alist = olist;                //   (an active cell has >= 2 members, so #occupied + #active <= P)
         cpos = take(cp ? 4 * (Ppad + 32) * tsz : 0);   // particle records in cell (CSR) order for the pre-check; the
@@ -539,6 +539,121 @@ __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(so2_)::"memory");
     tph[10] += so1_ - so0_; tph[11] += so2_ - so1_;
 #endif
+    return tear;
+}
+
+// The one-wave sweep again, shaped for how a LONE wave issues (round 5; tools/micro/lone_wave_issue.hip, MI355X): 4.5 cycles per
+// instruction whatever its kind, but ~40 cycles for a branch on a value a vector instruction has just produced (v_cmp -> vcc / SGPR
+// -> s_cbranch) and ~22 for any taken branch -- strain_sweep's quiet window (~75 instructions) runs through five taken branches and
+// two such dependencies, ~550 cycles of which its arithmetic is 60. Here a QUIET window is straight-line code with ONE conditional
+// branch (not taken) and the loop's back-edge every second window:
+//   * two register sets (the walk is unrolled by two, the sets swap roles by name: no queue moves): entry {ab, rest, dep}, decoded
+//     addresses, the two particle records;
+//   * per window: decode the NEXT window's entry and issue its two 16-byte particle reads (speculative: good unless this window
+//     corrects something, then they are read again), evaluate THIS window against t11 = rest * 1.1 -- no look at the pins: a
+//     both-pinned spring (skipped by the reference, :268) can only make the window take the exact path below for nothing --, branch,
+//     prefetch the entry of the window after next into the set this window has just released;
+//   * everything a correction needs -- pins and weights, the dependency word, the exact limit with both-pinned springs sorted out,
+//     the reach, the pass loop of strain_sweep (same rule, same arithmetic) -- sits behind that one branch.
+// Same walk, same passes, same results as strain_sweep (tear_thresh >= 1.1 only: the caller keeps strain_sweep for the other case).
+template <typename T, bool LDS_TAB, bool STATS>
+__device__ __forceinline__ int strain_sweep_lean(Pt<T> *cur, const WEnt<T> *wt, const uint32_t *g_ent, const T *g_rest,
+                                                 const unsigned long long *g_dep, int w0, int w_end, int rshift, const DevConsts<T> &k,
+                                                 int lane, int &st_windows, int &st_passes, int &st_commits) {
+    static_assert(WT_PAD_WINDOWS >= 3, "the entry stream reads two windows ahead, the particle reads one");
+    int tear = 0;
+    T c11 = k.c11, tth = k.tear_thresh;              // spring-test constants pinned in VGPRs
+    asm volatile("" : "+v"(c11), "+v"(tth));
+    const T INF_ = sizeof(T) == 4 ? (T)__builtin_huge_valf() : (T)__builtin_huge_val();
+    struct __attribute__((aligned(16))) P3 { T x, y, z; };
+    struct Set { uint32_t ab; T rest; unsigned long long dep; int a, b; Pt<T> A, B; };
+    auto load = [&](int wi, Set &s) {
+        const uint32_t ix = (uint32_t)(wi * 64 + lane);
+        if (LDS_TAB) { const WEnt<T> e_ = wt[ix]; s.ab = e_.ab; s.rest = e_.rest; }
+        else { s.ab = g_ent[ix]; s.rest = g_rest[ix]; }
+        s.dep = g_dep[ix];
+    };
+    auto decode_read = [&](Set &s) {
+        s.a = (int)(s.ab & WT_IDX_MASK); s.b = (int)__builtin_amdgcn_ubfe(s.ab, WT_IDX_BITS, WT_IDX_BITS);
+        s.A = cur[s.a]; s.B = cur[s.b];
+    };
+    int w = w0;
+    // one window: `c` holds it (entry decoded, particle records read or in flight), `n` the next one's entry
+    auto step = [&](Set &c, Set &n) {
+        decode_read(n);                                             // speculative: valid unless this window corrects something
+        T ax = c.A.x, ay = c.A.y, az = c.A.z, bx = c.B.x, by = c.B.y, bz = c.B.z;
+        T dx = ax - bx, dy = ay - by, dz = az - bz;
+        T len2 = sumsq<T>(dx, dy, dz);
+        const T t11 = c.rest * c11;
+        T len = (T)0; bool trig;
+        if constexpr (sizeof(T) == 4) { len = dev_sqrt<T>(len2); trig = len > t11; }
+        else trig = len2 > t11 * t11 * ((T)1 - filt_slack<T>());    // fp64: the squared pre-filter decides whether anybody looks closer
+        if (STATS) { st_windows++; st_passes++; }
+        if (__builtin_expect(ballot64(trig) != 0ull, 0)) {
+            // ---- the exact path (strain_sweep's pass loop; its first pass is the evaluation above) ----
+            // (measured and rejected, round 5: the commit computed by every lane with the stores of the lanes that must not write sent
+            //  to a per-lane sink record -- no exec-mask detour, one branch per pass --: -4 %; the window's "nobody left" exit dropped
+            //  in favour of the next pass's "nobody over-stretched": -2.5 %)
+            const uint32_t ca = w_cnt(c.A.w), cb = w_cnt(c.B.w);    // pins do not change during a sweep
+            T tl = ((ca != 0) & (cb != 0)) ? INF_ : t11;           // both ends pinned: skipped by the reference (:268)
+            T tl2 = tl * tl * ((T)1 - filt_slack<T>());
+            auto test = [&]() {
+                if constexpr (sizeof(T) == 4) { trig = len > tl; }
+                else { trig = false; if (len2 > tl2) { len = dev_sqrt<T>(len2); trig = len > tl; } }
+            };
+            test();
+            unsigned long long tb = ballot64(trig);
+            if (tb) {
+                P3 *const pa = reinterpret_cast<P3 *>(cur + c.a), *const pb = reinterpret_cast<P3 *>(cur + c.b);
+                const uint32_t dlo = (uint32_t)c.dep, dhi = (uint32_t)(c.dep >> 32);
+                // every correction of the window may move particles whose springs sit as far as the window's reach
+                const int reach = w + ((int)((uint32_t)__builtin_amdgcn_readfirstlane((int)c.ab) >> WT_REACH_SHIFT) << rshift);
+                w_end = reach > w_end ? reach : w_end;
+                bool pl = true;
+                unsigned long long plm = ~0ull;
+                for (;;) {
+                    // a spring is VALID when none of its (transitive) predecessors in the window is over-stretched now (strain_sweep)
+                    const bool bad = ((dlo & (uint32_t)tb) | (dhi & (uint32_t)(tb >> 32))) != 0u;
+                    if (STATS) st_commits++;
+                    if (trig & !bad) {
+                        if (len > c.rest * tth) tear = 1;                               // :272 (tear implies stretch here)
+                        const T ux = dev_div<T>(dx, len), uy = dev_div<T>(dy, len), uz = dev_div<T>(dz, len);   // :276-278
+                        const T extra = len - t11;                                      // :279
+                        const T wa = ca != 0 ? (T)0 : (cb != 0 ? (T)1 : (T)0.5);        // :281-296 as weights (strain_sweep)
+                        const T wb = cb != 0 ? (T)0 : (ca != 0 ? (T)1 : (T)0.5);
+                        const T ea = extra * wa, eb = extra * wb;
+                        *pa = P3{mad<T>(-ux, ea, ax), mad<T>(-uy, ea, ay), mad<T>(-uz, ea, az)};
+                        *pb = P3{mad<T>(ux, eb, bx), mad<T>(uy, eb, by), mad<T>(uz, eb, bz)};
+                    }
+                    pl = pl & bad;
+                    tl = pl ? tl : INF_; if (sizeof(T) == 8) tl2 = pl ? tl2 : INF_;
+                    plm &= ballot64(bad);
+                    if (plm == 0ull) break;
+                    __builtin_amdgcn_wave_barrier();                // same-wave LDS operations execute in program order
+                    const P3 na = *pa, nb = *pb;
+                    ax = na.x; ay = na.y; az = na.z; bx = nb.x; by = nb.y; bz = nb.z;
+                    dx = ax - bx; dy = ay - by; dz = az - bz;
+                    len2 = sumsq<T>(dx, dy, dz);
+                    if constexpr (sizeof(T) == 4) len = dev_sqrt<T>(len2);
+                    test();
+                    tb = ballot64(trig);
+                    if (STATS) st_passes++;
+                    if (tb == 0ull) break;                          // a quiet pass ends the window
+                }
+                n.A = cur[n.a]; n.B = cur[n.b];                     // the speculative records are stale now
+            }
+        }
+        load(w + 2, c);                                             // this set is free: the entry of the window after next
+    };
+    Set S0, S1;
+    load(w, S0); load(w + 1, S1);
+    decode_read(S0);
+    for (;;) {
+        step(S0, S1);
+        if (++w > w_end) break;
+        step(S1, S0);
+        if (++w > w_end) break;
+    }
     return tear;
 }
 
@@ -1137,6 +1252,10 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
     const FusedArgs<T> *const Fp = A.fz;
     constexpr bool fused = FUSED != 0;
     constexpr bool with_tier2 = FUSED == 2;
+    // FUSED 3: like 1, with the two ORDERED phases relaxed (SURVEY 7-H4's labelled, non-parity data point): self-collision in Jacobi
+    // order (every particle corrected against the phase's start positions), strain limit in coloured order (twelve classes of springs
+    // that share no particle, each class in parallel). Different trajectories from the reference's: never a product path, bench only.
+    constexpr bool RELAXED = FUSED == 3;
     ClothSchedule sc;
     if (!fused) {
         sc = A.sched[e];
@@ -1181,6 +1300,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
     uint32_t gt[GT_REG ? PPT : 1][HK_SLOTS];
     T rr[REST_R ? PPT : 1][HK_SLOTS];     // and those springs' rest lengths
     uint32_t vm[LEAN ? PPT : 1];            // LEAN: which of the twelve stencil positions exist for the particle
+    uint32_t rc[RELAXED ? PPT : 1];         // RELAXED: the particle's grid position, r | c << 8 (parities of the colour classes)
     auto lean_entry = [&](int i, uint32_t vmq, int sl) -> uint32_t {      // a gather entry without its table-slot field
         const bool ok = ((vmq >> sl) & 1u) != 0u;
         return (uint32_t)(ok ? i + lean_off(sl, A.N) : i) | (ok ? HK_VALID : 0u) | (sl < HK_SLOTS / 2 ? HK_ASB : 0u) |
@@ -1197,7 +1317,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
             const int i = tid + q * NT;
             const bool ok = i < P;
             pvx[q] = ok ? gq[i] : (T)0; pvy[q] = ok ? gq[Ppad + i] : (T)0; pvz[q] = ok ? gq[2 * Ppad + i] : (T)0;
-            if (LEAN) { const int r_ = i / A.N; vm[LEAN ? q : 0] = ok ? lean_valid_mask(r_, i - r_ * A.N, A.N) : 0u; }
+            if (LEAN) { const int r_ = i / A.N; vm[LEAN ? q : 0] = ok ? lean_valid_mask(r_, i - r_ * A.N, A.N) : 0u; if (RELAXED) rc[RELAXED ? q : 0] = (uint32_t)r_ | ((uint32_t)(i - r_ * A.N) << 8); }
             else
 #pragma unroll
             for (int sl = 0; sl < HK_SLOTS; sl++) {
@@ -1249,6 +1369,14 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
     constexpr bool SWEEP_TIMED = true;
 #else
     constexpr bool SWEEP_TIMED = false;
+#endif
+#ifndef CLOTHHIP_SWEEP_LEAN
+#define CLOTHHIP_SWEEP_LEAN 1           // A/B: 0 = strain_sweep everywhere, 2 = the lean walk for fp32 only
+#endif
+#if !defined(CLOTHHIP_SWEEP_STAMPS) && !defined(CLOTHHIP_SWEEP_OUTER) && !defined(CLOTHHIP_CELL_COUNTERS)
+    constexpr bool SWEEP_LEAN = CLOTHHIP_SWEEP_LEAN != 0 && (CLOTHHIP_SWEEP_LEAN != 2 || sizeof(T) == 4);
+#else
+    constexpr bool SWEEP_LEAN = false;  // (the sweep-stamps and census builds instrument strain_sweep)
 #endif
 #if defined(CLOTHHIP_SWEEP_MW) && !defined(CLOTHHIP_SWEEP_STAMPS) && !defined(CLOTHHIP_SWEEP_OUTER)
     constexpr bool SWEEP_MW = true;     // A/B build (round 5): every wave of the cloth looks ahead one window each (strain_sweep_mw);
@@ -1933,6 +2061,33 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
             }
             __syncthreads();
             TSTAMP(4)
+            if constexpr (RELAXED) {
+                // Jacobi order (NOT the reference's Gauss-Seidel order, cloth.pyx:313-343): every unpinned particle collects its hits
+                // against the cell-ordered snapshot of the phase's start positions and moves by itself; no seeds, no cell sweeps
+#pragma unroll
+                for (int q = 0; q < PPT; q++) {
+                    const int i = tid + q * NT;
+                    if (cn[q] >= 2) {
+                        const Pt<T> me_ = cme[q];
+                        T tx = (T)0, ty = (T)0, tz = (T)0; int nh = 0;
+#pragma unroll 1
+                        for (int b = 0; b < cn[q]; b++) {
+                            const Pt<T> o = cpos[cstart[q] + b];
+                            const T dx = me_.x - o.x, dy = me_.y - o.y, dz = me_.z - o.z;
+                            const T dist = dev_sqrt<T>(sumsq<T>(dx, dy, dz));
+                            const bool hit_ = ((int)w_cnt(o.w) != i) & (dist <= k.thresh);
+                            const T factor = hit_ ? dev_div<T>(k.thresh - dist, dist) : (T)0;
+                            tx = hit_ ? mad<T>(dx, factor, tx) : tx; ty = hit_ ? mad<T>(dy, factor, ty) : ty; tz = hit_ ? mad<T>(dz, factor, tz) : tz;
+                            nh += hit_ ? 1 : 0;
+                        }
+                        if (nh) {
+                            const T nf = (T)nh;
+                            cur[i] = Pt<T>{me_.x + dev_div<T>(dev_div<T>(tx, nf), k.sim_steps), me_.y + dev_div<T>(dev_div<T>(ty, nf), k.sim_steps),
+                                           me_.z + dev_div<T>(dev_div<T>(tz, nf), k.sim_steps), me_.w};
+                        }
+                    }
+                }
+            } else {
             // ---- self-collision (cloth.pyx:313-343) ------------------------------------------------------
             // (1) seeds: every unpinned particle, in parallel: does it have a hit (a same-cell member within
             //     2*thickness) at the CURRENT positions? A seed gets the flag bit of its slot word; the first seed of
@@ -1961,6 +2116,21 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
                             if (Ak_->cell_copy) {
                                 // a read past the cell's range (another cell's record or the padding behind the array) is masked out
                                 // by the member count; the trip base is clamped so that no read leaves the padded array
+#ifndef CLOTHHIP_PRECHECK2              // (round 5: four members per trip -- half the loop branches and LDS waits per member: +0.25 %; -DCLOTHHIP_PRECHECK2: two)
+#pragma unroll 1
+                                for (int b = 0; b < nq; b += 4) {
+                                    const int base = cs_ + b < Ppad + 28 ? cs_ + b : Ppad + 28;
+                                    const Pt<T> o0 = cpos[base], o1 = cpos[base + 1], o2 = cpos[base + 2], o3 = cpos[base + 3];
+                                    const T dx0 = me_.x - o0.x, dy0 = me_.y - o0.y, dz0 = me_.z - o0.z;
+                                    const T dx1 = me_.x - o1.x, dy1 = me_.y - o1.y, dz1 = me_.z - o1.z;
+                                    const T dx2 = me_.x - o2.x, dy2 = me_.y - o2.y, dz2 = me_.z - o2.z;
+                                    const T dx3 = me_.x - o3.x, dy3 = me_.y - o3.y, dz3 = me_.z - o3.z;
+                                    h_ |= (b < cn_) & ((int)w_cnt(o0.w) != iq_) & !(sumsq<T>(dx0, dy0, dz0) > thr2);
+                                    h_ |= (b + 1 < cn_) & ((int)w_cnt(o1.w) != iq_) & !(sumsq<T>(dx1, dy1, dz1) > thr2);
+                                    h_ |= (b + 2 < cn_) & ((int)w_cnt(o2.w) != iq_) & !(sumsq<T>(dx2, dy2, dz2) > thr2);
+                                    h_ |= (b + 3 < cn_) & ((int)w_cnt(o3.w) != iq_) & !(sumsq<T>(dx3, dy3, dz3) > thr2);
+                                }
+#else
 #pragma unroll 1
                                 for (int b = 0; b < nq; b += 2) {
                                     const int base = cs_ + b < Ppad + 30 ? cs_ + b : Ppad + 30;
@@ -1970,6 +2140,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
                                     h_ |= (b < cn_) & ((int)w_cnt(o0.w) != iq_) & !(sumsq<T>(dx0, dy0, dz0) > thr2);       // branch-free on purpose (& not &&)
                                     h_ |= (b + 1 < cn_) & ((int)w_cnt(o1.w) != iq_) & !(sumsq<T>(dx1, dy1, dz1) > thr2);
                                 }
+#endif
                             } else {
 #pragma unroll 1
                                 for (int b = 0; b < nq; b += 2) {
@@ -2118,6 +2289,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
                 }
             }
             __builtin_amdgcn_s_setprio(0);
+            }   // (exact order)
             __syncthreads();
             TSTAMP(6)
             for (int t = tid; t < nocc; t += NT) { const int h = (int)olist[t]; hkey[h] = KEY_EMPTY; hco[h] = 0; }   // ready for the next substep
@@ -2163,6 +2335,48 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
         //     evaluated here, so nothing before the first needs a look, and nothing behind the last unless a correction
         //     reaches it. No spring flagged: the sweep is skipped (a cloth at rest).
         // (2) wave 0 walks the windows in between (strain_sweep above).
+        if constexpr (RELAXED) {
+            // Coloured order (NOT the reference's list order, cloth.pyx:258-296): the six springs a particle owns (to r-1, c-1, the two
+            // diagonals, r-2, c-2) in two parity classes each -- twelve classes whose springs share no particle --, one class after the
+            // other, every class in parallel by the owners of its springs. Same test, same correction per spring.
+            CLOTH_PHASE_ARGS()
+            static_assert(!RELAXED || LEAN, "the relaxed-order companion exists for the LEAN arithmetic (stencil from the grid position, palette rest lengths)");
+            int tear_ = 0;
+#pragma unroll 1
+            for (int col = 0; col < 12; col++) {
+                const int kind = col >> 1, par = col & 1;
+#pragma unroll
+                for (int q = 0; q < PPT; q++) {
+                    const int i = tid + q * NT;
+                    const int r_ = (int)(rc[RELAXED ? q : 0] & 0xFFu), c_ = (int)(rc[RELAXED ? q : 0] >> 8);
+                    const int key = (kind == 1 || kind == 5) ? c_ : r_;
+                    const bool on = i < P && ((vm[LEAN ? q : 0] >> kind) & 1u) && (((kind >= 4 ? key >> 1 : key) & 1) == par);
+                    if (on) {
+                        const int j = i + (kind == 0 ? -Ak_->N : kind == 1 ? -1 : kind == 2 ? -Ak_->N - 1 : kind == 3 ? -Ak_->N + 1 : kind == 4 ? -2 * Ak_->N : -2);
+                        const Pt<T> a_ = cur[j], b_ = cur[i];                                  // ptA (the earlier point), ptB (the owner)
+                        const uint32_t ca = w_cnt(a_.w), cb = w_cnt(b_.w);
+                        const T rest = kind >= 4 ? Ak_->pal_bend : (kind >= 2 ? Ak_->pal_shear : Ak_->pal_struct);
+                        const T dx = a_.x - b_.x, dy = a_.y - b_.y, dz = a_.z - b_.z;
+                        const T len = fastnorm<T>(dx, dy, dz);
+                        if (!((ca != 0) & (cb != 0))) {
+                            if (len > rest * k.tear_thresh) tear_ = 1;
+                            const T t11 = rest * k.c11;
+                            if (len > t11) {
+                                const T ux = dev_div<T>(dx, len), uy = dev_div<T>(dy, len), uz = dev_div<T>(dz, len);
+                                const T extra = len - t11;
+                                const T wa = ca != 0 ? (T)0 : (cb != 0 ? (T)1 : (T)0.5), wb = cb != 0 ? (T)0 : (ca != 0 ? (T)1 : (T)0.5);
+                                const T ea = extra * wa, eb = extra * wb;
+                                if (ca == 0) cur[j] = Pt<T>{mad<T>(-ux, ea, a_.x), mad<T>(-uy, ea, a_.y), mad<T>(-uz, ea, a_.z), a_.w};
+                                if (cb == 0) cur[i] = Pt<T>{mad<T>(ux, eb, b_.x), mad<T>(uy, eb, b_.y), mad<T>(uz, eb, b_.z), b_.w};
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            if (__any(tear_) && lane == 0) misc[0] = 1;
+            __syncthreads();
+        } else
         if (pm & PH_STRAIN) {
             CLOTH_PHASE_ARGS()
             {
@@ -2305,8 +2519,10 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
 #else
                 const unsigned long long fmask_ = 0ull;
 #endif
-                const int tear = tic ? strain_sweep<T, v_ldstab(TAB), SWEEP_TIMED, SWEEP_STATS, true>(cur, wtab, Ak_->wt_ent, g_rest, Ak_->wt_dep, w0, w1, Ak_->nW, Ak_->wt_rshift, k,
-                                                                                                 lane, st_windows, st_passes, st_commits, tph, fmask_)
+                const int tear = tic ? (SWEEP_LEAN ? strain_sweep_lean<T, v_ldstab(TAB), SWEEP_STATS>(cur, wtab, Ak_->wt_ent, g_rest, Ak_->wt_dep, w0, w1, Ak_->wt_rshift, k,
+                                                                                                  lane, st_windows, st_passes, st_commits)
+                                                   : strain_sweep<T, v_ldstab(TAB), SWEEP_TIMED, SWEEP_STATS, true>(cur, wtab, Ak_->wt_ent, g_rest, Ak_->wt_dep, w0, w1, Ak_->nW, Ak_->wt_rshift, k,
+                                                                                                 lane, st_windows, st_passes, st_commits, tph, fmask_))
                                      : strain_sweep<T, v_ldstab(TAB), SWEEP_TIMED, SWEEP_STATS, false>(cur, wtab, Ak_->wt_ent, g_rest, Ak_->wt_dep, w0, w1, Ak_->nW, Ak_->wt_rshift, k,
                                                                                                   lane, st_windows, st_passes, st_commits, tph, fmask_);
                 if (__any(tear) && lane == 0) misc[0] = 1;

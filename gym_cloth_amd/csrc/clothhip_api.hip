@@ -68,6 +68,7 @@ struct clothhip_handle {
     // It needs ONE shared rest table whose fp32 values are one per spring type (checked on the device's table whenever that table
     // may have changed) and the regular gather stencil (checked once); otherwise the (0, false) variant runs on the same layout.
     bool lean = false, lean_dirty = true, lean_ok = false, lean_stencil_ok = false;
+    bool relaxed = false;   // CLOTHHIP_RELAXED_ORDER=1 at create: the episode launches run the relaxed-order companion kernel (bench only, no parity)
     int lean_r = 3;         // cloths per CU the chosen LEAN build is compiled for (3: 168 VGPRs, 4: 128 VGPRs; 2: eight waves per cloth, table in LDS; 1: the large grids)
     float pal[3] = {0, 0, 0};
     int32_t last_variant[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // what the last launch ran (clothhip_last_variant)
@@ -441,6 +442,8 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
             }
             h->nt = keep.nt; h->ppt = keep.ppt; h->tab = keep.tab; h->rest_reg = keep.rest_reg;
         }
+        if (const char *t = getenv("CLOTHHIP_RELAXED_ORDER")) h->relaxed = atoi(t) != 0;
+        if (h->relaxed) HC(hipFuncSetAttribute((const void *)k_run_schedule<float, 512, 2, 2, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         const void *fn = stepper_fn(h, 0), *fnf = stepper_fn(h, 1), *fnf2 = stepper_fn(h, 2);
         if (!fn || !fnf || !fnf2) { free_handle(h); return fail(CLOTHHIP_EINVAL, "no stepper variant for n_side %d", h->N); }
         HC(hipFuncSetAttribute(fnf, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -806,6 +809,18 @@ template <typename T, int FUSED> static void launch_run(clothhip_handle *h, cons
 #undef X
 }
 
+// The relaxed-order companion (k_run_schedule<float, 512, 2, 2, true, 3>: Jacobi self-collision, coloured strain limit): ONE instantiation,
+// the headline variant's layout. Results differ from the reference's by construction -- a labelled measurement of what the exact order
+// costs (bench.py's companion record "exact_order": false), never a product path.
+static void launch_relaxed(clothhip_handle *h, const void *d_fz) {
+    StepArgs<float> a = make_args<float>(h, h->d_sched);
+    a.fz = (const FusedArgs<float> *)d_fz;
+    hipLaunchKernelGGL((k_run_schedule<float, 512, 2, 2, true, 3>), dim3(h->E), dim3(512), h->lds_bytes, h->stream, a);
+    const int occ_ = cached_occupancy(h, (const void *)k_run_schedule<float, 512, 2, 2, true, 3>, 512);
+    const int32_t v_[10] = {512, 2, 2, 1, 1, 3, h->lds_bytes, occ_, h->n_cus, 1};
+    memcpy(h->last_variant, v_, sizeof(v_)); h->have_variant = true;
+}
+
 static int run_common(clothhip_handle *h, const ClothSchedule *d_sched) {
     if (int rc = drop_in_flight(h, nullptr, d_sched)) return rc;
     if (int rc = lean_refresh(h)) return rc;         // (may synchronise and read the rest table back: outside the timed events)
@@ -1027,7 +1042,12 @@ extern "C" int clothhip_run_actions_begin(clothhip_handle *h, const ClothEpisode
                            rng_states != nullptr, rng_tier, domrand_words, NS, NH);
     HIPCHECK(hipMemcpyAsync(h->d_fz, fzbuf, 1024, hipMemcpyHostToDevice, h->stream));
     HIPCHECK(hipStreamSynchronize(h->stream));          // fzbuf is on this stack frame
+    if (h->relaxed && !(h->precision == CLOTHHIP_F32 && h->nt == 512 && h->ppt == 2 && h->tab == 2 && h->rest_reg && h->cell_copy && !tier2 &&
+                        policy != CLOTHHIP_POLICY_HIGHEST_POINT))
+        return fail(CLOTHHIP_ESTATE, "CLOTHHIP_RELAXED_ORDER: the relaxed-order companion exists for the eight-wave LEAN layout only (fp32, flat tiers, 25x25 class, <= 512 cloths)");
     HIPCHECK(hipEventRecord(h->ev0, h->stream));
+    if (h->relaxed) launch_relaxed(h, h->d_fz);
+    else
     if (tier2 || policy == CLOTHHIP_POLICY_HIGHEST_POINT) {   // the variant that also carries the tier-2 reset code and the cold policies
         if (h->precision == CLOTHHIP_F64) launch_run<double, 2>(h, h->d_sched, h->d_fz);
         else launch_run<float, 2>(h, h->d_sched, h->d_fz);
