@@ -249,7 +249,9 @@ __device__ __forceinline__ int strain_sweep_lean(Pt<T> *cur, const WEnt<T> *wt, 
             // ---- the exact path (strain_sweep's pass loop; its first pass is the evaluation above) ----
             // (measured and rejected, round 5: the commit computed by every lane with the stores of the lanes that must not write sent
             //  to a per-lane sink record -- no exec-mask detour, one branch per pass --: -4 %; the window's "nobody left" exit dropped
-            //  in favour of the next pass's "nobody over-stretched": -2.5 %)
+            //  in favour of the next pass's "nobody over-stretched": -2.5 %; the pass hand-ordered so that every scalar instruction that waits for
+            //  a vector compare's mask has independent vector work in front of it -- the correction computed before the exec mask is formed, the
+            //  re-reads issued before the "nobody left" decision --: -2.5 %)
             const uint32_t ca = w_cnt(c.A.w), cb = w_cnt(c.B.w);    // pins do not change during a sweep
             T tl = ((ca != 0) & (cb != 0)) ? INF_ : t11;           // both ends pinned: skipped by the reference (:268)
             T tl2 = tl * tl * ((T)1 - filt_slack<T>());
