@@ -165,7 +165,12 @@ def _run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, ran
     cfg = bench_cfg(n_side, thickness, init)
     env = ClothVecEnv(cfg, n_envs=E, device=local_rank, precision=precision, consume_domrand_draws=False)
     transport_name = "none (1 GPU)"
-    if world > 1:
+    if world > 1 and os.environ.get("CLOTH_BENCH_FORCE_TCP") == "1":
+        # test hook (tests/test_gpu_dist.py): two ranks on ONE GPU cannot form an RCCL communicator; the rank logic around the exchange --
+        # sharding, per-rank streams, sums / max over ranks, the value arithmetic -- is the same over the TCP transport. Never a bench result.
+        transport = SocketTransport(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")) + 17)
+        transport_name = "TCP sockets (forced by CLOTH_BENCH_FORCE_TCP: test only)"
+    elif world > 1:
         try:
             transport, transport_name = RcclTransport(rank, world, env.batch), "RCCL (ctypes binding, handle stream, device-resident tables)"
         except Exception as exc:

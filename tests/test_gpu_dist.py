@@ -92,3 +92,39 @@ def test_rccl_unique_id_file_round_trip_and_comm_count(tmp_path, monkeypatch):
     t = RcclTransport(0, 1, b, rdzv_path=str(tmp_path / "one.id"))
     assert t.comm.nranks == 1
     t.close(); b.close()
+
+
+def test_bench_two_ranks_on_one_gpu_over_tcp(tmp_path):
+    """bench.py's multi-rank path end to end with REAL kernels: two ranks (two processes, both on this box's one GPU, the exchange forced
+    onto the TCP transport because two ranks on one device cannot form an RCCL communicator) run the fused workload on 64 cloths each.
+    Checks what a 2-GPU run's line must satisfy whatever the transport: one JSON line from rank 0, n_gpus 2, the env blocks of both ranks
+    counted (env steps, substeps), `value` = the actions' substeps of BOTH ranks over the actions' share of the max-over-ranks clock, and
+    the per-rank streams sharded by global env index (rank 1's envs are envs 64..127 of a single-process run)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    args = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--envs", "64", "--steps", "4", "--warmup", "2", "--fuse", "2",
+            "--no-extra", "--no-cpu-baseline"]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   CLOTH_BENCH_FORCE_TCP="1", CLOTHHIP_RDZV_FILE=str(tmp_path / "unused.id"))
+        procs.append(subprocess.Popen(args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1].decode()[-2000:] for o in outs]
+    lines = [l for l in outs[0][0].decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and not [l for l in outs[1][0].decode().splitlines() if l.startswith("{")]
+    rec = json.loads(lines[0])
+    c = rec["config"]
+    assert rec["n_gpus"] == 2 and c["envs_per_gpu"] == 64 and "TCP" in c["transport"] and c["rccl_nranks"] is None
+    assert rec["cpu_baseline"].startswith("skipped")
+    assert 2 * 64 * 2 <= c["env_steps_executed"] <= 2 * 64 * 16           # both ranks' envs are counted (about 4 steps per env)
+    assert 0.2 < c["action_time_frac"] <= 1.0 and rec["value"] > 0 and c["blended_substeps_per_s"] > 0
+    # value x (the actions' share of the clock) = action substeps of the whole job
+    n_act = c["action_substeps_per_env_step"] * c["env_steps_executed"]
+    assert abs(rec["value"] * c["timed_region_s"] * c["action_time_frac"] - n_act) <= 1e-6 * n_act
+    assert abs(rec["ms_per_step"] * c["steps_equivalent"] - 1e3 * c["timed_region_s"] * c["action_time_frac"]) <= 1e-6 * 1e3 * c["timed_region_s"]
+    assert rec["roofline"]["traffic"] is None or rec["roofline"]["traffic_source"]
