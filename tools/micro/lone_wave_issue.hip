@@ -67,6 +67,20 @@ __global__ __launch_bounds__(512) void k(unsigned long long *out, int iters, int
                 asm volatile(REP16("v_cmp_gt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc\n\tv_add_f32 %0, %0, %1\n\t") : "+v"(v0) : "v"(1.0f) : "vcc");
             } else if (MODE == 14) {  // 16 x (s_and_saveexec, v_add, s_or exec): exec-mask detours
                 asm volatile(REP16("s_and_saveexec_b64 %1, %2\n\tv_add_f32 %0, %0, %3\n\ts_or_b64 exec, exec, %1\n\t") : "+v"(v0), "=s"(m0) : "s"(~0ull), "v"(1.0f) : "scc");
+            } else if (MODE == 15 || MODE == 16 || MODE == 17 || MODE == 18) {
+                // 4 x (NR independent 16-byte LDS reads back to back, then one use of all): are a lone wave's reads pipelined?
+                // 15: 2 reads, lane-consecutive records; 16: 4 reads, consecutive; 17: 4 reads, scattered records (a hash of the lane); 18: 8 reads, scattered
+                for (int u = 0; u < 4; u++) {
+                    const int base = (MODE == 17 || MODE == 18) ? ((tid * 37 + u * 101 + i * 7) & 1023) : ((tid + u * 64 + i) & 1023);
+                    float acc4 = 0.f;
+                    constexpr int NR = MODE == 15 ? 2 : (MODE == 18 ? 8 : 4);
+                    float4 p[NR];
+#pragma unroll
+                    for (int r = 0; r < NR; r++) p[r] = pts[(base + ((MODE == 17 || MODE == 18) ? r * 211 : r * 64)) & 1023];
+#pragma unroll
+                    for (int r = 0; r < NR; r++) acc4 += p[r].x;
+                    v0 += acc4;
+                }
             } else if (MODE == 7) {   // 16 x (v_cmp -> vcc -> s_cbranch_vccz not taken)
                 asm volatile(REP16("v_cmp_gt_f32 vcc, %0, %1\n\ts_cbranch_vccnz 1f\n\tv_add_f32 %0, %0, %1\n\t1:\n\t") : "+v"(v0) : "v"(-1.0f) : "vcc");
             }
@@ -113,6 +127,10 @@ int main() {
             run<12>("16 x (s_waitcnt idle, v_add)", 32, blocks, busy, prio);
             run<13>("16 x (v_cmp vcc, v_cndmask vcc, v_add)", 48, blocks, busy, prio);
             run<14>("16 x (s_and_saveexec, v_add, s_or exec)", 48, blocks, busy, prio);
+            run<15>("4 x (2 independent b128 reads, consecutive lanes, use)", 4, blocks, busy, prio);
+            run<16>("4 x (4 independent b128 reads, consecutive lanes, use)", 4, blocks, busy, prio);
+            run<17>("4 x (4 independent b128 reads, scattered records, use)", 4, blocks, busy, prio);
+            run<18>("4 x (8 independent b128 reads, scattered records, use)", 4, blocks, busy, prio);
         }
     return 0;
 }
