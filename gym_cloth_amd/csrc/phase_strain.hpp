@@ -252,7 +252,8 @@ __device__ __forceinline__ int strain_sweep_lean(Pt<T> *cur, const WEnt<T> *wt, 
             //  in favour of the next pass's "nobody over-stretched": -2.5 %; the pass hand-ordered so that every scalar instruction that waits for
             //  a vector compare's mask has independent vector work in front of it -- the correction computed before the exec mask is formed, the
             //  re-reads issued before the "nobody left" decision --: -2.5 %; the next window's records re-read together with every pass's own
-            //  re-read, so that a window ending in a quiet pass leaves them fresh: -5 % -- two more scattered 16-byte reads per pass cost ~180 cycles)
+            //  re-read, so that a window ending in a quiet pass leaves them fresh: -5 % -- two more scattered 16-byte reads per pass cost ~180 cycles;
+            //  the re-read under an exec mask of the lanes still pending: -4 %)
             const uint32_t ca = w_cnt(c.A.w), cb = w_cnt(c.B.w);    // pins do not change during a sweep
             T tl = ((ca != 0) & (cb != 0)) ? INF_ : t11;           // both ends pinned: skipped by the reference (:268)
             T tl2 = tl * tl * ((T)1 - filt_slack<T>());
