@@ -140,6 +140,50 @@ inline WindowTable build_windows(const Topology &t, const LevelSchedule &L) {
         }
     }
     W.nW = w + 1;
+#ifndef CLOTHHIP_WINDOW_LEVEL_ORDER
+    // Lane order inside a window (round 5): any linear extension of "an earlier spring that shares a particle comes first" serves the sweep
+    // (its pass rule reads the dependency masks, not the lane numbers). Level order is one; this one is chosen for the LDS banks: the sweep
+    // reads the two particle records of every lane (16-byte records: two particles whose indices agree mod 16 share their banks), sixteen lanes
+    // to a bank cycle, so within each group of sixteen lanes the ptA indices -- and the ptB indices -- should differ mod 16 (same particle =
+    // same address = a broadcast, no conflict). Greedy list scheduling over the window's springs: 25x25 per window, summed over its four
+    // groups of sixteen, max records per bank group 12.7 (ptA) / 9.9 (ptB) in level order -> 7.7 / 4.5 (4 = conflict-free).
+    {
+        std::vector<std::vector<int>> members((size_t)W.nW);
+        for (int s = 0; s < t.S; s++) members[W.slot_of[s] >> 6].push_back(s);          // (ascending list index)
+        std::vector<int> last_in_win(t.P, -1), npred(t.S, 0);
+        std::vector<std::vector<int>> succ(t.S);
+        for (int ws = 0; ws < W.nW; ws++) {
+            const std::vector<int> &m = members[ws];
+            for (int s : m) {                                                            // in-window predecessors: the previous spring of either particle
+                const int pa = last_in_win[t.a[s]], pb = last_in_win[t.b[s]];
+                if (pa >= 0) { succ[pa].push_back(s); npred[s]++; }
+                if (pb >= 0 && pb != pa) { succ[pb].push_back(s); npred[s]++; }
+                last_in_win[t.a[s]] = s; last_in_win[t.b[s]] = s;
+            }
+            for (int s : m) { last_in_win[t.a[s]] = -1; last_in_win[t.b[s]] = -1; }
+            std::vector<int> ready, placed;
+            for (int s : m) if (npred[s] == 0) ready.push_back(s);
+            while (!ready.empty()) {
+                const int g0 = (int)placed.size() / 16 * 16;                             // the sixteen-lane group being filled
+                int best = -1, best_key = 0;
+                for (int s : ready) {
+                    int ca = 0, cb = 0;                                                  // other particles of the group in the same bank group
+                    for (size_t q = g0; q < placed.size(); q++) {
+                        const int o = placed[q];
+                        if (t.a[o] != t.a[s] && (t.a[o] & 15) == (t.a[s] & 15)) ca++;
+                        if (t.b[o] != t.b[s] && (t.b[o] & 15) == (t.b[s] & 15)) cb++;
+                    }
+                    const int key = (std::max(ca, cb) << 20) | ((ca + cb) << 12) | 0;     // then the earliest spring (ready is kept in list order)
+                    if (best < 0 || key < best_key) { best = s; best_key = key; }
+                }
+                placed.push_back(best);
+                ready.erase(std::find(ready.begin(), ready.end(), best));
+                for (int n : succ[best]) if (--npred[n] == 0) ready.insert(std::upper_bound(ready.begin(), ready.end(), n), n);
+            }
+            for (size_t q = 0; q < placed.size(); q++) W.slot_of[placed[q]] = ws * 64 + (int)q;
+        }
+    }
+#endif
 
     std::vector<int> last_win(t.P, 0);                            // window of the last spring incident to a point
     for (int s = 0; s < t.S; s++) {
