@@ -245,7 +245,7 @@ __device__ __forceinline__ int strain_sweep_lean(Pt<T> *cur, const WEnt<T> *wt, 
         if constexpr (sizeof(T) == 4) { len = dev_sqrt<T>(len2); trig = len > t11; }
         else trig = len2 > t11 * t11 * ((T)1 - filt_slack<T>());    // fp64: the squared pre-filter decides whether anybody looks closer
         if (STATS) { st_windows++; st_passes++; }
-        if (__builtin_expect(ballot64(trig) != 0ull, 0)) {
+        if (ballot64(trig) != 0ull) {                               // (no "unlikely" hint: with the exact path out of line the pulled states ran 2.5 % slower)
             // ---- the exact path (strain_sweep's pass loop; its first pass is the evaluation above) ----
             // (measured and rejected, round 5: the commit computed by every lane with the stores of the lanes that must not write sent
             //  to a per-lane sink record -- no exec-mask detour, one branch per pass --: -4 %; the window's "nobody left" exit dropped
