@@ -288,7 +288,7 @@ __device__ __forceinline__ int strain_sweep_lean(Pt<T> *cur, const WEnt<T> *wt, 
                     pl = pl & bad;
                     tl = pl ? tl : INF_; if (sizeof(T) == 8) tl2 = pl ? tl2 : INF_;
                     plm &= ballot64(bad);
-                    if (plm == 0ull) break;
+                    if (__builtin_expect(plm == 0ull, 0)) break;    // ("another pass" as the loop's fall-through: pulled states -1 %, bench +0.5 %)
                     __builtin_amdgcn_wave_barrier();                // same-wave LDS operations execute in program order
                     const P3 na = *pa, nb = *pb;
                     ax = na.x; ay = na.y; az = na.z; bx = nb.x; by = nb.y; bz = nb.z;
@@ -298,7 +298,7 @@ __device__ __forceinline__ int strain_sweep_lean(Pt<T> *cur, const WEnt<T> *wt, 
                     test();
                     tb = ballot64(trig);
                     if (STATS) st_passes++;
-                    if (tb == 0ull) break;                          // a quiet pass ends the window
+                    if (__builtin_expect(tb == 0ull, 0)) break;     // a quiet pass ends the window
                 }
                 n.A = cur[n.a]; n.B = cur[n.b];                     // the speculative records are stale now
             }
