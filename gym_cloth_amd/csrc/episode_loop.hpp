@@ -191,6 +191,11 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
 #else
     constexpr bool SWEEP_LEAN = false;  // (the sweep-stamps and census builds instrument strain_sweep)
 #endif
+#ifndef CLOTHHIP_SWEEP_AHEAD_MIN_TAB
+#define CLOTHHIP_SWEEP_AHEAD_MIN_TAB -2     // TAB below this (the build for six cloths per CU: 1 536 cloths 33.8 -> 34.2 M/s; five per CU: +-0): the lean walk without its read-ahead
+#endif
+    constexpr bool SWEEP_AHEAD = TAB >= CLOTHHIP_SWEEP_AHEAD_MIN_TAB;
+    (void)SWEEP_AHEAD;
 #if defined(CLOTHHIP_SWEEP_MW) && !defined(CLOTHHIP_SWEEP_STAMPS) && !defined(CLOTHHIP_SWEEP_OUTER)
     constexpr bool SWEEP_MW = true;     // A/B build (round 5): every wave of the cloth looks ahead one window each (strain_sweep_mw);
                                         // bit-identical, measured -8 % on the headline workload: not the production path

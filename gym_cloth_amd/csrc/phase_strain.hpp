@@ -212,7 +212,9 @@ __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const
 //   * everything a correction needs -- pins and weights, the dependency word, the exact limit with both-pinned springs sorted out,
 //     the reach, the pass loop of strain_sweep (same rule, same arithmetic) -- sits behind that one branch.
 // Same walk, same passes, same results as strain_sweep (tear_thresh >= 1.1 only: the caller keeps strain_sweep for the other case).
-template <typename T, bool LDS_TAB, bool STATS>
+// (AHEAD false -- the high-residency builds, whose other waves hide the latency: a window's particle records are read when the window starts,
+//  not a window ahead: sixteen registers fewer across the walk)
+template <typename T, bool LDS_TAB, bool STATS, bool AHEAD = true>
 __device__ __forceinline__ int strain_sweep_lean(Pt<T> *cur, const WEnt<T> *wt, const uint32_t *g_ent, const T *g_rest,
                                                  const unsigned long long *g_dep, int w0, int w_end, int rshift, const DevConsts<T> &k,
                                                  int lane, int &st_windows, int &st_passes, int &st_commits) {
@@ -236,7 +238,8 @@ __device__ __forceinline__ int strain_sweep_lean(Pt<T> *cur, const WEnt<T> *wt, 
     int w = w0;
     // one window: `c` holds it (entry decoded, particle records read or in flight), `n` the next one's entry
     auto step = [&](Set &c, Set &n) {
-        decode_read(n);                                             // speculative: valid unless this window corrects something
+        if (AHEAD) decode_read(n);                                  // speculative: valid unless this window corrects something
+        else decode_read(c);
         T ax = c.A.x, ay = c.A.y, az = c.A.z, bx = c.B.x, by = c.B.y, bz = c.B.z;
         T dx = ax - bx, dy = ay - by, dz = az - bz;
         T len2 = sumsq<T>(dx, dy, dz);
@@ -300,14 +303,14 @@ __device__ __forceinline__ int strain_sweep_lean(Pt<T> *cur, const WEnt<T> *wt, 
                     if (STATS) st_passes++;
                     if (__builtin_expect(tb == 0ull, 0)) break;     // a quiet pass ends the window
                 }
-                n.A = cur[n.a]; n.B = cur[n.b];                     // the speculative records are stale now
+                if (AHEAD) { n.A = cur[n.a]; n.B = cur[n.b]; }      // the speculative records are stale now
             }
         }
         load(w + 2, c);                                             // this set is free: the entry of the window after next
     };
     Set S0, S1;
     load(w, S0); load(w + 1, S1);
-    decode_read(S0);
+    if (AHEAD) decode_read(S0);
     for (;;) {
         step(S0, S1);
         if (++w > w_end) break;
