@@ -195,6 +195,9 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
 #define CLOTHHIP_SWEEP_AHEAD_MIN_TAB -2     // TAB below this (the build for six cloths per CU: 1 536 cloths 33.8 -> 34.2 M/s; five per CU: +-0): the lean walk without its read-ahead
 #endif
     constexpr bool SWEEP_AHEAD = TAB >= CLOTHHIP_SWEEP_AHEAD_MIN_TAB;
+#ifndef CLOTHHIP_PRECHECK2_MAX_TAB
+#define CLOTHHIP_PRECHECK2_MAX_TAB -3       // TAB at or below this: the collision pre-check takes two members per trip instead of four (substep_collision.inc.hpp)
+#endif
     (void)SWEEP_AHEAD;
 #if defined(CLOTHHIP_SWEEP_MW) && !defined(CLOTHHIP_SWEEP_STAMPS) && !defined(CLOTHHIP_SWEEP_OUTER)
     constexpr bool SWEEP_MW = true;     // A/B build (round 5): every wave of the cloth looks ahead one window each (strain_sweep_mw);

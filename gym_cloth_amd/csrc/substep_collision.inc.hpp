@@ -152,7 +152,9 @@
                             if (Ak_->cell_copy) {
                                 // a read past the cell's range (another cell's record or the padding behind the array) is masked out
                                 // by the member count; the trip base is clamped so that no read leaves the padded array
-#ifndef CLOTHHIP_PRECHECK2              // (round 5: four members per trip -- half the loop branches and LDS waits per member: +0.25 %; -DCLOTHHIP_PRECHECK2: two)
+                                // (round 5: four members per trip -- half the loop branches and LDS waits per member: +0.25 % at two cloths per
+                                //  CU; two per trip where the register cap is 80 (six per CU): 23 fewer spill reloads, +1.6 % at 1536 cloths)
+                                if constexpr (TAB > CLOTHHIP_PRECHECK2_MAX_TAB) {
 #pragma unroll 1
                                 for (int b = 0; b < nq; b += 4) {
                                     const int base = cs_ + b < Ppad + 28 ? cs_ + b : Ppad + 28;
@@ -166,7 +168,7 @@
                                     h_ |= (b + 2 < cn_) & ((int)w_cnt(o2.w) != iq_) & !(sumsq<T>(dx2, dy2, dz2) > thr2);
                                     h_ |= (b + 3 < cn_) & ((int)w_cnt(o3.w) != iq_) & !(sumsq<T>(dx3, dy3, dz3) > thr2);
                                 }
-#else
+                                } else {
 #pragma unroll 1
                                 for (int b = 0; b < nq; b += 2) {
                                     const int base = cs_ + b < Ppad + 30 ? cs_ + b : Ppad + 30;
@@ -176,7 +178,7 @@
                                     h_ |= (b < cn_) & ((int)w_cnt(o0.w) != iq_) & !(sumsq<T>(dx0, dy0, dz0) > thr2);       // branch-free on purpose (& not &&)
                                     h_ |= (b + 1 < cn_) & ((int)w_cnt(o1.w) != iq_) & !(sumsq<T>(dx1, dy1, dz1) > thr2);
                                 }
-#endif
+                                }
                             } else {
 #pragma unroll 1
                                 for (int b = 0; b < nq; b += 2) {
