@@ -127,6 +127,7 @@ template <typename T> struct StepArgs {
     // externally decoded schedule per env (clothhip_run). By pointer, not by value: kernel arguments are invariant loads
     // that the compiler hoists to the kernel entry and keeps in SGPRs across the substep loop, which has none to spare.
     const struct FusedArgs<T> *fz;
+    int32_t e0;              // env of workgroup 0: a time-sliced episode launch over more cloths than are resident goes out as one launch per generation (launch_run)
 };
 
 constexpr int KEY_SHIFT = 12;

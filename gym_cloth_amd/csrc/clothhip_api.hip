@@ -711,6 +711,7 @@ extern "C" int clothhip_pin_points(clothhip_handle *h, int32_t env, const int32_
 
 template <typename T> static StepArgs<T> make_args(clothhip_handle *h, const ClothSchedule *d_sched) {
     StepArgs<T> a;
+    a.e0 = 0;
     a.pos = (T *)h->d_pos; a.prev = (T *)h->d_prev; a.cnt = h->d_cnt; a.rest = (const T *)h->d_rest;
     a.tear = h->d_tear; a.executed = h->d_exec; a.stats = h->d_stats; a.sched = d_sched;
     a.gather = h->d_gather; a.wt_ent = h->d_wt_ent; a.wt_dep = h->d_wt_dep; a.nW = h->wt.nW; a.wt_rshift = h->wt.reach_shift; a.cell_copy = h->cell_copy;
@@ -793,13 +794,24 @@ static int cached_occupancy(clothhip_handle *h, const void *fn, int nt) {
 }
 
 // (the caller has run lean_refresh(h) -- which of the handle's two layouts may run now -- BEFORE recording its start event)
-template <typename T, int FUSED> static void launch_run(clothhip_handle *h, const ClothSchedule *d_sched, const void *d_fz) {
+// `by_generation` (the time-sliced episode launches): every workgroup runs for the same time slice, counted from its own start, so a batch of
+// more cloths than are resident runs in generations -- which go out as ONE LAUNCH EACH, in stream order. Left to the hardware's
+// dispatcher the generations of a single launch change hands on every CU within a few dozen microseconds, and now and then a CU
+// that has just lost both of its workgroups takes only one new one for the whole slice (measured on 1 024 cloths of 50x50, two per
+// CU at 79.9 KB of LDS and 4 x 128 VGPRs per SIMD: in 3 launches of 8 one workgroup of the 1 024 started only when the second
+// generation had ended, 2 400 instead of 1 600 ms -- tools/placement.py, profiles/r05_placement.txt). A fresh launch finds every CU empty.
+template <typename T, int FUSED> static void launch_run(clothhip_handle *h, const ClothSchedule *d_sched, const void *d_fz, bool by_generation = false) {
     StepArgs<T> a = make_args<T>(h, d_sched);
     a.fz = (const FusedArgs<T> *)d_fz;
+    a.e0 = 0;
 #define X(T_, NT, PPT, TAB, RR)                                                                         \
     if (h->nt == NT && h->ppt == PPT && h->tab == TAB && h->rest_reg == RR) {                           \
-        hipLaunchKernelGGL((k_run_schedule<T_, NT, PPT, TAB, RR, FUSED>), dim3(h->E), dim3(NT), h->lds_bytes, h->stream, a); \
         const int occ_ = cached_occupancy(h, (const void *)k_run_schedule<T_, NT, PPT, TAB, RR, FUSED>, NT);    \
+        const int cap_ = by_generation && occ_ > 0 && h->n_cus > 0 && !getenv("CLOTHHIP_DEBUG_ONE_LAUNCH") ? occ_ * h->n_cus : h->E;   \
+        for (int e0_ = 0; e0_ < h->E; e0_ += cap_) {                                                    \
+            a.e0 = e0_;                                                                                 \
+            hipLaunchKernelGGL((k_run_schedule<T_, NT, PPT, TAB, RR, FUSED>), dim3(std::min(cap_, h->E - e0_)), dim3(NT), h->lds_bytes, h->stream, a); \
+        }                                                                                               \
         const int32_t v_[10] = {NT, PPT, TAB, RR ? 1 : 0, v_lean(TAB, RR, (int)sizeof(T_)) ? 1 : 0, FUSED, h->lds_bytes, occ_, h->n_cus, sizeof(T_) == 4 ? 1 : 0}; \
         memcpy(h->last_variant, v_, sizeof(v_)); h->have_variant = true;                                \
         return;                                                                                         \
@@ -1049,10 +1061,10 @@ extern "C" int clothhip_run_actions_begin(clothhip_handle *h, const ClothEpisode
     if (h->relaxed) launch_relaxed(h, h->d_fz);
     else
     if (tier2 || policy == CLOTHHIP_POLICY_HIGHEST_POINT) {   // the variant that also carries the tier-2 reset code and the cold policies
-        if (h->precision == CLOTHHIP_F64) launch_run<double, 2>(h, h->d_sched, h->d_fz);
-        else launch_run<float, 2>(h, h->d_sched, h->d_fz);
-    } else if (h->precision == CLOTHHIP_F64) launch_run<double, 1>(h, h->d_sched, h->d_fz);
-    else launch_run<float, 1>(h, h->d_sched, h->d_fz);
+        if (h->precision == CLOTHHIP_F64) launch_run<double, 2>(h, h->d_sched, h->d_fz, budget_ticks != 0);
+        else launch_run<float, 2>(h, h->d_sched, h->d_fz, budget_ticks != 0);
+    } else if (h->precision == CLOTHHIP_F64) launch_run<double, 1>(h, h->d_sched, h->d_fz, budget_ticks != 0);
+    else launch_run<float, 1>(h, h->d_sched, h->d_fz, budget_ticks != 0);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipEventRecord(h->ev1, h->stream));
     h->have_timing = true;

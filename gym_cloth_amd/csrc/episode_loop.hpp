@@ -57,7 +57,7 @@ constexpr int v_waves_per_eu(int NT, int TAB, bool lean, int PPT = 0) {      // 
 template <typename T, int NT, int PPT, int TAB, bool REST_REG, int FUSED>
 __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (int)sizeof(T)), PPT)) void k_run_schedule(StepArgs<T> A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int e = blockIdx.x;
+    const int e = blockIdx.x + A.e0;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     // fz == nullptr: ONE externally decoded schedule per env (clothhip_run). Otherwise: nT whole ClothEnv.step calls per env with
@@ -173,6 +173,9 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
     unsigned long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0, tstart = 0;
 #endif
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tstart)::"memory");   // whole-schedule clock of this cloth (stats[15])
+#ifdef CLOTHHIP_DIAG_PLACEMENT
+    const unsigned long long diag_t0_ = __builtin_amdgcn_s_memrealtime();
+#endif
 #ifdef CLOTHHIP_PHASE_STAMPS                 // profiling build (make stamps): phase mask bit 32 turns the stamps on
     const bool timing = (pm & PH_TIME) != 0;
 #else
@@ -368,6 +371,13 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
                 unsigned long long tend;
                 asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tend)::"memory");
                 A.stats[16 * e + 15] = (int)((tend - tstart) >> 10);   // shader clocks / 1024 this cloth's schedule took
+#endif
+#ifdef CLOTHHIP_DIAG_PLACEMENT          // dev: where and when this workgroup ran (tools/placement.py)
+                unsigned hw_, xcc_;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));
+                A.stats[16 * e + 12] = (int)xcc_; A.stats[16 * e + 13] = (int)hw_;
+                A.stats[16 * e + 14] = (int)(diag_t0_ & 0x7fffffffull); A.stats[16 * e + 11] = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffffull);
 #endif
             }
         }

@@ -170,3 +170,32 @@ def test_relaxed_order_companion_runs_and_is_labelled(monkeypatch):
     with pytest.raises(ClothHipError):
         env.step_many(_bench_actions(4, 1), auto_reset=False)
     env.close()
+
+
+def test_time_sliced_launch_goes_out_per_generation_and_equals_the_single_launch(monkeypatch):
+    """A time-sliced episode launch over more cloths than are resident is issued as one launch per generation (launch_run: workgroup
+    0 of a launch is env `e0`): 1 100 cloths at two per CU = 512 + 512 + 76. With a slice long enough for every action the result
+    must equal the single launch over all workgroups (CLOTHHIP_DEBUG_ONE_LAUNCH) bit for bit -- records, observations, particles."""
+    for v in DEBUG_VARS:
+        monkeypatch.delenv(v, raising=False)
+    monkeypatch.setenv("CLOTHHIP_DEBUG_LEAN", "8")                   # the eight-wave build: two cloths per CU whatever the batch size
+    E, T = 1100, 2
+    acts = _bench_actions(E, T)
+    runs = []
+    for one_launch in (False, True):
+        if one_launch:
+            monkeypatch.setenv("CLOTHHIP_DEBUG_ONE_LAUNCH", "1")
+        cfg, env = _bench_env(E, 25, "tier1", "f32")
+        out = env.step_many(acts, auto_reset=True, time_budget_ms=120000.0)
+        var = env.batch.last_variant()
+        assert out["ran"].all()
+        runs.append((var, out["rew"].copy(), out["executed"].copy(), out["done"].copy(), out["actual_coverage"].copy(), out["obs"].copy(),
+                     out["reset_before"].copy(), [x.copy() for x in env.batch.get_state()]))
+        env.close()
+    (va, *a), (vb, *b) = runs
+    assert va["threads"] == 512 and va["cloths_per_cu"] == 2 and va == vb, (va, vb)
+    assert a[1].sum() > 200 * E
+    for x, y in zip(a[:6], b[:6]):
+        assert np.array_equal(x, y, equal_nan=True)
+    for x, y in zip(a[6], b[6]):
+        assert np.array_equal(x, y)
