@@ -401,6 +401,9 @@ def _run_workload(n_side, E, precision, init, mode, steps, warmup, fuse_max, ran
                          "kernel": "k_run_schedule", "kernel_ms_avg": stat["kms"] / max(stat["launches"], 1),
                          "kernel_ms_in_actions_avg": kms_act / max(stat["launches"], 1),
                          "launches": stat["launches"], "alg_bytes_per_substep": b_alg,
+                         # a time-sliced launch over more cloths than are resident is issued as one kernel dispatch per generation
+                         # (clothhip_api.hip launch_run): kernel_ms_avg spans them all, rocprofv3 lists them one by one
+                         "dispatches_per_launch": (-(-E // max(n_conc, 1)) if mode == "fused" else 1),
                          "frac_on_fp32_bytes": (stat["act_sub"] * b_alg32 / 1e9) / (kms_act / 1e3) / HBM_PEAK_GBS if kms_act > 0 else 0.0,
                          "achieved_blended": ach_blended, "frac_blended": ach_blended / HBM_PEAK_GBS,
                          "substeps_per_launch": stat["sub"] / max(stat["launches"], 1),

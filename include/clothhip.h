@@ -255,6 +255,9 @@ typedef struct ClothResetRecord {
  * other state-changing call on the handle (set_state, reset_flat, grab*, run*, update) drops the operations in flight.
  * Which launch executes an action never changes its result (envs are independent); only the partition
  * of an env's action sequence into launches depends on timing. 0 = every env executes all T slots.
+ * The slice counts from each cloth's own start: a batch of more cloths than the device holds at once runs in generations,
+ * each of them a kernel dispatch of its own on the handle's stream (the call is still one call, and
+ * clothhip_last_kernel_ms spans all of them).
  * Returns CLOTHHIP_ESTATE when the handle's variant cannot run fused (per-env rest tables with reset scripts,
  * non-25x25 oracle policy, grid too large for the in-kernel metrics). Synchronous. */
 /* Resets drawn ON THE DEVICE (the _begin/_end form only): instead of `scripts`, pass rng_states[E][626] = every env's

@@ -105,8 +105,17 @@ def main():
             return
         tb = json.loads(txt[-1])
         nl = int(tb.get("roofline", {}).get("launches", 0) or 0)
-        fk = per_dispatch(os.path.join(src, prefix + "FETCH_SIZE")).get("FETCH_SIZE")
-        wk = per_dispatch(os.path.join(src, prefix + "WRITE_SIZE")).get("WRITE_SIZE")
+        g_ = int(tb.get("roofline", {}).get("dispatches_per_launch", 1) or 1)      # one kernel dispatch per generation of a time-sliced launch
+
+        def grouped(v):
+            # per LAUNCH: the launch's consecutive dispatches summed (counted from the end: calibration / warm-up launches come first)
+            if not v or g_ <= 1:
+                return v
+            v = list(v)[len(v) % g_:]
+            return [sum(v[i:i + g_]) for i in range(0, len(v), g_)]
+        pd_ = lambda d: {k_: grouped(v_) for k_, v_ in per_dispatch(d).items()}      # noqa: E731
+        fk = pd_(os.path.join(src, prefix + "FETCH_SIZE")).get("FETCH_SIZE")
+        wk = pd_(os.path.join(src, prefix + "WRITE_SIZE")).get("WRITE_SIZE")
         if not (nl and fk and wk and len(fk) >= nl and len(wk) >= nl):
             return
         # the timed launches of every pass of the counter, pooled; the per-launch figure is their (lower) median and a dispatch
@@ -116,7 +125,7 @@ def main():
             vals = list(first[-nl:])
             if prefix == "pmc_":
                 for d in sorted(glob.glob(os.path.join(src, "pmcrep*_" + cname)) + glob.glob(os.path.join(src, "pmcx*_" + cname + "_*"))):
-                    v = per_dispatch(d).get(cname)
+                    v = pd_(d).get(cname)
                     if v and len(v) >= nl:
                         vals += v[-nl:]
             med = sorted(vals)[(len(vals) - 1) // 2]
