@@ -195,7 +195,8 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
     constexpr bool SWEEP_LEAN = false;  // (the sweep-stamps and census builds instrument strain_sweep)
 #endif
 #ifndef CLOTHHIP_SWEEP_AHEAD_MIN_TAB
-#define CLOTHHIP_SWEEP_AHEAD_MIN_TAB -2     // TAB below this (the build for six cloths per CU: 1 536 cloths 33.8 -> 34.2 M/s; five per CU: +-0): the lean walk without its read-ahead
+#define CLOTHHIP_SWEEP_AHEAD_MIN_TAB 1      // TAB below this (the four-wave builds for three to six cloths per CU: 768 cloths 24.9 -> 25.2 M/s, 1 024: 31.4 -> 31.7, 1 280: +-0,
+                                            // 1 536: 33.8 -> 34.2): the lean walk without its read-ahead; the eight-wave headline build loses 2.8 % without it
 #endif
     constexpr bool SWEEP_AHEAD = TAB >= CLOTHHIP_SWEEP_AHEAD_MIN_TAB;
 #ifndef CLOTHHIP_PRECHECK2_MAX_TAB
