@@ -277,7 +277,11 @@ __device__ __forceinline__ int strain_sweep_lean(Pt<T> *cur, const WEnt<T> *wt, 
                 for (;;) {
                     // a spring is VALID when none of its (transitive) predecessors in the window is over-stretched now (strain_sweep)
                     const bool bad = ((dlo & (uint32_t)tb) | (dhi & (uint32_t)(tb >> 32))) != 0u;
+#ifdef CLOTHHIP_COUNT_SPRINGS        // dev (profiling builds): count the SPRINGS a pass corrects instead of the correcting passes
+                    if (STATS) st_commits += __builtin_popcountll(ballot64(trig & !bad));
+#else
                     if (STATS) st_commits++;
+#endif
                     if (trig & !bad) {
                         if (len > c.rest * tth) tear = 1;                               // :272 (tear implies stretch here)
                         const T ux = dev_div<T>(dx, len), uy = dev_div<T>(dy, len), uz = dev_div<T>(dz, len);   // :276-278
