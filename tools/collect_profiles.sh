@@ -8,7 +8,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 T="timeout -k 10 900"                      # (-k: a python child that ignores the signal is killed, not left holding the GPU)
 HEAD="--no-extra --no-cpu-baseline"        # the headline configuration only (512 cloths, fp32, fused time slices)
-# STAGES="bench trace traffic writerep l2 sq sq2 phases census action n50 ablation" selects stages (default: all)
+# STAGES="bench trace traffic writerep l2 sq sq2 phases census action large n50 ablation" selects stages (default: all)
 want() { [[ -z "${STAGES:-}" || " $STAGES " == *" $1 "* ]]; }
 if want bench; then
 # 0. the full default bench line (what the driver runs), untraced
@@ -81,6 +81,12 @@ $T python3 tools/phase_profile.py --precision f64 > "$OUT/phase_f64.txt" 2>&1
 if [ -f gym_cloth_amd/libclothhip_sweepstamps.so ]; then
   CLOTHHIP_LIB=$PWD/gym_cloth_amd/libclothhip_sweepstamps.so CLOTHHIP_DEBUG_PHASES=47 $T python3 tools/phase_profile.py > "$OUT/sweepstamps_f32.txt" 2>&1
 fi
+fi
+if want large; then
+# 5b. kernel trace of the large-batch companions: 1 536 cloths (six per CU, one generation) and 2 048 (four per CU: two generations, one dispatch each)
+for E in 1536 2048; do
+  $T rocprofv3 --kernel-trace --stats -d "$OUT/trace$E" -o run -- python3 bench.py $HEAD --envs $E --steps 10 --fuse 5 > "$OUT/bench${E}_traced.json" 2> "$OUT/trace$E.log"
+done
 fi
 if want n50; then
 # 6. rocprofv3 trace of the 50x50 companion (configs[4]) alone

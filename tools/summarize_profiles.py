@@ -159,6 +159,21 @@ def main():
         p = os.path.join(src, nm)
         if os.path.exists(p):
             shutil.copy(p, dst + to)
+    for tag in ("1536", "2048"):
+        cl = db_of(os.path.join(src, "trace" + tag))
+        if cl is None:
+            continue
+        with open(dst + "_%s_cloths_dispatches.csv" % tag, "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["Name", "DurationMs", "Workgroups", "WorkgroupSize", "LdsBytes", "ScratchBytes"])
+            for r in cl.execute("select name, duration, grid_x, workgroup_x, lds_size, scratch_size from kernels where name like '%k_run_schedule%' order by start").fetchall():
+                w.writerow([r[0], "%.3f" % (r[1] / 1e6), int(r[2] // max(r[3], 1)), r[3], r[4], r[5]])
+            try:
+                tb_ = json.loads([l for l in open(os.path.join(src, "bench%s_traced.json" % tag)).read().splitlines() if l.startswith("{")][-1])
+                w.writerow(["bench.py of the same run: launches %d x dispatches_per_launch %d, roofline.kernel_ms_avg %.3f ms (spans a launch's dispatches), blended %.3f M substeps/s" %
+                            (tb_["roofline"]["launches"], tb_["roofline"]["dispatches_per_launch"], tb_["roofline"]["kernel_ms_avg"], tb_["config"]["blended_substeps_per_s"] / 1e6)])
+            except (OSError, ValueError, KeyError, IndexError):
+                pass
     c50 = db_of(os.path.join(src, "trace50"))
     if c50 is not None:
         rows = c50.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels "
