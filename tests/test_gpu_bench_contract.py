@@ -39,6 +39,7 @@ def test_bench_line_contract_small_batch():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert abs(r["achieved"] - 1e-9 * r["alg_bytes_per_substep"] * r["action_substeps_per_launch"] / (1e-3 * r["kernel_ms_in_actions_avg"])) <= 1e-6 * r["achieved"]
     assert r["alg_bytes_per_substep"] == 49 * 625 and r["launches"] == 2 and r["kernel_ms_avg"] > 0
+    assert r["dispatches_per_launch"] == 1                                   # (64 cloths: one generation of workgroups per launch)
     assert (r["traffic"] is None) == (r["traffic_source"] is None)        # (64 cloths: no committed PMC record -> null, and said so)
     assert b["kind"] == "port" and b["cores"] >= 1 and b["value"] > 0 and "sample" in b and b["unit"] == "cloth-substeps/s"
     assert "k_run_schedule<float,512,2,2,true,1>" in c["variant"]
