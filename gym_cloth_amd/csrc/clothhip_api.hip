@@ -217,7 +217,7 @@ static const void *stepper_fn(const clothhip_handle *h, int fused);
 static bool fit_scratch(clothhip_handle::Layout &L, int tsz, int Ppad, int Spad, int P, int budget) {
     int NS = 1; while (NS < P) NS <<= 1;
     const LdsLayout lay(tsz, Ppad, Spad, L.HT, L.tab == 2 ? 2 : (v_ldstab(L.tab) ? 1 : 0), L.cell_copy);
-    L.scratch_need = metrics_scratch_bytes(NS, Ppad + 8, tsz, v_hull_idx(L.tab));
+    L.scratch_need = metrics_scratch_bytes(NS, Ppad + 8, tsz, v_hull_idx(L.tab, tsz, L.nt, L.ppt));
     if (L.lds_bytes < lay.total) L.lds_bytes = lay.total;
     if (L.lds_bytes - lay.hkey < L.scratch_need && lay.hkey + L.scratch_need <= budget) L.lds_bytes = (lay.hkey + L.scratch_need + 15) / 16 * 16;
     L.scratch_have = L.lds_bytes - lay.hkey;
@@ -924,7 +924,7 @@ static int grow(void **p, size_t *cap, size_t need) {
 static int fused_scratch(const clothhip_handle *h, int *need_out) {
     int NS = 1; while (NS < h->P) NS <<= 1;
     const int NH = h->Ppad + 8;
-    *need_out = metrics_scratch_bytes(NS, NH, (int)h->tsz, v_hull_idx(h->tab));
+    *need_out = metrics_scratch_bytes(NS, NH, (int)h->tsz, v_hull_idx(h->tab, (int)h->tsz, h->nt, h->ppt));
     const LdsLayout lay((int)h->tsz, h->Ppad, h->Spad, h->HT, h->tab == 2 ? 2 : (v_ldstab(h->tab) ? 1 : 0), h->cell_copy);
     return h->lds_bytes - lay.hkey;
 }

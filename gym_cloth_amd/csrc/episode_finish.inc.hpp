@@ -29,7 +29,7 @@
                 auto src = [&](int i, double &x, double &y, double &z) { const Pt<T> c = cur[i]; x = (double)c.x; y = (double)c.y; z = (double)c.z; };
                 // (the sort buffers and the hull stack live BEHIND the window table -- hash table, member lists, cell-ordered copy: all
                 //  rebuilt below --, so the table itself stays in LDS for the whole launch and is not re-read from L2 after every action)
-                metrics_block<NT, T, decltype(src), v_hull_idx(TAB)>(src, P, F.NS, F.NH, smem + lay.hkey, tid, F.half_thickness, mo);
+                metrics_block<NT, T, decltype(src), v_hull_idx(TAB, (int)sizeof(T), NT, PPT)>(src, P, F.NS, F.NH, smem + lay.hkey, tid, F.half_thickness, mo);
                 init_lds(tear_now, nullptr, nullptr);
                 __syncthreads();
             }

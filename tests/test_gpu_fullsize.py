@@ -99,9 +99,10 @@ def test_full_batch_bench_step_f64_sample_matches_oracle(E, n_side, tier, oracle
         out = env.step_many(acts, auto_reset=False)                  # ONE bench step of the whole batch, episode-launch kernel
         ex = out["executed"][0]
         assert out["ran"][0].all()
-    else:                                                            # fp64 50x50: the in-kernel metrics' fp64 sort buffers do not fit in
-        env.step(acts[0], auto_reset=False)                          # LDS -- bench.py runs this configuration in its step mode too
+    else:                                                            # (a grid whose in-kernel metrics do not fit the CU's LDS: none of the
+        env.step(acts[0], auto_reset=False)                          #  benched ones since the fp64 large-grid variants keep the hull stack as indices)
         ex = env.last_executed.copy()
+    assert env.batch.fused_supported                                 # 512 x 25x25 and 1 024 x 50x50 alike
     var = env.batch.last_variant()
     assert var["precision"] == "f64" and not var["lean"] and (var["fused"] >= 1) == bool(env.batch.fused_supported), var
     if var["n_cus"] == 256:

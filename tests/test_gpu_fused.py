@@ -363,15 +363,17 @@ def test_highest_point_policy_on_the_device_equals_the_host_policy(tier):
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("variant", ["force_grab", "no_clip", "grid50_f32"])
+@pytest.mark.parametrize("variant", ["force_grab", "no_clip", "grid50_f32", "grid50_f64"])
 def test_step_many_equals_sequential_other_configurations(variant):
     """The episode launch against sequential step() calls in configurations the other tests do not touch: force_grab (the
     in-kernel radius-growing loop, cloth_env.py:434-444), clip_act_space off (actions and reset pulls in world units, the
     out-of-bounds action penalty computed from the recorded action), and the 50x50 grid in fp32 (the 512-thread x 5-particle
-    variant with float sort keys in the in-kernel metrics; same kernel arithmetic on both paths, so identical results)."""
+    variant with float sort keys in the in-kernel metrics; same kernel arithmetic on both paths, so identical results), and in
+    fp64 (BASELINE configs[4] in the reference's arithmetic: the in-kernel metrics keep their hull stack as indices there -- 71 KB of
+    LDS scratch instead of 107 KB -- and must give the bits of the stand-alone metrics kernel the step path runs)."""
     import bench
     from gym_cloth_amd.envs import ClothVecEnv
-    n_side, prec, E, T = (50, "f32", 3, 2) if variant == "grid50_f32" else (25, "f64", 8, 3)
+    n_side, prec, E, T = (50, "f32", 3, 2) if variant == "grid50_f32" else ((50, "f64", 3, 2) if variant == "grid50_f64" else (25, "f64", 8, 3))
     cfg = bench.bench_cfg(n_side, 0.02 if n_side == 25 else 0.0095)
     if variant == "force_grab":
         cfg["env"]["force_grab"] = True
@@ -385,6 +387,7 @@ def test_step_many_equals_sequential_other_configurations(variant):
         v.reset()
         envs.append(v)
     a, b = envs
+    assert b.batch.fused_supported
     lo, hi = (-1.2, 1.2) if variant != "no_clip" else (-0.3, 1.3)       # some actions outside the action space
     acts = np.stack([np.random.RandomState(2000 + e).uniform(lo, hi, size=(T, 4)) for e in range(E)], axis=1)
     seq = [a.step(acts[t], auto_reset=True) for t in range(T)]
