@@ -48,9 +48,9 @@ __host__ __device__ inline uint32_t lean_valid_mask(int r, int c, int N) {
 constexpr bool v_lean(int TAB, bool RR, int tsz) { return (TAB <= 0 || TAB == 2 || TAB == 3 || TAB == 4) && RR && tsz == 4; }
 constexpr bool v_ldstab(int TAB) { return TAB == 1 || TAB == 2; }
 // the in-kernel metrics' hull stack as u16 indices (same arithmetic, an eighth of the LDS): the variants whose LDS is tight -- two large-grid
-// cloths per CU, five / six 25x25 cloths per CU, and the fp64 instantiation of the large grids (50x50: 71 KB of scratch instead of 107 KB,
-// which is what lets its episode launches exist at all)
-constexpr bool v_hull_idx(int TAB, int tsz = 4, int NT = 0, int PPT = 0) { return TAB == 4 || TAB <= -2 || (tsz == 8 && NT * PPT > 1024); }
+// cloths per CU, five / six 25x25 cloths per CU, the fp64 instantiation of the large grids (50x50: 71 KB of scratch instead of 107 KB,
+// which is what lets its episode launches exist at all) and the 1024 x 4 variants (64x64)
+constexpr bool v_hull_idx(int TAB, int tsz = 4, int NT = 0, int PPT = 0) { return TAB == 4 || TAB <= -2 || (tsz == 8 && NT * PPT > 1024) || NT * PPT >= 4096; }
 constexpr int v_waves_per_eu(int NT, int TAB, bool lean, int PPT = 0) {      // __launch_bounds__' second argument: waves per SIMD
     if (!lean && NT == 512 && PPT == 2) return 4;                // eight waves per cloth, two cloths per CU (standard arithmetic)
     if (!lean || TAB == 3) return NT <= 512 ? 2 : NT / 256;

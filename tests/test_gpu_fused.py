@@ -363,7 +363,7 @@ def test_highest_point_policy_on_the_device_equals_the_host_policy(tier):
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("variant", ["force_grab", "no_clip", "grid50_f32", "grid50_f64"])
+@pytest.mark.parametrize("variant", ["force_grab", "no_clip", "grid50_f32", "grid50_f64", "grid64_f32"])
 def test_step_many_equals_sequential_other_configurations(variant):
     """The episode launch against sequential step() calls in configurations the other tests do not touch: force_grab (the
     in-kernel radius-growing loop, cloth_env.py:434-444), clip_act_space off (actions and reset pulls in world units, the
@@ -373,8 +373,8 @@ def test_step_many_equals_sequential_other_configurations(variant):
     LDS scratch instead of 107 KB -- and must give the bits of the stand-alone metrics kernel the step path runs)."""
     import bench
     from gym_cloth_amd.envs import ClothVecEnv
-    n_side, prec, E, T = (50, "f32", 3, 2) if variant == "grid50_f32" else ((50, "f64", 3, 2) if variant == "grid50_f64" else (25, "f64", 8, 3))
-    cfg = bench.bench_cfg(n_side, 0.02 if n_side == 25 else 0.0095)
+    n_side, prec, E, T = {"grid50_f32": (50, "f32", 3, 2), "grid50_f64": (50, "f64", 3, 2), "grid64_f32": (64, "f32", 2, 2)}.get(variant, (25, "f64", 8, 3))
+    cfg = bench.bench_cfg(n_side, 0.02 if n_side == 25 else (0.0095 if n_side == 50 else 0.007))     # (64x64: the largest grid, the 1024 x 4 variant)
     if variant == "force_grab":
         cfg["env"]["force_grab"] = True
     if variant == "no_clip":
