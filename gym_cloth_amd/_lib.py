@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("CLOTHHIP_LIB") or os.path.join(_HERE, "libclothhip.so
 
 F64, F32 = 0, 1
 REST_SHARED, KEEP_TEAR = 1, 2           # clothhip_set_state flags
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 OK, EINVAL, ENODEV, EHIP, ENOMEM, ESTATE = 0, -1, -2, -3, -4, -5
 
@@ -130,6 +130,8 @@ SYMBOLS = [
     ("clothhip_last_kernel_ms", C.c_double, [_vp]),
     ("clothhip_debug_stats", C.c_int, [_vp, _i32p]),
     ("clothhip_last_variant", C.c_int, [_vp, _i32p]),
+    ("clothhip_last_dispatches", C.c_int, [_vp, _i32p]),
+    ("clothhip_set_relaxed_order", C.c_int, [_vp, C.c_int32]),
     ("clothhip_selftest_windows", C.c_int, [_PP, _i32p, _i32p, _i32p, _i32p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_int32]),
     ("clothhip_selftest_layout", C.c_int, [_PP, C.c_int32, C.c_int32, C.c_int32, _i32p, C.c_int32]),
     ("clothhip_selftest_rng", C.c_int, [_vp, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, _dp]),

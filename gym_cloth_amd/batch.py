@@ -354,7 +354,15 @@ class ClothBatch(object):
                  fused=int(v[5]), lds_bytes=int(v[6]), cloths_per_cu=int(v[7]), n_cus=int(v[8]), precision="f32" if v[9] else "f64")
         d["name"] = "k_run_schedule<%s,%d,%d,%d,%s,%d>%s: %d B LDS, %d cloths per CU" % (
             "float" if v[9] else "double", v[0], v[1], v[2], "true" if v[3] else "false", v[5], " (LEAN)" if v[4] else "", v[6], v[7])
+        n = np.zeros(1, dtype=np.int32)
+        check(self._L.clothhip_last_dispatches(self._h, _lib.i32p(n)))
+        d["dispatches"] = int(n[0])            # kernel dispatches the launch went out as (one per generation of a time-sliced launch)
         return d
+
+    def set_relaxed_order(self, on=True):
+        """MEASUREMENT ONLY (bench.py's labelled companion): this handle's episode launches run the relaxed-order kernel -- Jacobi
+        self-collision, coloured strain limit; NOT the reference's trajectories (clothhip_set_relaxed_order). Per handle."""
+        check(self._L.clothhip_set_relaxed_order(self._h, 1 if on else 0))
 
     @property
     def last_kernel_ms(self):

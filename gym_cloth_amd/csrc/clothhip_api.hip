@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "cloth_kernels.hpp"
+#include "stepper_variants.hpp"
 #include "lean_rates.hpp"
 #include "cloth_render.hpp"
 
@@ -68,7 +69,8 @@ struct clothhip_handle {
     // It needs ONE shared rest table whose fp32 values are one per spring type (checked on the device's table whenever that table
     // may have changed) and the regular gather stencil (checked once); otherwise the (0, false) variant runs on the same layout.
     bool lean = false, lean_dirty = true, lean_ok = false, lean_stencil_ok = false;
-    bool relaxed = false;   // CLOTHHIP_RELAXED_ORDER=1 at create: the episode launches run the relaxed-order companion kernel (bench only, no parity)
+    bool relaxed = false;   // clothhip_set_relaxed_order(h, 1): THIS handle's episode launches run the relaxed-order companion kernel (bench only, no parity)
+    int last_dispatches = 0; // kernel dispatches the last stepper launch was issued as (clothhip_last_dispatches)
     int lean_r = 3;         // cloths per CU the chosen LEAN build is compiled for (3: 168 VGPRs, 4: 128 VGPRs; 2: eight waves per cloth, table in LDS; 1: the large grids)
     float pal[3] = {0, 0, 0};
     int32_t last_variant[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // what the last launch ran (clothhip_last_variant)
@@ -224,10 +226,18 @@ static bool fit_scratch(clothhip_handle::Layout &L, int tsz, int Ppad, int Spad,
     return L.scratch_have >= L.scratch_need;
 }
 
+// LDS a workgroup may use when r workgroups are to share a CU: LDS is allocated in granules of 1 280 bytes on gfx950 (128 granules = the CU's
+// 160 KiB), so r cloths fit when each takes at most floor(128 / r) granules -- 160 KiB / r overstates that for r = 3, 5, 6.
+static constexpr int LDS_GRANULE = 1280;
+static constexpr int lds_budget(int r) { return (128 / (r < 1 ? 1 : r)) * LDS_GRANULE; }
+static_assert(lds_budget(1) == 160 * 1024 && lds_budget(2) == 80 * 1024 && lds_budget(4) == 40 * 1024, "granule arithmetic");
+
 // Which stepper variant and which LDS layout a handle runs: pure host logic (no HIP call), so that the CPU test suite can sweep it
 // over grid sizes and precisions (clothhip_selftest_layout). Fills nt / ppt / HT / tab / rest_reg / cell_copy / lds_bytes, the
 // standard layout lay_std and, where the LEAN arithmetic applies, lay_lean + lean_r.
-static void plan_layouts(clothhip_handle *h, int cus, const std::vector<uint32_t> &gather) {
+// max_r: the highest residency the pick may choose (clothhip_create lowers it when the device's occupancy query grants the chosen LEAN
+// build fewer workgroups per CU than it was planned for).
+static void plan_layouts(clothhip_handle *h, int cus, const std::vector<uint32_t> &gather, int max_r = 6) {
     // threads per cloth x particles per thread (compile-time variants of the stepper)
     // P <= 768 (the 25x25 class, two cloths per CU): EIGHT waves per cloth -- 512 threads x 2 particles, compiled for 128 VGPRs: the cell
     // sweeps have eight ticket takers and the parallel phases two waves per SIMD to hide their LDS latency (+4 % fp32 standard
@@ -246,7 +256,7 @@ static void plan_layouts(clothhip_handle *h, int cus, const std::vector<uint32_t
         const int tsz = (int)h->tsz;
         const int precision = h->precision;
         // 256-thread variants: two cloths per CU (<= 80 KiB each); the larger ones own the CU (<= 160 KiB)
-        const int budget = small_grid ? 80 * 1024 : 160 * 1024;
+        const int budget = small_grid ? lds_budget(2) : lds_budget(1);
         const int tmax = h->nt <= 512 ? 1 : 0;
         h->tab = (tmax >= 1 && LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 1, 0).total <= budget) ? 1 : 0;
         if (const char *t = getenv("CLOTHHIP_DEBUG_TAB_LDS")) h->tab = std::min(h->tab, atoi(t));
@@ -265,9 +275,9 @@ static void plan_layouts(clothhip_handle *h, int cus, const std::vector<uint32_t
             const bool lean_able = small_grid && precision == CLOTHHIP_F32;
             const double rate[5] = {lean_able ? LEAN_RATE_2_PER_CU_8W : 1.0, LEAN_RATE_3_PER_CU, LEAN_RATE_4_PER_CU, LEAN_RATE_5_PER_CU, LEAN_RATE_6_PER_CU};
             double best = 0.0; int best_r = 2;
-            for (int r = 2; r <= 6; r++) {
+            for (int r = 2; r <= std::max(2, std::min(6, max_r)); r++) {
                 // (r >= 3: the four-wave LEAN layout, table streamed, must fit r times in the CU's LDS -- 27x27 does not at five per CU)
-                if (r >= 3 && (!lean_able || (long)LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, 0).total * r > 160 * 1024)) continue;
+                if (r >= 3 && (!lean_able || LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, 0).total > lds_budget(r))) continue;
                 const double v = rate[r - 2] / (double)((h->E + r * cus - 1) / (r * cus));
                 if (v > best * 1.02) { best = v; best_r = r; }
             }
@@ -322,7 +332,7 @@ static void plan_layouts(clothhip_handle *h, int cus, const std::vector<uint32_t
         }
         h->lds_bytes = h->lay_std.lds_bytes;
         if (h->lean) {                                   // the lean layout: window table streamed from L2, 33 KB of LDS
-            int cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, 1).total <= (160 * 1024) / std::max(h->lean_r, 3) ? 1 : 0;
+            int cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, 1).total <= lds_budget(std::max(h->lean_r, 3)) ? 1 : 0;
             if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) cc = cc && atoi(t);
             h->lay_lean = {256, 3, h->lean_r >= 4 ? 3 - h->lean_r : 0, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, cc).total, h->HT, h->ht_bits};   // (r = 3, 4: four waves per cloth)
             if (h->lean_r == 2 && small_grid) {          // eight waves per cloth, two cloths per CU: the standard variant's LDS budget
@@ -349,7 +359,7 @@ static void plan_layouts(clothhip_handle *h, int cus, const std::vector<uint32_t
                 if (want2) { h->lay_lean = {512, 5, 4, true, 0, lds2, ht2, 0}; h->lean_r = 2; }
             }
             // the in-kernel metrics borrow the region behind the hash table (clothhip_fused_supported): it must hold them here too
-            const int lean_budget = h->lean_r == 1 ? 160 * 1024 : (h->lean_r == 2 ? 80 * 1024 : (160 * 1024) / h->lean_r);
+            const int lean_budget = lds_budget(h->lean_r);
             if (!fit_scratch(h->lay_lean, tsz, h->Ppad, h->Spad, h->P, lean_budget)) h->lean = false;
         }
     }
@@ -431,6 +441,19 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
         int cus = 256;
         if (hipGetDeviceProperties(&dp, device) == hipSuccess && dp.multiProcessorCount > 0) cus = dp.multiProcessorCount;
         plan_layouts(h, cus, gather);
+        // the pick assumed lean_r resident cloths per CU: ask the device (registers, LDS granules, what else it counts) and fall back to the
+        // best residency it does grant -- a build planned for r that runs at r - 1 would be slower than the build meant for r - 1
+        for (int guard = 0; guard < 5 && h->lean && h->lean_r >= 3 && !getenv("CLOTHHIP_DEBUG_LEAN"); guard++) {
+            const clothhip_handle::Layout keep = {h->nt, h->ppt, h->tab, h->rest_reg, h->cell_copy, h->lds_bytes};
+            h->nt = h->lay_lean.nt; h->ppt = h->lay_lean.ppt; h->tab = h->lay_lean.tab; h->rest_reg = h->lay_lean.rest_reg;
+            const void *fl = stepper_fn(h, 1);
+            h->nt = keep.nt; h->ppt = keep.ppt; h->tab = keep.tab; h->rest_reg = keep.rest_reg;
+            int occ = 0;
+            if (!fl || hipFuncSetAttribute(fl, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fl, h->lay_lean.nt, (size_t)h->lay_lean.lds_bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+            if (occ >= h->lean_r) break;
+            plan_layouts(h, cus, gather, std::max(2, occ));
+        }
         if (h->lds_bytes > 160 * 1024) { free_handle(h); return fail(CLOTHHIP_EINVAL, "n_side %d needs %d B of LDS (> 160 KiB)", h->N, h->lds_bytes); }
         if (h->lean) {                                   // the lean kernels too (which layout runs is decided per launch)
             const clothhip_handle::Layout keep = {h->nt, h->ppt, h->tab, h->rest_reg, h->cell_copy, h->lds_bytes};
@@ -442,8 +465,6 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
             }
             h->nt = keep.nt; h->ppt = keep.ppt; h->tab = keep.tab; h->rest_reg = keep.rest_reg;
         }
-        if (const char *t = getenv("CLOTHHIP_RELAXED_ORDER")) h->relaxed = atoi(t) != 0;
-        if (h->relaxed) HC(hipFuncSetAttribute((const void *)k_run_schedule<float, 512, 2, 2, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         const void *fn = stepper_fn(h, 0), *fnf = stepper_fn(h, 1), *fnf2 = stepper_fn(h, 2);
         if (!fn || !fnf || !fnf2) { free_handle(h); return fail(CLOTHHIP_EINVAL, "no stepper variant for n_side %d", h->N); }
         HC(hipFuncSetAttribute(fnf, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -752,22 +773,7 @@ static int lean_refresh(clothhip_handle *h) {
     return 0;
 }
 
-// compile-time variants: (threads per cloth, particles per thread) x tables-in-LDS level x rest-in-registers
-#ifdef CLOTHHIP_FAST_BUILD           // development builds: the 25x25-class variants only (make fast)
-#define CLOTH_VARIANTS(X, T) X(T, 512, 2, 1, false) X(T, 512, 2, 0, false) X(T, 256, 3, 1, true) X(T, 256, 3, 1, false) X(T, 256, 3, 0, false)
-#else
-#define CLOTH_VARIANTS(X, T)                                              \
-    X(T, 512, 2, 1, false) X(T, 512, 2, 0, false)                         \
-    X(T, 256, 3, 1, true) X(T, 256, 3, 1, false) X(T, 256, 3, 0, false)   \
-    X(T, 512, 5, 0, false) X(T, 512, 5, 1, false) X(T, 1024, 3, 0, false) X(T, 1024, 4, 0, false)
-#endif
-// the LEAN builds (fp32 only; 25x25 class: three / four cloths per CU, and eight waves per cloth at two per CU; the whole CU for the 512 x 5 grids)
-#ifdef CLOTHHIP_FAST_BUILD
-#define CLOTH_VARIANTS_LEAN(X, T) X(T, 256, 3, 0, true) X(T, 256, 3, -1, true) X(T, 256, 3, -2, true) X(T, 256, 3, -3, true) X(T, 512, 2, 2, true)
-#else
-#define CLOTH_VARIANTS_LEAN(X, T) X(T, 256, 3, 0, true) X(T, 256, 3, -1, true) X(T, 256, 3, -2, true) X(T, 256, 3, -3, true) X(T, 512, 2, 2, true) X(T, 1024, 3, 3, true) X(T, 1024, 4, 3, true) X(T, 512, 5, 4, true)
-#endif
-
+// (the compile-time variants -- CLOTH_VARIANTS, CLOTH_VARIANTS_LEAN -- and the object file each is compiled in: stepper_variants.hpp)
 template <typename T, int FUSED> static const void *stepper_fn_t(const clothhip_handle *h) {
 #define X(T_, NT, PPT, TAB, RR) \
     if (h->nt == NT && h->ppt == PPT && h->tab == TAB && h->rest_reg == RR) return (const void *)k_run_schedule<T_, NT, PPT, TAB, RR, FUSED>;
@@ -808,8 +814,9 @@ template <typename T, int FUSED> static void launch_run(clothhip_handle *h, cons
     if (h->nt == NT && h->ppt == PPT && h->tab == TAB && h->rest_reg == RR) {                           \
         const int occ_ = cached_occupancy(h, (const void *)k_run_schedule<T_, NT, PPT, TAB, RR, FUSED>, NT);    \
         const int cap_ = by_generation && occ_ > 0 && h->n_cus > 0 && !getenv("CLOTHHIP_DEBUG_ONE_LAUNCH") ? occ_ * h->n_cus : h->E;   \
+        h->last_dispatches = 0;                                                                         \
         for (int e0_ = 0; e0_ < h->E; e0_ += cap_) {                                                    \
-            a.e0 = e0_;                                                                                 \
+            a.e0 = e0_; h->last_dispatches++;                                                           \
             hipLaunchKernelGGL((k_run_schedule<T_, NT, PPT, TAB, RR, FUSED>), dim3(std::min(cap_, h->E - e0_)), dim3(NT), h->lds_bytes, h->stream, a); \
         }                                                                                               \
         const int32_t v_[10] = {NT, PPT, TAB, RR ? 1 : 0, v_lean(TAB, RR, (int)sizeof(T_)) ? 1 : 0, FUSED, h->lds_bytes, occ_, h->n_cus, sizeof(T_) == 4 ? 1 : 0}; \
@@ -828,6 +835,7 @@ static void launch_relaxed(clothhip_handle *h, const void *d_fz) {
     StepArgs<float> a = make_args<float>(h, h->d_sched);
     a.fz = (const FusedArgs<float> *)d_fz;
     hipLaunchKernelGGL((k_run_schedule<float, 512, 2, 2, true, 3>), dim3(h->E), dim3(512), h->lds_bytes, h->stream, a);
+    h->last_dispatches = 1;
     const int occ_ = cached_occupancy(h, (const void *)k_run_schedule<float, 512, 2, 2, true, 3>, 512);
     const int32_t v_[10] = {512, 2, 2, 1, 1, 3, h->lds_bytes, occ_, h->n_cus, 1};
     memcpy(h->last_variant, v_, sizeof(v_)); h->have_variant = true;
@@ -1056,7 +1064,7 @@ extern "C" int clothhip_run_actions_begin(clothhip_handle *h, const ClothEpisode
     HIPCHECK(hipStreamSynchronize(h->stream));          // fzbuf is on this stack frame
     if (h->relaxed && !(h->precision == CLOTHHIP_F32 && h->nt == 512 && h->ppt == 2 && h->tab == 2 && h->rest_reg && h->cell_copy && !tier2 &&
                         policy != CLOTHHIP_POLICY_HIGHEST_POINT))
-        return fail(CLOTHHIP_ESTATE, "CLOTHHIP_RELAXED_ORDER: the relaxed-order companion exists for the eight-wave LEAN layout only (fp32, flat tiers, 25x25 class, <= 512 cloths)");
+        return fail(CLOTHHIP_ESTATE, "clothhip_set_relaxed_order: the relaxed-order companion exists for the eight-wave LEAN layout only (fp32, flat tiers, 25x25 class, <= 512 cloths)");
     HIPCHECK(hipEventRecord(h->ev0, h->stream));
     if (h->relaxed) launch_relaxed(h, h->d_fz);
     else
@@ -1295,6 +1303,23 @@ extern "C" int clothhip_debug_stats(clothhip_handle *h, int32_t *stats) {
     HIPCHECK(hipSetDevice(h->device));
     HIPCHECK(hipStreamSynchronize(h->stream));
     HIPCHECK(hipMemcpy(stats, h->d_stats, (size_t)h->E * 64, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int clothhip_set_relaxed_order(clothhip_handle *h, int32_t on) {
+    if (!h) return fail(CLOTHHIP_EINVAL, "handle is NULL");
+    if (on) {
+        HIPCHECK(hipSetDevice(h->device));
+        HIPCHECK(hipFuncSetAttribute((const void *)k_run_schedule<float, 512, 2, 2, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    h->relaxed = on != 0;
+    return 0;
+}
+
+extern "C" int clothhip_last_dispatches(clothhip_handle *h, int32_t *n) {
+    if (!h || !n) return fail(CLOTHHIP_EINVAL, "NULL argument");
+    if (!h->have_variant) return fail(CLOTHHIP_ESTATE, "no stepper launch on this handle yet");
+    *n = h->last_dispatches;
     return 0;
 }
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CLOTHHIP_ABI_VERSION 6
+#define CLOTHHIP_ABI_VERSION 7
 
 enum {
     CLOTHHIP_OK = 0,
@@ -373,6 +373,19 @@ double clothhip_last_kernel_ms(clothhip_handle *h);
  *   (hipOccupancyMaxActiveBlocksPerMultiprocessor), v[8] compute units of the device, v[9] precision (0 f64, 1 f32).
  * Returns CLOTHHIP_ESTATE when the handle has not launched a stepper yet. */
 int clothhip_last_variant(clothhip_handle *h, int32_t v[10]);
+
+/* (new, ABI 7) Kernel dispatches the handle's last stepper launch was issued as: 1, or -- a time-sliced clothhip_run_actions over more
+ * cloths than are resident -- one per generation of resident cloths (rocprofv3 lists them one by one; clothhip_last_kernel_ms spans
+ * them all). CLOTHHIP_ESTATE before the first launch. */
+int clothhip_last_dispatches(clothhip_handle *h, int32_t *n);
+
+/* (new, ABI 7; measurement only, NOT a reference path) on != 0: THIS handle's clothhip_run_actions launches run the relaxed-order
+ * companion kernel -- self-collision in Jacobi order, strain limit in coloured order (cloth.pyx:258-296 and :313-343 keep list order;
+ * this does not) -- so that bench.py can state what the reference's Gauss-Seidel orders cost. Its trajectories are not the
+ * reference's; clothhip_last_variant reports flavour v[5] == 3 for such a launch. Per handle (round 5 read an environment variable at
+ * create time, which leaked into every handle created meanwhile). Only the eight-wave LEAN layout has the companion (fp32, flat tiers,
+ * 25x25 class, <= 512 cloths): other handles get CLOTHHIP_ESTATE from clothhip_run_actions*. update() / step() on the handle stay exact. */
+int clothhip_set_relaxed_order(clothhip_handle *h, int32_t on);
 
 /* Diagnostics of the last clothhip_run*: stats[E][16]: [0..3] = {strain sweeps run, 64-spring windows walked, passes
  * over a window, passes in which a correction was applied}; [15] = shader clocks/1024 the env's whole schedule

@@ -105,13 +105,16 @@ def test_bench_two_ranks_on_one_gpu_over_tcp(tmp_path):
     import subprocess
     import sys
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    # two free ports, both held until both are known: MASTER_PORT and the one the TCP transport binds (bench.tcp_port)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    s2 = socket.socket(); s2.bind(("127.0.0.1", 0)); tcp_port = s2.getsockname()[1]
+    s.close(); s2.close()
     args = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--envs", "64", "--steps", "4", "--warmup", "2", "--fuse", "2",
             "--no-extra", "--no-cpu-baseline"]
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   CLOTH_BENCH_FORCE_TCP="1", CLOTHHIP_RDZV_FILE=str(tmp_path / "unused.id"))
+                   CLOTH_BENCH_FORCE_TCP="1", CLOTH_BENCH_TCP_PORT=str(tcp_port), CLOTHHIP_RDZV_FILE=str(tmp_path / "unused.id"))
         procs.append(subprocess.Popen(args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
     outs = [p.communicate(timeout=300) for p in procs]
     assert all(p.returncode == 0 for p in procs), [o[1].decode()[-2000:] for o in outs]
@@ -125,6 +128,7 @@ def test_bench_two_ranks_on_one_gpu_over_tcp(tmp_path):
     assert 0.2 < c["action_time_frac"] <= 1.0 and rec["value"] > 0 and c["blended_substeps_per_s"] > 0
     # value x (the actions' share of the clock) = action substeps of the whole job
     n_act = c["action_substeps_per_env_step"] * c["env_steps_executed"]
-    assert abs(rec["value"] * c["timed_region_s"] * c["action_time_frac"] - n_act) <= 1e-6 * n_act
-    assert abs(rec["ms_per_step"] * c["steps_equivalent"] - 1e3 * c["timed_region_s"] * c["action_time_frac"]) <= 1e-6 * 1e3 * c["timed_region_s"]
+    # (the printed line carries six significant digits)
+    assert abs(rec["value"] * c["timed_region_s"] * c["action_time_frac"] - n_act) <= 1e-4 * n_act
+    assert abs(rec["ms_per_step"] * c["steps_equivalent"] - 1e3 * c["timed_region_s"] * c["action_time_frac"]) <= 1e-4 * 1e3 * c["timed_region_s"]
     assert rec["roofline"]["traffic"] is None or rec["roofline"]["traffic_source"]

@@ -134,7 +134,7 @@ def test_full_batch_bench_step_f64_sample_matches_oracle(E, n_side, tier, oracle
 
 
 def test_relaxed_order_companion_runs_and_is_labelled(monkeypatch):
-    """bench.py's relaxed-order companion (CLOTHHIP_RELAXED_ORDER=1: self-collision in Jacobi order, strain limit in coloured order) is a
+    """bench.py's relaxed-order companion (ClothBatch.set_relaxed_order / clothhip_set_relaxed_order, per handle: self-collision in Jacobi order, strain limit in coloured order) is a
     MEASUREMENT, not a mode with a parity claim: this only checks that the companion kernel is the one that runs (clothhip_last_variant:
     episode flavour 3), that it is refused where it does not exist (fp64), that it leaves sane cloths behind (finite positions, coverage
     comparable with the exact order's) and that its results DO differ from the exact order's -- so that nobody mistakes one for the
@@ -148,9 +148,9 @@ def test_relaxed_order_companion_runs_and_is_labelled(monkeypatch):
     acts = _bench_actions(E, T)
     outs = {}
     for relaxed in (False, True):
-        if relaxed:
-            monkeypatch.setenv("CLOTHHIP_RELAXED_ORDER", "1")
         cfg, env = _bench_env(E, 25, "tier1", "f32")
+        if relaxed:
+            env.batch.set_relaxed_order(True)
         out = env.step_many(acts, auto_reset=False)
         var = env.batch.last_variant()
         assert var["fused"] == (3 if relaxed else 1) and var["lean"] and var["threads"] == 512, var
@@ -164,9 +164,9 @@ def test_relaxed_order_companion_runs_and_is_labelled(monkeypatch):
     assert np.array_equal(outs[False][0][0] > 0, outs[True][0][0] > 0)               # the same envs grabbed something
     assert not np.array_equal(outs[False][2], outs[True][2])                          # ... but these are different trajectories
     assert np.median(np.abs(outs[False][1][0] - outs[True][1][0])) < 0.1              # of the same physics (coverage stays comparable)
-    monkeypatch.setenv("CLOTHHIP_RELAXED_ORDER", "1")
     cfg64 = bench.bench_cfg(25, 0.02, "tier1")
     env = ClothVecEnv(cfg64, n_envs=4, precision="f64", consume_domrand_draws=False)
+    env.batch.set_relaxed_order(True)
     env.reset()                                                                       # (the per-step path is not affected)
     with pytest.raises(ClothHipError):
         env.step_many(_bench_actions(4, 1), auto_reset=False)

@@ -133,7 +133,7 @@ def main():
         fetch, f_all, f_out = pooled("FETCH_SIZE", fk)
         write, w_all, w_out = pooled("WRITE_SIZE", wk)
         cfg = tb["config"]
-        records.append({"mode": "fused" if cfg["mode"].startswith("fused") else "step", "envs": cfg["envs_per_gpu"], "n_side": cfg["n_side"],
+        records.append({"mode": "fused" if str(cfg["mode"]).startswith("fused") else "step", "envs": cfg["envs_per_gpu"], "n_side": cfg["n_side"],
                         "precision": tb["dtype"], "init": cfg["init"], "slice_ms": cfg.get("slice_ms"),
                         "fetch_size_bytes_per_launch_raw": fetch, "fetch_size_kb_of_the_timed_launches": f_all, "fetch_outliers_kb": f_out,
                         "write_size_bytes_per_launch": write, "write_size_kb_of_the_timed_launches": w_all, "write_outliers_kb": w_out,
