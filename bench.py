@@ -726,7 +726,7 @@ def _summary(r):
         return {"error": r["error"][:120]}
     s = {"value": r["value"]}
     if "roofline" in r:
-        s["frac"] = r["roofline"]["frac"]
+        s["frac"] = r["roofline"]["frac_on_fp32_bytes"]          # on SURVEY 8d's 49 P bytes per substep whatever the instantiation's state width
         s["blended"] = r["config"]["blended_substeps_per_s"]
         s["variant"] = r["config"]["variant_short"]
     return s

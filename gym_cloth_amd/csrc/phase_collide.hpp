@@ -47,8 +47,17 @@ __device__ __forceinline__ int collide_cell_wave(Pt<T> *cur, uint16_t *m, const 
         const unsigned long long freem = ballot64(free_);
         unsigned long long movedm = 0ull;
         while (todo) {
+#if defined(CLOTHHIP_MUTATE) && CLOTHHIP_MUTATE == 2
+            // MUTANT 2 (tools/run_mutants.sh; never a product build): the first visit of a cell goes to the SECOND member due, the first one
+            // follows -- cloth.pyx:324-343 visits in ascending point index
+            const bool mut2_ = visits_ == 0 && (todo & (todo - 1ull)) != 0ull;
+            const unsigned long long pick_ = mut2_ ? (todo & (todo - 1ull)) : todo;
+            const int a = __builtin_amdgcn_readfirstlane(__ffsll((long long)pick_) - 1);
+            todo &= ~(1ull << a);
+#else
             const int a = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
             todo &= todo - 1ull;
+#endif
             visits_++;
             const T xa = bcast(x, a), ya = bcast(y, a), za = bcast(z, a);
             const T dx = xa - x, dy = ya - y, dz = za - z;
@@ -80,8 +89,15 @@ __device__ __forceinline__ int collide_cell_wave(Pt<T> *cur, uint16_t *m, const 
 #endif
     {
     while (todo) {
+#if defined(CLOTHHIP_MUTATE) && CLOTHHIP_MUTATE == 2
+        const bool mut2_ = visits_ == 0 && (todo & (todo - 1ull)) != 0ull;      // MUTANT 2 (see the fp32 loop above)
+        const unsigned long long pick_ = mut2_ ? (todo & (todo - 1ull)) : todo;
+        const int a = __builtin_amdgcn_readfirstlane(__ffsll((long long)pick_) - 1);
+        todo &= ~(1ull << a);
+#else
         const int a = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
         todo &= todo - 1ull;
+#endif
         visits_++;
         const T xa = bcast(x, a), ya = bcast(y, a), za = bcast(z, a);
         const T dx = xa - x, dy = ya - y, dz = za - z;
@@ -155,10 +171,21 @@ __device__ __forceinline__ void collide_cells_group(Pt<T> *cur, uint16_t *memb, 
     const T cfac = (T)1 + (T)2 / k.sim_steps;
     const T thr2c = thr2 * cfac * cfac;
     bool moved = false;
+#if defined(CLOTHHIP_MUTATE) && CLOTHHIP_MUTATE == 2
+    bool first_ = true;                       // MUTANT 2 (see collide_cell_wave): the small cells' first visit too
+#endif
     while (__any(todo != 0u)) {
         const bool act = todo != 0u;
+#if defined(CLOTHHIP_MUTATE) && CLOTHHIP_MUTATE == 2
+        const bool mut2_ = first_ && (todo & (todo - 1u)) != 0u;
+        const unsigned int pick_ = mut2_ ? (todo & (todo - 1u)) : todo;
+        const int a = act ? __ffs((int)pick_) - 1 : 0;
+        todo &= ~(act ? (1u << a) : 0u);
+        first_ = false;
+#else
         const int a = act ? __ffs((int)todo) - 1 : 0;
         todo &= todo - 1u;
+#endif
         const T xa = lane_pull(x, base + a), ya = lane_pull(y, base + a), za = lane_pull(z, base + a);
         const T dx = xa - x, dy = ya - y, dz = za - z;
         const T d2 = sumsq<T>(dx, dy, dz);

@@ -258,7 +258,11 @@ __device__ __forceinline__ int strain_sweep_lean(Pt<T> *cur, const WEnt<T> *wt, 
             //  re-read, so that a window ending in a quiet pass leaves them fresh: -5 % -- two more scattered 16-byte reads per pass cost ~180 cycles;
             //  the re-read under an exec mask of the lanes still pending: -4 %)
             const uint32_t ca = w_cnt(c.A.w), cb = w_cnt(c.B.w);    // pins do not change during a sweep
+#if defined(CLOTHHIP_MUTATE) && CLOTHHIP_MUTATE == 4
+            T tl = t11;             // MUTANT 4 (tools/run_mutants.sh; never a product build): the both-pinned skip of cloth.pyx:268 dropped
+#else
             T tl = ((ca != 0) & (cb != 0)) ? INF_ : t11;           // both ends pinned: skipped by the reference (:268)
+#endif
             T tl2 = tl * tl * ((T)1 - filt_slack<T>());
             auto test = [&]() {
                 if constexpr (sizeof(T) == 4) { trig = len > tl; }
@@ -276,7 +280,14 @@ __device__ __forceinline__ int strain_sweep_lean(Pt<T> *cur, const WEnt<T> *wt, 
                 unsigned long long plm = ~0ull;
                 for (;;) {
                     // a spring is VALID when none of its (transitive) predecessors in the window is over-stretched now (strain_sweep)
+#if defined(CLOTHHIP_MUTATE) && CLOTHHIP_MUTATE == 3
+                    // MUTANT 3 (tools/run_mutants.sh; never a product build): the SECOND over-stretched spring of the pass is committed together
+                    // with the first whether or not it depends on it -- cloth.pyx:265-296 shows a later spring the earlier one's correction
+                    const unsigned long long tb2_ = tb & (tb - 1ull);
+                    const bool bad = (((dlo & (uint32_t)tb) | (dhi & (uint32_t)(tb >> 32))) != 0u) && !(tb2_ != 0ull && lane == __ffsll((long long)tb2_) - 1);
+#else
                     const bool bad = ((dlo & (uint32_t)tb) | (dhi & (uint32_t)(tb >> 32))) != 0u;
+#endif
 #ifdef CLOTHHIP_COUNT_SPRINGS        // dev (profiling builds): count the SPRINGS a pass corrects instead of the correcting passes
                     if (STATS) st_commits += __builtin_popcountll(ballot64(trig & !bad));
 #else

@@ -26,6 +26,14 @@
 #pragma unroll
                     for (int sl = 0; sl < HK_SLOTS; sl++)
                         gl[sl] = LEAN ? lean_entry(iq_, vq_, sl) : (GT_REG ? gt[GT_REG ? q : 0][sl] : Ak_->gather[sl * Ppad + tid + q * NT]);
+#if defined(CLOTHHIP_MUTATE) && CLOTHHIP_MUTATE == 1
+                    // MUTANT 1 (tools/run_mutants.sh; never a product build): ONE particle adds two of its incident springs in swapped list
+                    // order (stencil positions 2 and 3: both shearing springs, same rest-length class) -- cloth.pyx:221-237 keeps list order
+                    if (iq_ == P / 2) {
+                        const uint32_t t_ = gl[2]; gl[2] = gl[3]; gl[3] = t_;      // (rest lengths follow the entry's table slot; the register-held
+                                                                                   //  ones of the 256 x 3 debug variant are one value per class on the flat tiers)
+                    }
+#endif
                     // software pipeline: the neighbour records of the next springs are in flight while spring sl is
                     // evaluated (left to itself the scheduler, which minimises live registers at this kernel's pressure, issues
                     // each 16-byte read right before its use and waits out the whole LDS latency 12 times per particle)

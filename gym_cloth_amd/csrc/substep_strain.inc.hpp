@@ -101,9 +101,14 @@
                             l2s[sl] = len2;
                             const T t11 = r * k.c11, tt = r * k.tear_thresh;
                             const T tmin = t11 < tt ? t11 : tt;
+#if defined(CLOTHHIP_MUTATE) && CLOTHHIP_MUTATE == 4       // MUTANT 4 (see strain_sweep_lean): the pre-pass flags both-pinned springs too
+                            const bool pre = ((g & (HK_VALID | HK_ASB)) == (HK_VALID | HK_ASB)) &
+                                             (len2 > tmin * tmin * ((T)1 - filt_slack<T>()));
+#else
                             const bool pre = ((g & (HK_VALID | HK_ASB)) == (HK_VALID | HK_ASB)) &
                                              !((cme_ != 0) & (w_cnt(nb.w) != 0)) &
                                              (len2 > tmin * tmin * ((T)1 - filt_slack<T>()));
+#endif
                             cand |= pre ? (1u << sl) : 0u;
                         }
                         // (b) those few: inside the slack band around the limit the sweep's exact test (:270-275) decides: a

@@ -194,6 +194,8 @@ def test_time_sliced_launch_goes_out_per_generation_and_equals_the_single_launch
                      out["reset_before"].copy(), [x.copy() for x in env.batch.get_state()]))
         env.close()
     (va, *a), (vb, *b) = runs
+    # (the library says how many kernel dispatches a launch went out as: 512 + 512 + 76 -> three, the debug override -> one)
+    assert va.pop("dispatches") == 3 and vb.pop("dispatches") == 1
     assert va["threads"] == 512 and va["cloths_per_cu"] == 2 and va == vb, (va, vb)
     assert a[1].sum() > 200 * E
     for x, y in zip(a[:6], b[:6]):

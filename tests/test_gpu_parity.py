@@ -275,6 +275,43 @@ def test_tear_thresholds_around_the_strain_limit_f64(tear_thresh, oracle_lib):
     b.close()
 
 
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_both_pinned_spring_beyond_tear_length_is_skipped(prec, oracle_lib):
+    """cloth.pyx:268: a spring whose two ends are BOTH pinned is skipped by the strain limit before its tear test (:272). Two pinned
+    neighbours held 2.2 rest lengths apart (beyond tear_thresh = 2) must therefore raise no tear flag by themselves (the flag appears one substep later, from the free
+    springs around them, exactly when the oracle's does), while the free particles around them are strain-limited as usual; fp64 bit-exact, fp32 within the single-substep band. (Mutant 4 of
+    tools/run_mutants.sh -- the skip dropped -- is rejected here: it reports a tear.)"""
+    from gym_cloth_amd import ClothBatch
+    g = oracle_lib.load_golden("g_traj_lift_pull_25.npz")
+    ocfg = dict(g["cfg"])
+    b = ClothBatch(cfg_from_golden({"cfg": ocfg}), n_envs=2, precision=prec)
+    pos0, rest0 = b.init_grid(1)
+    P, N = b.P, 25
+    i0, i1 = 12 * N + 12, 12 * N + 13                      # two structural neighbours in the middle of the cloth
+    pos = pos0.copy()
+    pos[i1, 2] += 0.02                                       # lifted a little, and dragged 2.2 rest lengths away from its neighbour
+    pos[i1, 1] = pos[i0, 1] + 2.2 * (pos0[i1, 1] - pos0[i0, 1])
+    pin = np.zeros(P, dtype=np.uint8); pin[i0] = 1; pin[i1] = 1
+    b.set_state(np.stack([pos, pos]), np.stack([pos, pos]), np.stack([pin, pin]), rest0)
+    oc = oracle_lib.OracleCloth(ocfg)
+    oc.set_state(pos, pos, pin, rest0)
+    for step in range(6):
+        b.update(1)
+        oc.update(1)
+        # substep 0: the only spring beyond 2 rest lengths is the both-pinned one -> no tear (the free springs around the pair stretch further
+        # in the substeps that follow and do tear: the flag must appear exactly when the oracle's does)
+        assert oc.have_tear == (step >= 1), step
+        assert bool(b.tear[0]) == oc.have_tear and bool(b.tear[1]) == oc.have_tear, (step, b.tear[:2], oc.have_tear)
+        gp, gq, _ = b.get_state()
+        op, oq, _ = oc.get_state()
+        if prec == "f64":
+            assert np.array_equal(gp[0], op) and np.array_equal(gq[0], oq) and np.array_equal(gp[1], op), (step, max_abs(gp[0], op))
+        else:
+            assert max_abs(gp[0], op) <= 2e-6 * (step + 1), (step, max_abs(gp[0], op))
+    assert max_abs(op, pos) > 1e-3                           # the neighbourhood did move (strain limit at work)
+    b.close()
+
+
 def test_grid_too_large_for_lds_is_rejected():
     from gym_cloth_amd import ClothBatch
     g_cfg = cfg_from_golden({"cfg": {"n_side": 64, "width": 1, "height": 1, "density": 200.0, "ks": 1e4, "damping": 2.0,
