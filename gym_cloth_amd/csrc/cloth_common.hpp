@@ -128,8 +128,13 @@ template <typename T> struct StepArgs {
     // that the compiler hoists to the kernel entry and keeps in SGPRs across the substep loop, which has none to spare.
     const struct FusedArgs<T> *fz;
     int32_t e0;              // env of workgroup 0: a time-sliced episode launch over more cloths than are resident goes out as one launch per generation (launch_run)
+    const uint16_t *ready;   // [Ppad] per particle: the last window of the strain sweep that touches the particle or one of its <= 12 spring neighbours
+                             // (cloth_tables.hpp::build_ready): once the sweep's frontier is past it, the next substep's Hooke sum of the particle may run
 };
 
+// misc[MISC_FRONT] (LDS): the strain sweep's FRONTIER -- the first window of the walk in flight that is not finished yet; INT_MAX when no sweep
+// is in flight, 0 between the Verlet commit of a substep and the start of its sweep (substep_hooke_stage.inc.hpp waits on it)
+constexpr int MISC_FRONT = 17;
 constexpr int KEY_SHIFT = 12;
 constexpr uint32_t KEY_BIAS = 1u << 19;
 constexpr uint32_t KEY_FLOOR = 4096u;         // stored keys are >= KEY_FLOOR so a slot can later hold a point index (< 4096)

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
             for (int i = tid; i < A.Spad; i += NT) { WEnt<T> w_; w_.ab = s_ent[i]; w_.rest = s_rest[i]; d0[i] = w_; }
         }
         for (int h = tid; h < HT; h += NT) { hkey[h] = KEY_EMPTY; hco[h] = 0; }
-        if (tid == 0) { misc[0] = tear_flag; misc[1] = 0; misc[2] = 0; misc[3] = 0; misc[4] = 0; misc[5] = 0; misc[6] = 0; misc[10] = 0x7fffffff; misc[11] = -1; misc[12] = 0; misc[13] = 0; misc[14] = 0; misc[20] = 0; misc[21] = 0; misc[22] = 0; misc[23] = 0; }
+        if (tid == 0) { misc[0] = tear_flag; misc[1] = 0; misc[2] = 0; misc[3] = 0; misc[4] = 0; misc[5] = 0; misc[6] = 0; misc[10] = 0x7fffffff; misc[11] = -1; misc[12] = 0; misc[13] = 0; misc[14] = 0; misc[20] = 0; misc[21] = 0; misc[22] = 0; misc[23] = 0; misc[MISC_FRONT] = 0x7fffffff; }
     };
     if (tid == 0) misc[15] = 0;
     init_lds(A.tear[e], A.wt_ent, g_rest);
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
     }
     __syncthreads();
 
-    int st_windows = 0, st_passes = 0, st_commits = 0;      // wave 0 only (uniform); the number of sweeps run lives in misc[15]
+    int st_windows = 0, st_passes = 0, st_commits = 0;      // the sweeping wave's (uniform); the number of sweeps run lives in misc[15]
 #ifdef CLOTHHIP_TPH_LDS
     const TphLds tph{reinterpret_cast<unsigned long long *>(smem + lay.tphs), tid == 0};
     if (tid < 12) tph.base[tid] = 0ull;
@@ -217,6 +217,18 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
 #else
     constexpr bool SWEEP_STATS = false;
 #endif
+    // PIPE: the rotated loop's overlap is live -- the sweep is walked by the cloth's LAST wave (it owns the fewest particles: nothing of the
+    // second round) while the others run the next substep's Hooke stage behind its frontier. Off in the builds that instrument or replace the
+    // one-wave sweep: there every wave waits for the sweep's end as before (the frontier stays at INT_MAX).
+#ifndef CLOTHHIP_PIPE
+#define CLOTHHIP_PIPE 1
+#endif
+#if defined(CLOTHHIP_SWEEP_STAMPS) || defined(CLOTHHIP_SWEEP_OUTER) || defined(CLOTHHIP_CELL_COUNTERS) || defined(CLOTHHIP_SWEEP_MW)
+    constexpr bool PIPE = false;
+#else
+    constexpr bool PIPE = CLOTHHIP_PIPE != 0 && !RELAXED && NT >= 128;
+#endif
+    constexpr int SW = PIPE ? NT / 64 - 1 : 0;      // the wave that walks the strain sweep
 #define TSTAMP(slot_)                                                          \
     if (timing) {                                                              \
         unsigned long long tn_;                                                \
@@ -307,7 +319,16 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
 #ifdef CLOTHHIP_CELL_COUNTERS
     bool frozen_prev_ = false;
 #endif
-    for (int it = resumed_run ? resume_it : 0; it < sc.n_total; it++) {
+    // ---- the substep loop, ROTATED (round 6): a trip is  [Hooke stage of substep it -> registers] B1 [checks of substep it - 1]
+    // [adjust / release / Verlet commit] [spatial map, self-collision, plane] [strain pre-pass] [strain sweep by ONE wave, no barrier behind it].
+    // The waves that do not sweep fall through to the next trip's Hooke stage and work there while the sweep walks, each particle slot
+    // as soon as the sweep's frontier has passed it (substep_hooke_stage.inc.hpp); barrier B1 ends the sweep and the Hooke stage together.
+    // Same operations on the same values in the reference's order as the unrotated loop (cloth.pyx:169-214): only WHEN the Hooke gather of
+    // a particle whose neighbourhood is final runs has changed.
+    int it = __builtin_amdgcn_readfirstlane(resumed_run ? resume_it : 0);       // (wave-uniform: kept in an SGPR)
+    const int it_first_ = it;
+    const int n_total_ = __builtin_amdgcn_readfirstlane(sc.n_total);
+    for (;;) {
         // LEAN and fp64: everything derived from the thread index (LDS addresses of the owned particles, table offsets) is formed anew in
         // every substep instead of being hoisted out of the loop and held -- or spilled -- for the whole schedule
         int tid = tid_outer_;
@@ -315,10 +336,18 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
         const int lane = tid & 63;
         KArgsC<T> *Ak_ = (KArgsC<T> *)__builtin_amdgcn_kernarg_segment_ptr();
 
-#include "substep_pull.inc.hpp"
-        TSTAMP(0)
-#include "substep_hooke_verlet.inc.hpp"
+#include "substep_hooke_stage.inc.hpp"
         TSTAMP(1)
+        __syncthreads();                    // B1: the sweep of substep it - 1 is over, every neighbour read of the Hooke stage is done
+        if (it > it_first_) {               // substep it - 1 is complete
+            if (timing) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory"); }
+            done++;
+            if (sc.break_on_tear && misc[0]) break;                                            // cloth_env.py:511-514
+            if (FUSED && sliced && misc[7] && it < n_total_) { it_next = it; break; }
+        }
+        if (it >= n_total_) break;
+#include "substep_write.inc.hpp"
+        TSTAMP(0)
 #include "substep_collision.inc.hpp"
 #include "substep_plane.inc.hpp"
         if (FUSED && sliced) {             // thread 0 looks at the clock here, between two barriers that every thread passes in
@@ -329,10 +358,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
 
         TSTAMP(7)
 #include "substep_strain.inc.hpp"
-        if (timing) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory"); }
-        done++;
-        if (sc.break_on_tear && misc[0]) break;                                            // cloth_env.py:511-514
-        if (FUSED && sliced && misc[7] && it + 1 < sc.n_total) { it_next = it + 1; break; }
+        it++;
     }
         }   // the run
         resume_it = -1;
@@ -366,10 +392,11 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
                 for (int q = 0; q < 4; q++) { Fp->op_ticks[8 * e + q] = eps->ticks[q]; Fp->op_ticks[8 * e + 4 + q] = eps->subs[q]; }
             }
         }
+        if (tid == SW * 64 && A.stats) { A.stats[16 * e + 1] = st_windows; A.stats[16 * e + 2] = st_passes; A.stats[16 * e + 3] = st_commits; }   // (the sweeping wave's counters)
         if (tid == 0) {
             A.tear[e] = misc[0]; A.executed[e] = done;
             if (A.stats) {
-                A.stats[16 * e] = misc[15]; A.stats[16 * e + 1] = st_windows; A.stats[16 * e + 2] = st_passes; A.stats[16 * e + 3] = st_commits;
+                A.stats[16 * e] = misc[15];
                 for (int q = 0; q < 12; q++) A.stats[16 * e + 4 + q] = (int)((unsigned long long)tph[q] >> 6);
 #ifndef CLOTHHIP_PHASE_STAMPS
                 unsigned long long tend;
