@@ -219,7 +219,8 @@ static const void *stepper_fn(const clothhip_handle *h, int fused);
 // behind `total` are free). False: the episode launches cannot run on this layout.
 static bool fit_scratch(clothhip_handle::Layout &L, int tsz, int Ppad, int Spad, int P, int budget) {
     int NS = 1; while (NS < P) NS <<= 1;
-    const LdsLayout lay(tsz, Ppad, Spad, L.HT, L.tab == 2 ? 2 : (v_ldstab(L.tab) ? 1 : 0), L.cell_copy);
+    const int vml = v_vm_lds(L.tab, L.rest_reg, tsz, L.nt, L.ppt) ? 1 : 0;
+    const LdsLayout lay(tsz, Ppad, Spad, L.HT, L.tab == 2 ? 2 : (v_ldstab(L.tab) ? 1 : 0), L.cell_copy, vml);
     L.scratch_need = metrics_scratch_bytes(NS, Ppad + 8, tsz, v_hull_idx(L.tab, tsz, L.nt, L.ppt));
     if (L.lds_bytes < lay.total) L.lds_bytes = lay.total;
     if (L.lds_bytes - lay.hkey < L.scratch_need && lay.hkey + L.scratch_need <= budget) L.lds_bytes = (lay.hkey + L.scratch_need + 15) / 16 * 16;
@@ -278,7 +279,7 @@ static void plan_layouts(clothhip_handle *h, int cus, const std::vector<uint32_t
             double best = 0.0; int best_r = 2;
             for (int r = 2; r <= std::max(2, std::min(6, max_r)); r++) {
                 // (r >= 3: the four-wave LEAN layout, table streamed, must fit r times in the CU's LDS -- 27x27 does not at five per CU)
-                if (r >= 3 && (!lean_able || LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, 0).total > lds_budget(r))) continue;
+                if (r >= 3 && (!lean_able || LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, 0, 1).total > lds_budget(r))) continue;
                 const double v = rate[r - 2] / (double)((h->E + r * cus - 1) / (r * cus));
                 if (v > best * 1.02) { best = v; best_r = r; }
             }
@@ -333,13 +334,13 @@ static void plan_layouts(clothhip_handle *h, int cus, const std::vector<uint32_t
         }
         h->lds_bytes = h->lay_std.lds_bytes;
         if (h->lean) {                                   // the lean layout: window table streamed from L2, 33 KB of LDS
-            int cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, 1).total <= lds_budget(std::max(h->lean_r, 3)) ? 1 : 0;
+            int cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, 1, 1).total <= lds_budget(std::max(h->lean_r, 3)) ? 1 : 0;
             if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) cc = cc && atoi(t);
-            h->lay_lean = {256, 3, h->lean_r >= 4 ? 3 - h->lean_r : 0, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, cc).total, h->HT, h->ht_bits};   // (r = 3, 4: four waves per cloth)
+            h->lay_lean = {256, 3, h->lean_r >= 4 ? 3 - h->lean_r : 0, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, cc, 1).total, h->HT, h->ht_bits};   // (r = 3, 4: four waves per cloth)
             if (h->lean_r == 2 && small_grid) {          // eight waves per cloth, two cloths per CU: the standard variant's LDS budget
-                cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 2, 1).total <= 80 * 1024 ? 1 : 0;
+                cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 2, 1, 1).total <= 80 * 1024 ? 1 : 0;
                 if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) cc = cc && atoi(t);
-                h->lay_lean = {512, 2, 2, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 2, cc).total, h->HT, h->ht_bits};
+                h->lay_lean = {512, 2, 2, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 2, cc, 1).total, h->HT, h->ht_bits};
                 if (h->lay_lean.lds_bytes > 80 * 1024 || h->P > 1024) h->lean = false;      // (the table must fit beside a second cloth)
             }
             if (h->lean_r == 1) {                        // the whole CU: same LDS budget as the standard variant of these grids

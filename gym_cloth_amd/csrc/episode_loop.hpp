@@ -47,6 +47,8 @@ __host__ __device__ inline uint32_t lean_valid_mask(int r, int c, int N) {
 //                         (with 512 threads x 2 particles: eight waves per cloth at 128 VGPRs, the headline variant)
 constexpr bool v_lean(int TAB, bool RR, int tsz) { return (TAB <= 0 || TAB == 2 || TAB == 3 || TAB == 4) && RR && tsz == 4; }
 constexpr bool v_ldstab(int TAB) { return TAB == 1 || TAB == 2; }
+// the LEAN stencil masks in LDS instead of registers (LdsLayout::vmk): the 25x25-class LEAN builds (the large grids' LDS is full)
+constexpr bool v_vm_lds(int TAB, bool RR, int tsz, int NT, int PPT) { return v_lean(TAB, RR, tsz) && NT * PPT <= 1024; }
 // the in-kernel metrics' hull stack as u16 indices (same arithmetic, an eighth of the LDS): the variants whose LDS is tight -- two large-grid
 // cloths per CU, five / six 25x25 cloths per CU, the fp64 instantiation of the large grids (50x50: 71 KB of scratch instead of 107 KB,
 // which is what lets its episode launches exist at all) and the 1024 x 4 variants (64x64)
@@ -85,7 +87,8 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
         sc.dz_up = sc.dx_pull = sc.dy_pull = sc.dz_pull = 0.0;
     }
     const int P = A.P, Ppad = A.Ppad, HT = A.HT;
-    const LdsLayout lay((int)sizeof(T), Ppad, A.Spad, HT, TAB == 2 ? 2 : (v_ldstab(TAB) ? 1 : 0), A.cell_copy);
+    constexpr bool VM_LDS = v_vm_lds(TAB, REST_REG, (int)sizeof(T), NT, PPT);
+    const LdsLayout lay((int)sizeof(T), Ppad, A.Spad, HT, TAB == 2 ? 2 : (v_ldstab(TAB) ? 1 : 0), A.cell_copy, VM_LDS ? 1 : 0);
     Pt<T> *cur = reinterpret_cast<Pt<T> *>(smem + lay.cur);
     uint32_t *hkey = reinterpret_cast<uint32_t *>(smem + lay.hkey);
     uint32_t *hco = reinterpret_cast<uint32_t *>(smem + lay.hco);
@@ -115,7 +118,9 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
     constexpr bool REST_R = REST_REG && !LEAN;
     uint32_t gt[GT_REG ? PPT : 1][HK_SLOTS];
     T rr[REST_R ? PPT : 1][HK_SLOTS];     // and those springs' rest lengths
-    uint32_t vm[LEAN ? PPT : 1];            // LEAN: which of the twelve stencil positions exist for the particle
+    uint32_t vm[(LEAN && !VM_LDS) ? PPT : 1];   // LEAN: which of the twelve stencil positions exist for the particle (VM_LDS: the table vmk in LDS instead)
+    const uint16_t *const vmk = reinterpret_cast<const uint16_t *>(smem + lay.vmk);
+    auto vm_of = [&](int q, int i) -> uint32_t { (void)q; (void)i; if constexpr (VM_LDS) return (uint32_t)vmk[i]; else return vm[(LEAN && !VM_LDS) ? q : 0]; };
     uint32_t rc[RELAXED ? PPT : 1];         // RELAXED: the particle's grid position, r | c << 8 (parities of the colour classes)
     auto lean_entry = [&](int i, uint32_t vmq, int sl) -> uint32_t {      // a gather entry without its table-slot field
         const bool ok = ((vmq >> sl) & 1u) != 0u;
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
             const int i = tid + q * NT;
             const bool ok = i < P;
             pvx[q] = ok ? gq[i] : (T)0; pvy[q] = ok ? gq[Ppad + i] : (T)0; pvz[q] = ok ? gq[2 * Ppad + i] : (T)0;
-            if (LEAN) { const int r_ = i / A.N; vm[LEAN ? q : 0] = ok ? lean_valid_mask(r_, i - r_ * A.N, A.N) : 0u; if (RELAXED) rc[RELAXED ? q : 0] = (uint32_t)r_ | ((uint32_t)(i - r_ * A.N) << 8); }
+            if (LEAN) { const int r_ = i / A.N; if (!VM_LDS) vm[(LEAN && !VM_LDS) ? q : 0] = ok ? lean_valid_mask(r_, i - r_ * A.N, A.N) : 0u; if (RELAXED) rc[RELAXED ? q : 0] = (uint32_t)r_ | ((uint32_t)(i - r_ * A.N) << 8); }
             else
 #pragma unroll
             for (int sl = 0; sl < HK_SLOTS; sl++) {
@@ -156,6 +161,10 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
     if (tid == 0) misc[15] = 0;
     init_lds(A.tear[e], A.wt_ent, g_rest);
     uint16_t *pslot = reinterpret_cast<uint16_t *>(smem + lay.pslot);       // TAB 2 only
+    if (VM_LDS) {
+        uint16_t *vmw_ = reinterpret_cast<uint16_t *>(smem + lay.vmk);
+        for (int i = tid; i < Ppad; i += NT) { const int r_ = i / A.N; vmw_[i] = i < P ? (uint16_t)lean_valid_mask(r_, i - r_ * A.N, A.N) : (uint16_t)0; }
+    }
     if (TAB == 2) {
         for (int i = tid; i < Ppad; i += NT) {
             const int r_ = i / A.N;

@@ -192,7 +192,7 @@ __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const
             } else if (TIMED) { unsigned long long td1; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(td1)::"memory"); tph[10] += td1 - td0; tph[9] += 64; }
         } while (more);
         w++;
-        if (PUB) { asm volatile("" ::: "memory"); *(volatile int *)front = w; }
+        if (PUB) lds_publish(front, w);
         if (dirty) { NA = cur[an]; NB = cur[bn]; }
     } while (w <= w_end);
 #ifdef CLOTHHIP_SWEEP_OUTER
@@ -334,11 +334,11 @@ __device__ __forceinline__ int strain_sweep_lean(Pt<T> *cur, const WEnt<T> *wt, 
     for (;;) {
         step(S0, S1);
         ++w;
-        if (PUB) { asm volatile("" ::: "memory"); *(volatile int *)front = w; }
+        if (PUB) lds_publish(front, w);
         if (w > w_end) break;
         step(S1, S0);
         ++w;
-        if (PUB) { asm volatile("" ::: "memory"); *(volatile int *)front = w; }
+        if (PUB) lds_publish(front, w);
         if (w > w_end) break;
     }
     return tear;

@@ -34,9 +34,17 @@
                     int f_ = __builtin_amdgcn_readfirstlane(*(volatile int *)&misc[MISC_FRONT]);
                     if (f_ != 0x7fffffff) {
                         const int mine_ = tid + q * NT < P ? (int)Ak_->ready[tid + q * NT] : -1;
-                        const int need_ = -__builtin_amdgcn_readlane(wave_incl_min(-mine_), 63);
+                        int need_ = -__builtin_amdgcn_readlane(wave_incl_min(-mine_), 63);
+#ifndef CLOTHHIP_PIPE_NO_SIMD_DEFER
+                        // the wave that shares the sweeping wave's SIMD (a workgroup's waves go round the four SIMDs: w and w + 4 meet) stays out of its
+                        // way: every instruction it issued there would come straight out of the sweep's issue slots (measured: the walk 20 % slower)
+                        if (NT >= 512 && (tid >> 6) == SW - 4) need_ = 0x7ffffffe;
+#endif
                         while (f_ <= need_) {
-                            __builtin_amdgcn_s_sleep(2);
+#ifndef CLOTHHIP_PIPE_SLEEP
+#define CLOTHHIP_PIPE_SLEEP 2
+#endif
+                            __builtin_amdgcn_s_sleep(CLOTHHIP_PIPE_SLEEP);
                             f_ = __builtin_amdgcn_readfirstlane(*(volatile int *)&misc[MISC_FRONT]);
                         }
                     }
@@ -49,7 +57,7 @@
                     T fx = (T)0 + (T)0, fy = (T)0 + (T)0, fz = (T)0 + k.mg;
                     uint32_t gl[HK_SLOTS];
                     uint32_t gacc = 0u;                                     // grab counts of the neighbours met (adjust substeps only)
-                    int iq_ = tid + q * NT; uint32_t vq_ = vm[LEAN ? q : 0];
+                    int iq_ = tid + q * NT; uint32_t vq_ = vm_of(q, iq_);
                     if (LEAN) asm volatile("" : "+v"(iq_), "+v"(vq_));     // opaque: the stencil is recomputed every substep, not hoisted and held
 #pragma unroll
                     for (int sl = 0; sl < HK_SLOTS; sl++)
@@ -95,7 +103,11 @@
                         const bool valid = (g & HK_VALID) != 0u;
                         fx = valid ? mad<T>(fm, dx, fx) : fx; fy = valid ? mad<T>(fm, dy, fy) : fy; fz = valid ? mad<T>(fm, dz, fz) : fz;   // :236-237
                     }
+#ifdef CLOTHHIP_EXP_NOCOLD
+                    if (false) {
+#else
                     if (__builtin_expect(__any(gacc != 0u), 0)) {
+#endif
                         // cold path (a wave that holds a neighbour of a grabbed particle, lift / pull substeps only): the sum again, every grabbed
                         // neighbour moved by the gripper first -- p <- x; x <- delta + x, once per entry in grabbed_pts (gripper.pyx:60-66)
                         fx = (T)0 + (T)0; fy = (T)0 + (T)0; fz = (T)0 + k.mg;

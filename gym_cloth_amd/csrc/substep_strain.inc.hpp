@@ -24,7 +24,7 @@
                     const int i = tid + q * NT;
                     const int r_ = (int)(rc[RELAXED ? q : 0] & 0xFFu), c_ = (int)(rc[RELAXED ? q : 0] >> 8);
                     const int key = (kind == 1 || kind == 5) ? c_ : r_;
-                    const bool on = i < P && ((vm[LEAN ? q : 0] >> kind) & 1u) && (((kind >= 4 ? key >> 1 : key) & 1) == par);
+                    const bool on = i < P && ((vm_of(q, i < P ? i : 0) >> kind) & 1u) && (((kind >= 4 ? key >> 1 : key) & 1) == par);
                     if (on) {
                         const int j = i + (kind == 0 ? -Ak_->N : kind == 1 ? -1 : kind == 2 ? -Ak_->N - 1 : kind == 3 ? -Ak_->N + 1 : kind == 4 ? -2 * Ak_->N : -2);
                         const Pt<T> a_ = cur[j], b_ = cur[i];                                  // ptA (the earlier point), ptB (the owner)
@@ -64,7 +64,7 @@
                         const Pt<T> me = cur[tid + q * NT];
                         const uint32_t cme_ = w_cnt(me.w);
                         uint32_t gl[HK_SLOTS / 2];
-                        int iq_ = tid + q * NT; uint32_t vq_ = vm[LEAN ? q : 0];
+                        int iq_ = tid + q * NT; uint32_t vq_ = vm_of(q, iq_);
                         if (LEAN) asm volatile("" : "+v"(iq_), "+v"(vq_));
 #pragma unroll
                         for (int sl = 0; sl < HK_SLOTS / 2; sl++)
