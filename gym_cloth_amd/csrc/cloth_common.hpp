@@ -128,19 +128,8 @@ template <typename T> struct StepArgs {
     // that the compiler hoists to the kernel entry and keeps in SGPRs across the substep loop, which has none to spare.
     const struct FusedArgs<T> *fz;
     int32_t e0;              // env of workgroup 0: a time-sliced episode launch over more cloths than are resident goes out as one launch per generation (launch_run)
-    const uint16_t *ready;   // [Ppad] per particle: the last window of the strain sweep that touches the particle or one of its <= 12 spring neighbours
-                             // (cloth_tables.hpp::build_ready): once the sweep's frontier is past it, the next substep's Hooke sum of the particle may run
 };
 
-// misc[MISC_FRONT] (LDS): the strain sweep's FRONTIER -- the first window of the walk in flight that is not finished yet; INT_MAX when no sweep
-// is in flight, 0 between the Verlet commit of a substep and the start of its sweep (substep_hooke_stage.inc.hpp waits on it)
-constexpr int MISC_FRONT = 17;
-// One LDS store the compiler neither tracks nor waits for (a VOLATILE store is followed by s_waitcnt vmcnt(0) lgkmcnt(0): in the sweep's walk that
-// drains the read-ahead of the next windows at every window). LDS operations of a wave execute in order, so an extra one in flight only makes the
-// compiler's own lgkmcnt waits stricter. The low half of a generic pointer into LDS is the LDS address.
-__device__ __forceinline__ void lds_publish(int *p, int v) {
-    asm volatile("ds_write_b32 %0, %1" ::"v"((uint32_t)(uintptr_t)p), "v"(v) : "memory");
-}
 constexpr int KEY_SHIFT = 12;
 constexpr uint32_t KEY_BIAS = 1u << 19;
 constexpr uint32_t KEY_FLOOR = 4096u;         // stored keys are >= KEY_FLOOR so a slot can later hold a point index (< 4096)
@@ -293,19 +282,16 @@ static_assert(WT_IDX_BITS == 12 && HK_NBR_MASK == WT_IDX_MASK, "point indices ar
 struct LdsLayout {
     int lkey;        // census build: every particle's cell key of the previous substep
     int tphs;        // profiling / census builds: their twelve 64-bit accumulators (in front of the region the in-kernel metrics borrow)
-    int cur, eps, wtab, pslot, vmk, hkey, hco, memb, slot, misc, alist, olist, cpos, total;
+    int cur, eps, wtab, pslot, hkey, hco, memb, slot, misc, alist, olist, cpos, total;
     // tab 2 (the eight-wave LEAN build): like 1, plus the table slots of every particle's six own springs (u16 [6][Ppad]): the strain
     // pre-pass of the LEAN arithmetic needs the slot of a flagged spring, and read it from the L2-resident gather table otherwise
-    // vml 1 (the LEAN builds of the 25x25 class): every particle's stencil mask (which of its twelve springs exist) as u16 [Ppad] -- two registers
-    // less across the whole substep loop, whose 128-VGPR builds spill what they cannot hold (round 6)
-    __host__ __device__ LdsLayout(int tsz, int Ppad, int Spad, int HT, int tab, int cp, int vml = 0) {
+    __host__ __device__ LdsLayout(int tsz, int Ppad, int Spad, int HT, int tab, int cp) {
         int o = 0;
         auto take = [&](int bytes) { int r = o; o += (bytes + 15) / 16 * 16; return r; };
         cur = take(4 * Ppad * tsz);
         eps = take(EPSTATE_LDS_BYTES);   // EpState (fused episodes)
         wtab = take(tab >= 1 ? Spad * (tsz == 8 ? 16 : 8) : 0);   // WEnt<T>[Spad]
         pslot = take(tab == 2 ? (HK_SLOTS / 2) * Ppad * 2 : 0);
-        vmk = take(vml ? Ppad * 2 : 0);
 #ifdef CLOTHHIP_TPH_LDS
         tphs = take(96);
 #else
@@ -321,7 +307,7 @@ struct LdsLayout {
         memb = take(Ppad * 2);
         slot = take(Ppad * 2);
         misc = take(256);            // flags and scan scratch (64 ints)
-        olist = take(2 * Ppad);       // u16 hash slots: occupied cells from the front, cells with a seed from the back (substep_collision.inc.hpp relies on olist == misc + 256)
+        olist = take(2 * Ppad);       // u16 hash slots: occupied cells from the front, cells with a seed from the back
         alist = olist;                //   (an active cell has >= 2 members, so #occupied + #active <= P)
         cpos = take(cp ? 4 * (Ppad + 32) * tsz : 0);   // particle records in cell (CSR) order for the pre-check; the
                                                        // unclamped member loop may read up to a cell's width past the end

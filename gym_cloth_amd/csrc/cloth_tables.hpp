@@ -237,27 +237,6 @@ inline WindowTable build_windows(const Topology &t, const LevelSchedule &L) {
     return W;
 }
 
-// Per particle: the last window of the strain sweep after which the particle's position AND its spring neighbours' positions are final for
-// the substep -- max over the particle and its neighbours of the last window that holds a spring incident to them. When the sweep's frontier
-// (the first unfinished window) is beyond it, nothing the sweep still does can change what the particle's Hooke gather of the NEXT substep
-// reads (cloth.pyx:221-237 reads a spring's two end points only).
-inline std::vector<uint16_t> build_ready(const Topology &t, const WindowTable &W, int Ppad) {
-    std::vector<int> last_win(t.P, -1);
-    for (int s = 0; s < t.S; s++) {
-        const int ws = W.slot_of[s] >> 6;
-        last_win[t.a[s]] = std::max(last_win[t.a[s]], ws);
-        last_win[t.b[s]] = std::max(last_win[t.b[s]], ws);
-    }
-    std::vector<int> rdy(last_win);
-    for (int s = 0; s < t.S; s++) {
-        rdy[t.a[s]] = std::max(rdy[t.a[s]], last_win[t.b[s]]);
-        rdy[t.b[s]] = std::max(rdy[t.b[s]], last_win[t.a[s]]);
-    }
-    std::vector<uint16_t> out((size_t)Ppad, 0);
-    for (int i = 0; i < t.P; i++) out[i] = (uint16_t)(rdy[i] < 0 ? 0 : rdy[i]);       // (64x64: 375 windows)
-    return out;
-}
-
 // gather table [HK_SLOTS][Ppad]: slot k of point i = its k-th incident spring in ascending list index.
 inline std::vector<uint32_t> build_gather(const Topology &t, const WindowTable &W, int Ppad) {
     std::vector<uint32_t> tab((size_t)HK_SLOTS * Ppad, 0u);

@@ -61,7 +61,6 @@ struct clothhip_handle {
     ClothSchedule *d_sched = nullptr, *h_sched = nullptr;   // h_sched: pinned staging
     uint32_t *d_gather = nullptr, *d_wt_ent = nullptr;
     unsigned long long *d_wt_dep = nullptr;
-    uint16_t *d_ready = nullptr;     // [Ppad] cloth_tables.hpp::build_ready
     int cell_copy = 0;
     int HT = 0, ht_bits = 0, lds_bytes = 0, phase_mask = 15, nt = 256, ppt = 3;
     int tab = 0;            // the strain sweep's window table (+ rest lengths) resident in LDS: 0 no (streamed from L2), 1 yes
@@ -203,7 +202,7 @@ static void free_handle(clothhip_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_pos, h->d_prev, h->d_rest, h->d_cnt, h->d_active, h->d_tear, h->d_exec, h->d_ngrab, h->d_stats,
-                    h->d_sched, h->d_flat, h->d_flat_rest, h->d_hcnt, h->d_fz, h->d_fact, h->d_fscr, h->d_frec, h->d_frst, h->d_fobs, h->d_frobs, h->d_fsteps, h->d_fparg, h->d_fdone, h->d_fticks, h->d_fsum, h->d_fmt, h->d_resume, h->d_gather, h->d_wt_ent, h->d_wt_dep, h->d_ready, h->d_levels, h->d_xy, h->d_radius, h->d_cov, h->d_vinv, h->d_oob};
+                    h->d_sched, h->d_flat, h->d_flat_rest, h->d_hcnt, h->d_fz, h->d_fact, h->d_fscr, h->d_frec, h->d_frst, h->d_fobs, h->d_frobs, h->d_fsteps, h->d_fparg, h->d_fdone, h->d_fticks, h->d_fsum, h->d_fmt, h->d_resume, h->d_gather, h->d_wt_ent, h->d_wt_dep, h->d_levels, h->d_xy, h->d_radius, h->d_cov, h->d_vinv, h->d_oob};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->h_sched) (void)hipHostFree(h->h_sched);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -219,8 +218,7 @@ static const void *stepper_fn(const clothhip_handle *h, int fused);
 // behind `total` are free). False: the episode launches cannot run on this layout.
 static bool fit_scratch(clothhip_handle::Layout &L, int tsz, int Ppad, int Spad, int P, int budget) {
     int NS = 1; while (NS < P) NS <<= 1;
-    const int vml = v_vm_lds(L.tab, L.rest_reg, tsz, L.nt, L.ppt) ? 1 : 0;
-    const LdsLayout lay(tsz, Ppad, Spad, L.HT, L.tab == 2 ? 2 : (v_ldstab(L.tab) ? 1 : 0), L.cell_copy, vml);
+    const LdsLayout lay(tsz, Ppad, Spad, L.HT, L.tab == 2 ? 2 : (v_ldstab(L.tab) ? 1 : 0), L.cell_copy);
     L.scratch_need = metrics_scratch_bytes(NS, Ppad + 8, tsz, v_hull_idx(L.tab, tsz, L.nt, L.ppt));
     if (L.lds_bytes < lay.total) L.lds_bytes = lay.total;
     if (L.lds_bytes - lay.hkey < L.scratch_need && lay.hkey + L.scratch_need <= budget) L.lds_bytes = (lay.hkey + L.scratch_need + 15) / 16 * 16;
@@ -279,7 +277,7 @@ static void plan_layouts(clothhip_handle *h, int cus, const std::vector<uint32_t
             double best = 0.0; int best_r = 2;
             for (int r = 2; r <= std::max(2, std::min(6, max_r)); r++) {
                 // (r >= 3: the four-wave LEAN layout, table streamed, must fit r times in the CU's LDS -- 27x27 does not at five per CU)
-                if (r >= 3 && (!lean_able || LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, 0, 1).total > lds_budget(r))) continue;
+                if (r >= 3 && (!lean_able || LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, 0).total > lds_budget(r))) continue;
                 const double v = rate[r - 2] / (double)((h->E + r * cus - 1) / (r * cus));
                 if (v > best * 1.02) { best = v; best_r = r; }
             }
@@ -334,13 +332,13 @@ static void plan_layouts(clothhip_handle *h, int cus, const std::vector<uint32_t
         }
         h->lds_bytes = h->lay_std.lds_bytes;
         if (h->lean) {                                   // the lean layout: window table streamed from L2, 33 KB of LDS
-            int cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, 1, 1).total <= lds_budget(std::max(h->lean_r, 3)) ? 1 : 0;
+            int cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, 1).total <= lds_budget(std::max(h->lean_r, 3)) ? 1 : 0;
             if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) cc = cc && atoi(t);
-            h->lay_lean = {256, 3, h->lean_r >= 4 ? 3 - h->lean_r : 0, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, cc, 1).total, h->HT, h->ht_bits};   // (r = 3, 4: four waves per cloth)
+            h->lay_lean = {256, 3, h->lean_r >= 4 ? 3 - h->lean_r : 0, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, cc).total, h->HT, h->ht_bits};   // (r = 3, 4: four waves per cloth)
             if (h->lean_r == 2 && small_grid) {          // eight waves per cloth, two cloths per CU: the standard variant's LDS budget
-                cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 2, 1, 1).total <= 80 * 1024 ? 1 : 0;
+                cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 2, 1).total <= 80 * 1024 ? 1 : 0;
                 if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) cc = cc && atoi(t);
-                h->lay_lean = {512, 2, 2, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 2, cc, 1).total, h->HT, h->ht_bits};
+                h->lay_lean = {512, 2, 2, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 2, cc).total, h->HT, h->ht_bits};
                 if (h->lay_lean.lds_bytes > 80 * 1024 || h->P > 1024) h->lean = false;      // (the table must fit beside a second cloth)
             }
             if (h->lean_r == 1) {                        // the whole CU: same LDS budget as the standard variant of these grids
@@ -420,7 +418,6 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
     HC(hipMalloc(&h->d_gather, gather.size() * 4));
     HC(hipMalloc(&h->d_wt_ent, (size_t)h->Spad * 4));
     HC(hipMalloc(&h->d_wt_dep, (size_t)h->Spad * 8));
-    HC(hipMalloc(&h->d_ready, (size_t)h->Ppad * 2));
     HC(hipMalloc(&h->d_levels, (levels.size() + 1) * 8));
     HC(hipMalloc(&h->d_xy, E * 2 * 8));
     HC(hipMalloc(&h->d_radius, E * 8));
@@ -435,10 +432,6 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
     HC(hipMemcpy(h->d_gather, gather.data(), gather.size() * 4, hipMemcpyHostToDevice));
     HC(hipMemcpy(h->d_wt_ent, h->wt.ent.data(), (size_t)h->Spad * 4, hipMemcpyHostToDevice));
     HC(hipMemcpy(h->d_wt_dep, h->wt.dep.data(), (size_t)h->Spad * 8, hipMemcpyHostToDevice));
-    {
-        const std::vector<uint16_t> ready = build_ready(h->topo, h->wt, h->Ppad);
-        HC(hipMemcpy(h->d_ready, ready.data(), (size_t)h->Ppad * 2, hipMemcpyHostToDevice));
-    }
     HC(hipMemset(h->d_rest, 0, E * h->Spad * h->tsz));
     if (!levels.empty()) HC(hipMemcpy(h->d_levels, levels.data(), levels.size() * 8, hipMemcpyHostToDevice));
     HC(hipMemset(h->d_exec, 0, E * 4));
@@ -742,7 +735,7 @@ template <typename T> static StepArgs<T> make_args(clothhip_handle *h, const Clo
     a.e0 = 0;
     a.pos = (T *)h->d_pos; a.prev = (T *)h->d_prev; a.cnt = h->d_cnt; a.rest = (const T *)h->d_rest;
     a.tear = h->d_tear; a.executed = h->d_exec; a.stats = h->d_stats; a.sched = d_sched;
-    a.gather = h->d_gather; a.wt_ent = h->d_wt_ent; a.wt_dep = h->d_wt_dep; a.ready = h->d_ready; a.nW = h->wt.nW; a.wt_rshift = h->wt.reach_shift; a.cell_copy = h->cell_copy;
+    a.gather = h->d_gather; a.wt_ent = h->d_wt_ent; a.wt_dep = h->d_wt_dep; a.nW = h->wt.nW; a.wt_rshift = h->wt.reach_shift; a.cell_copy = h->cell_copy;
     a.N = h->N; a.P = h->P; a.Ppad = h->Ppad; a.S = h->S; a.Spad = h->Spad;
     a.HT = h->HT; a.ht_bits = h->ht_bits;
     a.rest_stride = h->rest_stride; a.phase_mask = h->phase_mask;

@@ -47,8 +47,6 @@ __host__ __device__ inline uint32_t lean_valid_mask(int r, int c, int N) {
 //                         (with 512 threads x 2 particles: eight waves per cloth at 128 VGPRs, the headline variant)
 constexpr bool v_lean(int TAB, bool RR, int tsz) { return (TAB <= 0 || TAB == 2 || TAB == 3 || TAB == 4) && RR && tsz == 4; }
 constexpr bool v_ldstab(int TAB) { return TAB == 1 || TAB == 2; }
-// the LEAN stencil masks in LDS instead of registers (LdsLayout::vmk): the 25x25-class LEAN builds (the large grids' LDS is full)
-constexpr bool v_vm_lds(int TAB, bool RR, int tsz, int NT, int PPT) { return v_lean(TAB, RR, tsz) && NT * PPT <= 1024; }
 // the in-kernel metrics' hull stack as u16 indices (same arithmetic, an eighth of the LDS): the variants whose LDS is tight -- two large-grid
 // cloths per CU, five / six 25x25 cloths per CU, the fp64 instantiation of the large grids (50x50: 71 KB of scratch instead of 107 KB,
 // which is what lets its episode launches exist at all) and the 1024 x 4 variants (64x64)
@@ -87,8 +85,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
         sc.dz_up = sc.dx_pull = sc.dy_pull = sc.dz_pull = 0.0;
     }
     const int P = A.P, Ppad = A.Ppad, HT = A.HT;
-    constexpr bool VM_LDS = v_vm_lds(TAB, REST_REG, (int)sizeof(T), NT, PPT);
-    const LdsLayout lay((int)sizeof(T), Ppad, A.Spad, HT, TAB == 2 ? 2 : (v_ldstab(TAB) ? 1 : 0), A.cell_copy, VM_LDS ? 1 : 0);
+    const LdsLayout lay((int)sizeof(T), Ppad, A.Spad, HT, TAB == 2 ? 2 : (v_ldstab(TAB) ? 1 : 0), A.cell_copy);
     Pt<T> *cur = reinterpret_cast<Pt<T> *>(smem + lay.cur);
     uint32_t *hkey = reinterpret_cast<uint32_t *>(smem + lay.hkey);
     uint32_t *hco = reinterpret_cast<uint32_t *>(smem + lay.hco);
@@ -118,9 +115,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
     constexpr bool REST_R = REST_REG && !LEAN;
     uint32_t gt[GT_REG ? PPT : 1][HK_SLOTS];
     T rr[REST_R ? PPT : 1][HK_SLOTS];     // and those springs' rest lengths
-    uint32_t vm[(LEAN && !VM_LDS) ? PPT : 1];   // LEAN: which of the twelve stencil positions exist for the particle (VM_LDS: the table vmk in LDS instead)
-    const uint16_t *const vmk = reinterpret_cast<const uint16_t *>(smem + lay.vmk);
-    auto vm_of = [&](int q, int i) -> uint32_t { (void)q; (void)i; if constexpr (VM_LDS) return (uint32_t)vmk[i]; else return vm[(LEAN && !VM_LDS) ? q : 0]; };
+    uint32_t vm[LEAN ? PPT : 1];            // LEAN: which of the twelve stencil positions exist for the particle
     uint32_t rc[RELAXED ? PPT : 1];         // RELAXED: the particle's grid position, r | c << 8 (parities of the colour classes)
     auto lean_entry = [&](int i, uint32_t vmq, int sl) -> uint32_t {      // a gather entry without its table-slot field
         const bool ok = ((vmq >> sl) & 1u) != 0u;
@@ -138,7 +133,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
             const int i = tid + q * NT;
             const bool ok = i < P;
             pvx[q] = ok ? gq[i] : (T)0; pvy[q] = ok ? gq[Ppad + i] : (T)0; pvz[q] = ok ? gq[2 * Ppad + i] : (T)0;
-            if (LEAN) { const int r_ = i / A.N; if (!VM_LDS) vm[(LEAN && !VM_LDS) ? q : 0] = ok ? lean_valid_mask(r_, i - r_ * A.N, A.N) : 0u; if (RELAXED) rc[RELAXED ? q : 0] = (uint32_t)r_ | ((uint32_t)(i - r_ * A.N) << 8); }
+            if (LEAN) { const int r_ = i / A.N; vm[LEAN ? q : 0] = ok ? lean_valid_mask(r_, i - r_ * A.N, A.N) : 0u; if (RELAXED) rc[RELAXED ? q : 0] = (uint32_t)r_ | ((uint32_t)(i - r_ * A.N) << 8); }
             else
 #pragma unroll
             for (int sl = 0; sl < HK_SLOTS; sl++) {
@@ -156,15 +151,11 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
             for (int i = tid; i < A.Spad; i += NT) { WEnt<T> w_; w_.ab = s_ent[i]; w_.rest = s_rest[i]; d0[i] = w_; }
         }
         for (int h = tid; h < HT; h += NT) { hkey[h] = KEY_EMPTY; hco[h] = 0; }
-        if (tid == 0) { misc[0] = tear_flag; misc[1] = 0; misc[2] = 0; misc[3] = 0; misc[4] = 0; misc[5] = 0; misc[6] = 0; misc[10] = 0x7fffffff; misc[11] = -1; misc[12] = 0; misc[13] = 0; misc[14] = 0; misc[20] = 0; misc[21] = 0; misc[22] = 0; misc[23] = 0; misc[MISC_FRONT] = 0x7fffffff; }
+        if (tid == 0) { misc[0] = tear_flag; misc[1] = 0; misc[2] = 0; misc[3] = 0; misc[4] = 0; misc[5] = 0; misc[6] = 0; misc[10] = 0x7fffffff; misc[11] = -1; misc[12] = 0; misc[13] = 0; misc[14] = 0; misc[20] = 0; misc[21] = 0; misc[22] = 0; misc[23] = 0; }
     };
     if (tid == 0) misc[15] = 0;
     init_lds(A.tear[e], A.wt_ent, g_rest);
     uint16_t *pslot = reinterpret_cast<uint16_t *>(smem + lay.pslot);       // TAB 2 only
-    if (VM_LDS) {
-        uint16_t *vmw_ = reinterpret_cast<uint16_t *>(smem + lay.vmk);
-        for (int i = tid; i < Ppad; i += NT) { const int r_ = i / A.N; vmw_[i] = i < P ? (uint16_t)lean_valid_mask(r_, i - r_ * A.N, A.N) : (uint16_t)0; }
-    }
     if (TAB == 2) {
         for (int i = tid; i < Ppad; i += NT) {
             const int r_ = i / A.N;
@@ -176,7 +167,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
     }
     __syncthreads();
 
-    int st_windows = 0, st_passes = 0, st_commits = 0;      // the sweeping wave's (uniform); the number of sweeps run lives in misc[15]
+    int st_windows = 0, st_passes = 0, st_commits = 0;      // wave 0 only (uniform); the number of sweeps run lives in misc[15]
 #ifdef CLOTHHIP_TPH_LDS
     const TphLds tph{reinterpret_cast<unsigned long long *>(smem + lay.tphs), tid == 0};
     if (tid < 12) tph.base[tid] = 0ull;
@@ -226,18 +217,6 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
 #else
     constexpr bool SWEEP_STATS = false;
 #endif
-    // PIPE: the rotated loop's overlap is live -- the sweep is walked by the cloth's LAST wave (it owns the fewest particles: nothing of the
-    // second round) while the others run the next substep's Hooke stage behind its frontier. Off in the builds that instrument or replace the
-    // one-wave sweep: there every wave waits for the sweep's end as before (the frontier stays at INT_MAX).
-#ifndef CLOTHHIP_PIPE
-#define CLOTHHIP_PIPE 1
-#endif
-#if defined(CLOTHHIP_SWEEP_STAMPS) || defined(CLOTHHIP_SWEEP_OUTER) || defined(CLOTHHIP_CELL_COUNTERS) || defined(CLOTHHIP_SWEEP_MW)
-    constexpr bool PIPE = false;
-#else
-    constexpr bool PIPE = CLOTHHIP_PIPE != 0 && !RELAXED && NT >= 128;
-#endif
-    constexpr int SW = PIPE ? NT / 64 - 1 : 0;      // the wave that walks the strain sweep
 #define TSTAMP(slot_)                                                          \
     if (timing) {                                                              \
         unsigned long long tn_;                                                \
@@ -328,16 +307,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
 #ifdef CLOTHHIP_CELL_COUNTERS
     bool frozen_prev_ = false;
 #endif
-    // ---- the substep loop, ROTATED (round 6): a trip is  [Hooke stage of substep it -> registers] B1 [checks of substep it - 1]
-    // [adjust / release / Verlet commit] [spatial map, self-collision, plane] [strain pre-pass] [strain sweep by ONE wave, no barrier behind it].
-    // The waves that do not sweep fall through to the next trip's Hooke stage and work there while the sweep walks, each particle slot
-    // as soon as the sweep's frontier has passed it (substep_hooke_stage.inc.hpp); barrier B1 ends the sweep and the Hooke stage together.
-    // Same operations on the same values in the reference's order as the unrotated loop (cloth.pyx:169-214): only WHEN the Hooke gather of
-    // a particle whose neighbourhood is final runs has changed.
-    int it = __builtin_amdgcn_readfirstlane(resumed_run ? resume_it : 0);       // (wave-uniform: kept in an SGPR)
-    const int it_first_ = it;
-    const int n_total_ = __builtin_amdgcn_readfirstlane(sc.n_total);
-    for (;;) {
+    for (int it = resumed_run ? resume_it : 0; it < sc.n_total; it++) {
         // LEAN and fp64: everything derived from the thread index (LDS addresses of the owned particles, table offsets) is formed anew in
         // every substep instead of being hoisted out of the loop and held -- or spilled -- for the whole schedule
         int tid = tid_outer_;
@@ -345,18 +315,10 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
         const int lane = tid & 63;
         KArgsC<T> *Ak_ = (KArgsC<T> *)__builtin_amdgcn_kernarg_segment_ptr();
 
-#include "substep_hooke_stage.inc.hpp"
-        TSTAMP(1)
-        __syncthreads();                    // B1: the sweep of substep it - 1 is over, every neighbour read of the Hooke stage is done
-        if (it > it_first_) {               // substep it - 1 is complete
-            if (timing) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory"); }
-            done++;
-            if (sc.break_on_tear && misc[0]) break;                                            // cloth_env.py:511-514
-            if (FUSED && sliced && misc[7] && it < n_total_) { it_next = it; break; }
-        }
-        if (it >= n_total_) break;
-#include "substep_write.inc.hpp"
+#include "substep_pull.inc.hpp"
         TSTAMP(0)
+#include "substep_hooke_verlet.inc.hpp"
+        TSTAMP(1)
 #include "substep_collision.inc.hpp"
 #include "substep_plane.inc.hpp"
         if (FUSED && sliced) {             // thread 0 looks at the clock here, between two barriers that every thread passes in
@@ -367,7 +329,10 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
 
         TSTAMP(7)
 #include "substep_strain.inc.hpp"
-        it++;
+        if (timing) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory"); }
+        done++;
+        if (sc.break_on_tear && misc[0]) break;                                            // cloth_env.py:511-514
+        if (FUSED && sliced && misc[7] && it + 1 < sc.n_total) { it_next = it + 1; break; }
     }
         }   // the run
         resume_it = -1;
@@ -401,11 +366,10 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
                 for (int q = 0; q < 4; q++) { Fp->op_ticks[8 * e + q] = eps->ticks[q]; Fp->op_ticks[8 * e + 4 + q] = eps->subs[q]; }
             }
         }
-        if (tid == SW * 64 && A.stats) { A.stats[16 * e + 1] = st_windows; A.stats[16 * e + 2] = st_passes; A.stats[16 * e + 3] = st_commits; }   // (the sweeping wave's counters)
         if (tid == 0) {
             A.tear[e] = misc[0]; A.executed[e] = done;
             if (A.stats) {
-                A.stats[16 * e] = misc[15];
+                A.stats[16 * e] = misc[15]; A.stats[16 * e + 1] = st_windows; A.stats[16 * e + 2] = st_passes; A.stats[16 * e + 3] = st_commits;
                 for (int q = 0; q < 12; q++) A.stats[16 * e + 4 + q] = (int)((unsigned long long)tph[q] >> 6);
 #ifndef CLOTHHIP_PHASE_STAMPS
                 unsigned long long tend;

@@ -23,14 +23,11 @@ namespace clothhip {
 // last window that holds a spring of one of the two moved particles (the entry's static `reach`). Everything outside
 // [w0, w_end] provably evaluates to "no correction, no tear".
 // Entry stream: lane-private, coalesced, read PF windows ahead (LDS or, for the large grids, L2).
-// PUB: the walk publishes its FRONTIER -- the first window not finished yet -- in *front after every window (one LDS store: same-wave LDS
-// operations execute in program order, so whoever reads a frontier beyond w sees every correction made up to window w): the cloth's other
-// waves run the next substep's Hooke stage behind it (substep_hooke_stage.inc.hpp).
-template <typename T, bool LDS_TAB, bool TIMED, bool STATS, bool TIC, bool PUB = false>
+template <typename T, bool LDS_TAB, bool TIMED, bool STATS, bool TIC>
 __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const uint32_t *g_ent, const T *g_rest,
                                             const unsigned long long *g_dep, int w0, int w_end,
                                             int nW, int rshift, const DevConsts<T> &k, int lane, int &st_windows, int &st_passes, int &st_commits,
-                                            TphT tph, unsigned long long fmask = 0ull, int *front = nullptr) {
+                                            TphT tph, unsigned long long fmask = 0ull) {
     constexpr int PF = LDS_TAB ? 1 : 3;          // entry stream: windows read ahead
     // dependency words (always from L2 / L1: one table for all cloths). The queue's rotation needs the NEWEST word, so whatever its
     // depth the stream runs one window ahead: fp32 keeps two words (three and four measured the same, with more moves per window)
@@ -192,7 +189,6 @@ __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const
             } else if (TIMED) { unsigned long long td1; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(td1)::"memory"); tph[10] += td1 - td0; tph[9] += 64; }
         } while (more);
         w++;
-        if (PUB) lds_publish(front, w);
         if (dirty) { NA = cur[an]; NB = cur[bn]; }
     } while (w <= w_end);
 #ifdef CLOTHHIP_SWEEP_OUTER
@@ -218,10 +214,10 @@ __device__ __forceinline__ int strain_sweep(Pt<T> *cur, const WEnt<T> *wt, const
 // Same walk, same passes, same results as strain_sweep (tear_thresh >= 1.1 only: the caller keeps strain_sweep for the other case).
 // (AHEAD false -- the high-residency builds, whose other waves hide the latency: a window's particle records are read when the window starts,
 //  not a window ahead: sixteen registers fewer across the walk)
-template <typename T, bool LDS_TAB, bool STATS, bool AHEAD = true, bool PUB = false>
+template <typename T, bool LDS_TAB, bool STATS, bool AHEAD = true>
 __device__ __forceinline__ int strain_sweep_lean(Pt<T> *cur, const WEnt<T> *wt, const uint32_t *g_ent, const T *g_rest,
                                                  const unsigned long long *g_dep, int w0, int w_end, int rshift, const DevConsts<T> &k,
-                                                 int lane, int &st_windows, int &st_passes, int &st_commits, int *front = nullptr) {
+                                                 int lane, int &st_windows, int &st_passes, int &st_commits) {
     static_assert(WT_PAD_WINDOWS >= 3, "the entry stream reads two windows ahead, the particle reads one");
     int tear = 0;
     T c11 = k.c11, tth = k.tear_thresh;              // spring-test constants pinned in VGPRs
@@ -330,16 +326,11 @@ __device__ __forceinline__ int strain_sweep_lean(Pt<T> *cur, const WEnt<T> *wt, 
     Set S0, S1;
     load(w, S0); load(w + 1, S1);
     if (AHEAD) decode_read(S0);
-    // (PUB: the frontier after every window, see strain_sweep)
     for (;;) {
         step(S0, S1);
-        ++w;
-        if (PUB) lds_publish(front, w);
-        if (w > w_end) break;
+        if (++w > w_end) break;
         step(S1, S0);
-        ++w;
-        if (PUB) lds_publish(front, w);
-        if (w > w_end) break;
+        if (++w > w_end) break;
     }
     return tear;
 }

@@ -330,12 +330,7 @@
             }   // (exact order)
             __syncthreads();
             TSTAMP(6)
-            {   // ready for the next substep. (The list is addressed from `misc`, which it follows in the layout and which every phase holds anyway: its own base,
-                //  hoisted out of the substep loop as a vector register, was spilled and reloaded from scratch right here, on every substep's path --
-                //  one scratch reload in the loop costs the headline ~1 %)
-                const uint16_t *ol_ = reinterpret_cast<const uint16_t *>(reinterpret_cast<const unsigned char *>(misc) + 256);
-                for (int t = tid; t < nocc; t += NT) { const int h = (int)ol_[t]; hkey[h] = KEY_EMPTY; hco[h] = 0; }
-            }
+            for (int t = tid; t < nocc; t += NT) { const int h = (int)olist[t]; hkey[h] = KEY_EMPTY; hco[h] = 0; }   // ready for the next substep
             if (tid == 0) { misc[2] = 0; misc[3] = 0; misc[4] = 0; misc[5] = 0; misc[6] = 0; }
         } else {
             __syncthreads();

@@ -24,7 +24,7 @@
                     const int i = tid + q * NT;
                     const int r_ = (int)(rc[RELAXED ? q : 0] & 0xFFu), c_ = (int)(rc[RELAXED ? q : 0] >> 8);
                     const int key = (kind == 1 || kind == 5) ? c_ : r_;
-                    const bool on = i < P && ((vm_of(q, i < P ? i : 0) >> kind) & 1u) && (((kind >= 4 ? key >> 1 : key) & 1) == par);
+                    const bool on = i < P && ((vm[LEAN ? q : 0] >> kind) & 1u) && (((kind >= 4 ? key >> 1 : key) & 1) == par);
                     if (on) {
                         const int j = i + (kind == 0 ? -Ak_->N : kind == 1 ? -1 : kind == 2 ? -Ak_->N - 1 : kind == 3 ? -Ak_->N + 1 : kind == 4 ? -2 * Ak_->N : -2);
                         const Pt<T> a_ = cur[j], b_ = cur[i];                                  // ptA (the earlier point), ptB (the owner)
@@ -64,7 +64,7 @@
                         const Pt<T> me = cur[tid + q * NT];
                         const uint32_t cme_ = w_cnt(me.w);
                         uint32_t gl[HK_SLOTS / 2];
-                        int iq_ = tid + q * NT; uint32_t vq_ = vm_of(q, iq_);
+                        int iq_ = tid + q * NT; uint32_t vq_ = vm[LEAN ? q : 0];
                         if (LEAN) asm volatile("" : "+v"(iq_), "+v"(vq_));
 #pragma unroll
                         for (int sl = 0; sl < HK_SLOTS / 2; sl++)
@@ -184,14 +184,12 @@
                     }
                 }
             } else
-            if ((tid >> 6) == SW && (misc[1] || (pm & PH_NOSKIP))) {
+            if (tid < 64 && (misc[1] || (pm & PH_NOSKIP))) {
                 __builtin_amdgcn_s_setprio(3);            // the serial sweep is the critical path of the whole cloth
                 const bool all_ = (pm & PH_NOSKIP) != 0;
                 const int w0 = __builtin_amdgcn_readfirstlane(all_ ? 0 : (misc[10] >> 6));
                 const int w1 = __builtin_amdgcn_readfirstlane(all_ ? Ak_->nW - 1 : (misc[11] >> 6));
                 if (lane == 0) misc[15]++;               // sweeps run (clothhip_debug_stats): in LDS -- as a register it was spilled, reloaded and stored by every sweep
-                int *const front_ = PIPE ? &misc[MISC_FRONT] : nullptr;
-                if (PIPE) { *(volatile int *)front_ = w0; }       // nothing before the first flagged window is touched: those particles are final already
                 // tear_thresh >= 1.1 (every shipped configuration): only a stretching spring can tear, the test sits in the commit
                 const bool tic = __builtin_amdgcn_readfirstlane(!(k.tear_thresh < k.c11) ? 1 : 0) != 0;
 #ifdef CLOTHHIP_CELL_COUNTERS
@@ -200,12 +198,12 @@
 #else
                 const unsigned long long fmask_ = 0ull;
 #endif
-                const int tear = tic ? (SWEEP_LEAN ? strain_sweep_lean<T, v_ldstab(TAB), SWEEP_STATS, SWEEP_AHEAD, PIPE>(cur, wtab, Ak_->wt_ent, g_rest, Ak_->wt_dep, w0, w1, Ak_->wt_rshift, k,
-                                                                                                  lane, st_windows, st_passes, st_commits, front_)
-                                                   : strain_sweep<T, v_ldstab(TAB), SWEEP_TIMED, SWEEP_STATS, true, PIPE>(cur, wtab, Ak_->wt_ent, g_rest, Ak_->wt_dep, w0, w1, Ak_->nW, Ak_->wt_rshift, k,
-                                                                                                 lane, st_windows, st_passes, st_commits, tph, fmask_, front_))
-                                     : strain_sweep<T, v_ldstab(TAB), SWEEP_TIMED, SWEEP_STATS, false, PIPE>(cur, wtab, Ak_->wt_ent, g_rest, Ak_->wt_dep, w0, w1, Ak_->nW, Ak_->wt_rshift, k,
-                                                                                                  lane, st_windows, st_passes, st_commits, tph, fmask_, front_);
+                const int tear = tic ? (SWEEP_LEAN ? strain_sweep_lean<T, v_ldstab(TAB), SWEEP_STATS, SWEEP_AHEAD>(cur, wtab, Ak_->wt_ent, g_rest, Ak_->wt_dep, w0, w1, Ak_->wt_rshift, k,
+                                                                                                  lane, st_windows, st_passes, st_commits)
+                                                   : strain_sweep<T, v_ldstab(TAB), SWEEP_TIMED, SWEEP_STATS, true>(cur, wtab, Ak_->wt_ent, g_rest, Ak_->wt_dep, w0, w1, Ak_->nW, Ak_->wt_rshift, k,
+                                                                                                 lane, st_windows, st_passes, st_commits, tph, fmask_))
+                                     : strain_sweep<T, v_ldstab(TAB), SWEEP_TIMED, SWEEP_STATS, false>(cur, wtab, Ak_->wt_ent, g_rest, Ak_->wt_dep, w0, w1, Ak_->nW, Ak_->wt_rshift, k,
+                                                                                                  lane, st_windows, st_passes, st_commits, tph, fmask_);
                 if (__any(tear) && lane == 0) misc[0] = 1;
                 if (lane == 0) { misc[1] = 0; misc[10] = 0x7fffffff; misc[11] = -1; }
 #ifdef CLOTHHIP_CELL_COUNTERS
@@ -213,10 +211,7 @@
 #endif
                 __builtin_amdgcn_s_setprio(0);
             }
-            // PIPE: no barrier here -- the other waves are already in the next substep's Hooke stage, behind the frontier; the sweeping wave
-            // opens it for good (also when there was nothing to sweep) and follows them; the barrier behind that stage ends this substep
-            if (PIPE) { if (tid == SW * 64) { asm volatile("" ::: "memory"); *(volatile int *)&misc[MISC_FRONT] = 0x7fffffff; } }
-            else __syncthreads();
+            __syncthreads();
 #ifndef CLOTHHIP_SWEEP_STAMPS          // (that build uses slots 9-11 for the sweep's passes)
             TSTAMP(9)
 #endif
@@ -232,6 +227,4 @@
             __syncthreads();
             if (tid == 0) { misc[12] = 0; misc[16] = 0; }
 #endif
-        } else if (PIPE) {
-            if (tid == SW * 64) *(volatile int *)&misc[MISC_FRONT] = 0x7fffffff;      // (ablation masks without the strain limit: nothing to wait for)
         }
