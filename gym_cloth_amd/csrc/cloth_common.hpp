@@ -84,6 +84,7 @@ struct EpState {
     uint64_t ticks[4];     //   ticks per class (0 action, 1 reset pull incl. its coverage test, 2 reset settling, 3 other),
     uint32_t subs[4];      //   update() calls per class
     double last_cov;       // coverage after the last action / reset of this launch (NaN: none yet)
+    uint64_t t_deadline;   // t_launch + the launch's time budget (~0: none): what thread 0 compares the clock with in every substep of a time-sliced launch
     uint64_t t_launch;     // 100 MHz clock when this cloth's workgroup started (the time slice counts from here); LDS, not a register pair:
                            // held in registers it was spilled, and its reload sat on every substep's path
 };
@@ -128,6 +129,8 @@ template <typename T> struct StepArgs {
     // that the compiler hoists to the kernel entry and keeps in SGPRs across the substep loop, which has none to spare.
     const struct FusedArgs<T> *fz;
     int32_t e0;              // env of workgroup 0: a time-sliced episode launch over more cloths than are resident goes out as one launch per generation (launch_run)
+    const uint4 *lstc;       // fp64 LEAN build: [Ppad] per particle {stencil mask, 12 rest-length offsets in ulps (one byte each)}: the flat tiers' fp64 rest
+                             // lengths (cloth.pyx:417 on the grid of :117-130) are one value per spring type up to a few dozen ulps -- rest = bits(pal_type) + offset
 };
 
 constexpr int KEY_SHIFT = 12;
@@ -282,16 +285,18 @@ static_assert(WT_IDX_BITS == 12 && HK_NBR_MASK == WT_IDX_MASK, "point indices ar
 struct LdsLayout {
     int lkey;        // census build: every particle's cell key of the previous substep
     int tphs;        // profiling / census builds: their twelve 64-bit accumulators (in front of the region the in-kernel metrics borrow)
-    int cur, eps, wtab, pslot, hkey, hco, memb, slot, misc, alist, olist, cpos, total;
+    int cur, eps, wtab, pslot, lstc, hkey, hco, memb, slot, misc, alist, olist, cpos, total;
     // tab 2 (the eight-wave LEAN build): like 1, plus the table slots of every particle's six own springs (u16 [6][Ppad]): the strain
     // pre-pass of the LEAN arithmetic needs the slot of a flagged spring, and read it from the L2-resident gather table otherwise
-    __host__ __device__ LdsLayout(int tsz, int Ppad, int Spad, int HT, int tab, int cp) {
+    // lst 1 (the fp64 LEAN build): the per-particle stencil constants (StepArgs::lstc, 16 bytes each) resident in LDS
+    __host__ __device__ LdsLayout(int tsz, int Ppad, int Spad, int HT, int tab, int cp, int lst = 0) {
         int o = 0;
         auto take = [&](int bytes) { int r = o; o += (bytes + 15) / 16 * 16; return r; };
         cur = take(4 * Ppad * tsz);
         eps = take(EPSTATE_LDS_BYTES);   // EpState (fused episodes)
         wtab = take(tab >= 1 ? Spad * (tsz == 8 ? 16 : 8) : 0);   // WEnt<T>[Spad]
         pslot = take(tab == 2 ? (HK_SLOTS / 2) * Ppad * 2 : 0);
+        lstc = take(lst ? Ppad * 16 : 0);
 #ifdef CLOTHHIP_TPH_LDS
         tphs = take(96);
 #else

@@ -73,6 +73,8 @@ struct clothhip_handle {
     int last_dispatches = 0; // kernel dispatches the last stepper launch was issued as (clothhip_last_dispatches)
     int lean_r = 3;         // cloths per CU the chosen LEAN build is compiled for (3: 168 VGPRs, 4: 128 VGPRs; 2: eight waves per cloth, table in LDS; 1: the large grids)
     float pal[3] = {0, 0, 0};
+    double pal64[3] = {0, 0, 0};     // fp64 LEAN build: the smallest rest length of each spring type (the others are it + a few ulps: StepArgs::lstc)
+    uint4 *d_lstc = nullptr;         // [Ppad] fp64 LEAN build: per particle {stencil mask, 12 offset bytes}
     int32_t last_variant[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // what the last launch ran (clothhip_last_variant)
     bool have_variant = false;
     int n_cus = 0;
@@ -202,7 +204,7 @@ static void free_handle(clothhip_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_pos, h->d_prev, h->d_rest, h->d_cnt, h->d_active, h->d_tear, h->d_exec, h->d_ngrab, h->d_stats,
-                    h->d_sched, h->d_flat, h->d_flat_rest, h->d_hcnt, h->d_fz, h->d_fact, h->d_fscr, h->d_frec, h->d_frst, h->d_fobs, h->d_frobs, h->d_fsteps, h->d_fparg, h->d_fdone, h->d_fticks, h->d_fsum, h->d_fmt, h->d_resume, h->d_gather, h->d_wt_ent, h->d_wt_dep, h->d_levels, h->d_xy, h->d_radius, h->d_cov, h->d_vinv, h->d_oob};
+                    h->d_sched, h->d_flat, h->d_flat_rest, h->d_hcnt, h->d_fz, h->d_fact, h->d_fscr, h->d_frec, h->d_frst, h->d_fobs, h->d_frobs, h->d_fsteps, h->d_fparg, h->d_fdone, h->d_fticks, h->d_fsum, h->d_fmt, h->d_resume, h->d_gather, h->d_wt_ent, h->d_wt_dep, h->d_lstc, h->d_levels, h->d_xy, h->d_radius, h->d_cov, h->d_vinv, h->d_oob};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->h_sched) (void)hipHostFree(h->h_sched);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -218,7 +220,8 @@ static const void *stepper_fn(const clothhip_handle *h, int fused);
 // behind `total` are free). False: the episode launches cannot run on this layout.
 static bool fit_scratch(clothhip_handle::Layout &L, int tsz, int Ppad, int Spad, int P, int budget) {
     int NS = 1; while (NS < P) NS <<= 1;
-    const LdsLayout lay(tsz, Ppad, Spad, L.HT, L.tab == 2 ? 2 : (v_ldstab(L.tab) ? 1 : 0), L.cell_copy);
+    const int lst = (tsz == 8 && v_lean(L.tab, L.rest_reg, tsz)) ? 1 : 0;
+    const LdsLayout lay(tsz, Ppad, Spad, L.HT, L.tab == 2 ? 2 : (v_ldstab(L.tab) ? 1 : 0), L.cell_copy, lst);
     L.scratch_need = metrics_scratch_bytes(NS, Ppad + 8, tsz, v_hull_idx(L.tab, tsz, L.nt, L.ppt));
     if (L.lds_bytes < lay.total) L.lds_bytes = lay.total;
     if (L.lds_bytes - lay.hkey < L.scratch_need && lay.hkey + L.scratch_need <= budget) L.lds_bytes = (lay.hkey + L.scratch_need + 15) / 16 * 16;
@@ -287,6 +290,9 @@ static void plan_layouts(clothhip_handle *h, int cus, const std::vector<uint32_t
             // off the L2 path, which lets SIXTEEN waves step a cloth at 128 VGPRs (1024 threads x 3 or 4 particles; 50x50: 2.90 M/s
             // standard 512 x 5 -> 3.05 LEAN 512 x 5 -> 3.26 LEAN 1024 x 3); the standard variant stays as the fallback (per-env rest tables)
             if (!small_grid && precision == CLOTHHIP_F32) { h->lean = true; h->lean_r = 1; }
+            // fp64, 25x25 class, eight waves per cloth (round 6): the LEAN arithmetic with per-spring ulp offsets (StepArgs::lstc) -- no gather-table and no
+            // rest-length loads from L2 in the Hooke gather and the strain pre-pass; same layout class as the standard fp64 variant (two cloths per CU)
+            if (small_grid && precision == CLOTHHIP_F64 && h->nt == 512) { h->lean = true; h->lean_r = 2; }
         }
         if (const char *t = getenv("CLOTHHIP_DEBUG_LEAN")) {      // 0: never; 8 (or 2): the eight-wave build; 3 (or 1) / 4 / 5 / 6: the LEAN build for that many cloths per CU, whatever the batch size
             const int v = atoi(t);
@@ -335,6 +341,12 @@ static void plan_layouts(clothhip_handle *h, int cus, const std::vector<uint32_t
             int cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, 1).total <= lds_budget(std::max(h->lean_r, 3)) ? 1 : 0;
             if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) cc = cc && atoi(t);
             h->lay_lean = {256, 3, h->lean_r >= 4 ? 3 - h->lean_r : 0, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, cc).total, h->HT, h->ht_bits};   // (r = 3, 4: four waves per cloth)
+            if (precision == CLOTHHIP_F64) {             // fp64 LEAN: table streamed (TAB 0), the stencil constants in LDS
+                cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, 1, 1).total <= lds_budget(2) ? 1 : 0;
+                if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) cc = cc && atoi(t);
+                h->lay_lean = {512, 2, 0, true, cc, LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 0, cc, 1).total, h->HT, h->ht_bits};
+                if (h->lay_lean.lds_bytes > lds_budget(2)) h->lean = false;
+            } else
             if (h->lean_r == 2 && small_grid) {          // eight waves per cloth, two cloths per CU: the standard variant's LDS budget
                 cc = LdsLayout(tsz, h->Ppad, h->Spad, h->HT, 2, 1).total <= 80 * 1024 ? 1 : 0;
                 if (const char *t = getenv("CLOTHHIP_DEBUG_CELL_COPY")) cc = cc && atoi(t);
@@ -418,6 +430,8 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
     HC(hipMalloc(&h->d_gather, gather.size() * 4));
     HC(hipMalloc(&h->d_wt_ent, (size_t)h->Spad * 4));
     HC(hipMalloc(&h->d_wt_dep, (size_t)h->Spad * 8));
+    HC(hipMalloc(&h->d_lstc, (size_t)h->Ppad * 16));
+    HC(hipMemset(h->d_lstc, 0, (size_t)h->Ppad * 16));
     HC(hipMalloc(&h->d_levels, (levels.size() + 1) * 8));
     HC(hipMalloc(&h->d_xy, E * 2 * 8));
     HC(hipMalloc(&h->d_radius, E * 8));
@@ -740,7 +754,9 @@ template <typename T> static StepArgs<T> make_args(clothhip_handle *h, const Clo
     a.HT = h->HT; a.ht_bits = h->ht_bits;
     a.rest_stride = h->rest_stride; a.phase_mask = h->phase_mask;
     a.k = make_consts<T>(h->prm);
-    a.pal_struct = (T)h->pal[SPRING_STRUCTURAL]; a.pal_shear = (T)h->pal[SPRING_SHEARING]; a.pal_bend = (T)h->pal[SPRING_BENDING];
+    if (sizeof(T) == 8) { a.pal_struct = (T)h->pal64[SPRING_STRUCTURAL]; a.pal_shear = (T)h->pal64[SPRING_SHEARING]; a.pal_bend = (T)h->pal64[SPRING_BENDING]; }
+    else { a.pal_struct = (T)h->pal[SPRING_STRUCTURAL]; a.pal_shear = (T)h->pal[SPRING_SHEARING]; a.pal_bend = (T)h->pal[SPRING_BENDING]; }
+    a.lstc = h->d_lstc;
     a.fz = nullptr;
     return a;
 }
@@ -753,6 +769,44 @@ static int lean_refresh(clothhip_handle *h) {
     if (!h->lean) return 0;
     if (h->lean_dirty) {
         h->lean_dirty = false; h->lean_ok = false;
+        if (h->rest_stride == 0 && h->precision == CLOTHHIP_F64) {
+            // fp64: every spring's rest length must be its type's smallest value + at most 255 ulps (the flat tiers: <= 46 at 50x50); the offsets go to
+            // the per-particle stencil table, slot k of particle i = its k-th stencil position (lean_off), i.e. the popcount(valid below k)-th gather entry
+            std::vector<double> r((size_t)h->Spad);
+            HIPCHECK(hipStreamSynchronize(h->stream));
+            HIPCHECK(hipMemcpy(r.data(), h->d_rest, r.size() * 8, hipMemcpyDeviceToHost));
+            long long base[3] = {0, 0, 0}; bool have[3] = {false, false, false}, ok = true;
+            auto bits = [](double v) { long long b; memcpy(&b, &v, 8); return b; };
+            for (int sp = 0; sp < h->S; sp++) {
+                const int ty = h->topo.type[sp];
+                const double v = r[h->wt.slot_of[sp]];
+                if (!(v > 0.0) || !std::isfinite(v)) { ok = false; break; }
+                if (!have[ty] || bits(v) < base[ty]) { base[ty] = bits(v); have[ty] = true; }
+            }
+            ok = ok && have[0] && have[1] && have[2];
+            std::vector<uint32_t> tab((size_t)h->Ppad * 4, 0u);
+            std::vector<uint32_t> gather = build_gather(h->topo, h->wt, h->Ppad);
+            for (int i = 0; i < h->P && ok; i++) {
+                const uint32_t vm = lean_valid_mask(i / h->N, i % h->N, h->N);
+                tab[(size_t)4 * i] = vm;
+                int slot = 0;
+                for (int k = 0; k < HK_SLOTS; k++) {
+                    if (!((vm >> k) & 1u)) continue;
+                    const uint32_t g = gather[(size_t)slot * h->Ppad + i];
+                    const int pos = (int)((g >> HK_POS_SHIFT) & HK_POS_MASK);
+                    const int sp = h->wt.spring_at[pos];
+                    const long long off = sp >= 0 ? bits(r[pos]) - base[h->topo.type[sp]] : -1;
+                    if (off < 0 || off > 255) { ok = false; break; }
+                    tab[(size_t)4 * i + 1 + (k >> 2)] |= (uint32_t)off << (8 * (k & 3));
+                    slot++;
+                }
+            }
+            if (ok) {
+                for (int t = 0; t < 3; t++) memcpy(&h->pal64[t], &base[t], 8);
+                HIPCHECK(hipMemcpy(h->d_lstc, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+            }
+            h->lean_ok = ok;
+        } else
         if (h->rest_stride == 0) {
             std::vector<float> r((size_t)h->Spad);
             HIPCHECK(hipStreamSynchronize(h->stream));
@@ -778,7 +832,7 @@ template <typename T, int FUSED> static const void *stepper_fn_t(const clothhip_
 #define X(T_, NT, PPT, TAB, RR) \
     if (h->nt == NT && h->ppt == PPT && h->tab == TAB && h->rest_reg == RR) return (const void *)k_run_schedule<T_, NT, PPT, TAB, RR, FUSED>;
     CLOTH_VARIANTS(X, T)
-    if constexpr (sizeof(T) == 4) { CLOTH_VARIANTS_LEAN(X, T) }
+    if constexpr (sizeof(T) == 4) { CLOTH_VARIANTS_LEAN(X, T) } else { CLOTH_VARIANTS_LEAN64(X, T) }
 #undef X
     return nullptr;
 }
@@ -824,7 +878,7 @@ template <typename T, int FUSED> static void launch_run(clothhip_handle *h, cons
         return;                                                                                         \
     }
     CLOTH_VARIANTS(X, T)
-    if constexpr (sizeof(T) == 4) { CLOTH_VARIANTS_LEAN(X, T) }
+    if constexpr (sizeof(T) == 4) { CLOTH_VARIANTS_LEAN(X, T) } else { CLOTH_VARIANTS_LEAN64(X, T) }
 #undef X
 }
 

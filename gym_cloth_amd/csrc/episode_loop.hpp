@@ -45,7 +45,9 @@ __host__ __device__ inline uint32_t lean_valid_mask(int r, int c, int N) {
 //   LEAN arithmetic       (REST_REG, fp32) TAB 0: built for three cloths per CU (168 VGPRs), -1: for four (128), 3: the whole CU for one cloth
 //                         (the large grids), 4: two large-grid cloths per CU -- the table streamed from L2 in these --; 2: table in LDS, two per CU
 //                         (with 512 threads x 2 particles: eight waves per cloth at 128 VGPRs, the headline variant)
-constexpr bool v_lean(int TAB, bool RR, int tsz) { return (TAB <= 0 || TAB == 2 || TAB == 3 || TAB == 4) && RR && tsz == 4; }
+//   LEAN arithmetic, fp64 (round 6) TAB 0 only: the stencil recomputed as above; a spring's rest length = the bit pattern of its type's palette value + a per-spring
+//                         offset in ulps (one byte, from an LDS-resident table): bit-identical to the table read it replaces, without the 24 L2 loads per particle
+constexpr bool v_lean(int TAB, bool RR, int tsz) { return RR && (tsz == 4 ? (TAB <= 0 || TAB == 2 || TAB == 3 || TAB == 4) : TAB == 0); }
 constexpr bool v_ldstab(int TAB) { return TAB == 1 || TAB == 2; }
 // the in-kernel metrics' hull stack as u16 indices (same arithmetic, an eighth of the LDS): the variants whose LDS is tight -- two large-grid
 // cloths per CU, five / six 25x25 cloths per CU, the fp64 instantiation of the large grids (50x50: 71 KB of scratch instead of 107 KB,
@@ -53,6 +55,7 @@ constexpr bool v_ldstab(int TAB) { return TAB == 1 || TAB == 2; }
 constexpr bool v_hull_idx(int TAB, int tsz = 4, int NT = 0, int PPT = 0) { return TAB == 4 || TAB <= -2 || (tsz == 8 && NT * PPT > 1024) || NT * PPT >= 4096; }
 constexpr int v_waves_per_eu(int NT, int TAB, bool lean, int PPT = 0) {      // __launch_bounds__' second argument: waves per SIMD
     if (!lean && NT == 512 && PPT == 2) return 4;                // eight waves per cloth, two cloths per CU (standard arithmetic)
+    if (lean && NT == 512 && PPT == 2 && TAB == 0) return 4;    // the fp64 LEAN build: eight waves per cloth, two cloths per CU (fp32 TAB 0 is a 256-thread build)
     if (!lean || TAB == 3) return NT <= 512 ? 2 : NT / 256;
     if (TAB == 2 || TAB == 4) return NT / 128;                   // two cloths per CU (4: the large grids, table streamed)
     return TAB < 0 ? 3 - TAB : 3;                                // TAB 0, -1, -2, -3: three, four, five, six cloths per CU
@@ -85,7 +88,8 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
         sc.dz_up = sc.dx_pull = sc.dy_pull = sc.dz_pull = 0.0;
     }
     const int P = A.P, Ppad = A.Ppad, HT = A.HT;
-    const LdsLayout lay((int)sizeof(T), Ppad, A.Spad, HT, TAB == 2 ? 2 : (v_ldstab(TAB) ? 1 : 0), A.cell_copy);
+    constexpr bool LEAN64 = v_lean(TAB, REST_REG, (int)sizeof(T)) && sizeof(T) == 8;
+    const LdsLayout lay((int)sizeof(T), Ppad, A.Spad, HT, TAB == 2 ? 2 : (v_ldstab(TAB) ? 1 : 0), A.cell_copy, LEAN64 ? 1 : 0);
     Pt<T> *cur = reinterpret_cast<Pt<T> *>(smem + lay.cur);
     uint32_t *hkey = reinterpret_cast<uint32_t *>(smem + lay.hkey);
     uint32_t *hco = reinterpret_cast<uint32_t *>(smem + lay.hco);
@@ -115,7 +119,16 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
     constexpr bool REST_R = REST_REG && !LEAN;
     uint32_t gt[GT_REG ? PPT : 1][HK_SLOTS];
     T rr[REST_R ? PPT : 1][HK_SLOTS];     // and those springs' rest lengths
-    uint32_t vm[LEAN ? PPT : 1];            // LEAN: which of the twelve stencil positions exist for the particle
+    uint32_t vm[(LEAN && !LEAN64) ? PPT : 1];   // LEAN: which of the twelve stencil positions exist for the particle (fp64: in the LDS table below)
+    // fp64 LEAN: per particle {mask, 12 offset bytes} in LDS (one 16-byte read at the head of the Hooke gather and of the strain pre-pass)
+    const uint4 *const lstc = reinterpret_cast<const uint4 *>(smem + lay.lstc);
+    auto lean_rest64 = [&](int sl, const uint4 &lw) -> T {
+        const uint32_t wsel = sl < 4 ? lw.y : (sl < 8 ? lw.z : lw.w);
+        const uint32_t off = (wsel >> (8 * (sl & 3))) & 0xFFu;
+        const double base = (double)(lean_bend(sl) ? A.pal_bend : (lean_shear(sl) ? A.pal_shear : A.pal_struct));
+        return (T)__longlong_as_double(__double_as_longlong(base) + (long long)off);
+    };
+    (void)lean_rest64; (void)lstc;
     uint32_t rc[RELAXED ? PPT : 1];         // RELAXED: the particle's grid position, r | c << 8 (parities of the colour classes)
     auto lean_entry = [&](int i, uint32_t vmq, int sl) -> uint32_t {      // a gather entry without its table-slot field
         const bool ok = ((vmq >> sl) & 1u) != 0u;
@@ -133,7 +146,8 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
             const int i = tid + q * NT;
             const bool ok = i < P;
             pvx[q] = ok ? gq[i] : (T)0; pvy[q] = ok ? gq[Ppad + i] : (T)0; pvz[q] = ok ? gq[2 * Ppad + i] : (T)0;
-            if (LEAN) { const int r_ = i / A.N; vm[LEAN ? q : 0] = ok ? lean_valid_mask(r_, i - r_ * A.N, A.N) : 0u; if (RELAXED) rc[RELAXED ? q : 0] = (uint32_t)r_ | ((uint32_t)(i - r_ * A.N) << 8); }
+            if (LEAN64) { }
+            else if (LEAN) { const int r_ = i / A.N; vm[(LEAN && !LEAN64) ? q : 0] = ok ? lean_valid_mask(r_, i - r_ * A.N, A.N) : 0u; if (RELAXED) rc[RELAXED ? q : 0] = (uint32_t)r_ | ((uint32_t)(i - r_ * A.N) << 8); }
             else
 #pragma unroll
             for (int sl = 0; sl < HK_SLOTS; sl++) {
@@ -155,6 +169,10 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
     };
     if (tid == 0) misc[15] = 0;
     init_lds(A.tear[e], A.wt_ent, g_rest);
+    if (LEAN64) {
+        uint4 *d_ = reinterpret_cast<uint4 *>(smem + lay.lstc);
+        for (int i = tid; i < Ppad; i += NT) d_[i] = A.lstc[i];
+    }
     uint16_t *pslot = reinterpret_cast<uint16_t *>(smem + lay.pslot);       // TAB 2 only
     if (TAB == 2) {
         for (int i = tid; i < Ppad; i += NT) {
@@ -277,7 +295,14 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
         __syncthreads();
         if (tid == 0 && Fp->resume != nullptr) Fp->resume[e].valid = 0;
     }
-    if (FUSED) { if (tid == 0) eps->t_launch = __builtin_amdgcn_s_memrealtime(); }   // 100 MHz, constant rate (thread 0 is the only reader)
+    if (FUSED) {
+        if (tid == 0) {
+            eps->t_launch = __builtin_amdgcn_s_memrealtime();   // 100 MHz, constant rate (thread 0 is the only reader)
+            // the time slice's DEADLINE beside it (EpState, LDS -- not in `misc`, which the in-kernel metrics overwrite): round 5 read Fp->budget_ticks --
+            // a global load on wave 0's path to a barrier -- in EVERY substep (found in the ISA while taking the pipelined loop apart, round 6)
+            eps->t_deadline = Fp->budget_ticks != 0 ? eps->t_launch + Fp->budget_ticks : ~0ull;
+        }
+    }
     int done_nf = 0;                   // executed substeps of the external schedule (not fused)
     for (;;) {
         bool do_run = true;
@@ -323,7 +348,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
 #include "substep_plane.inc.hpp"
         if (FUSED && sliced) {             // thread 0 looks at the clock here, between two barriers that every thread passes in
                                            // every substep; everyone reads its verdict at the end of the substep
-            if (tid == 0) misc[7] = (__builtin_amdgcn_s_memrealtime() - eps->t_launch >= Fp->budget_ticks) ? 1 : 0;
+            if (tid == 0) misc[7] = (__builtin_amdgcn_s_memrealtime() >= eps->t_deadline) ? 1 : 0;
         }
         __syncthreads();
 

@@ -26,6 +26,8 @@
 #define CLOTH_VARIANTS_LEAN_LARGE(X, T) X(T, 1024, 3, 3, true) X(T, 1024, 4, 3, true) X(T, 512, 5, 4, true)
 #endif
 #define CLOTH_VARIANTS_LEAN(X, T) CLOTH_VARIANTS_LEAN_SMALL(X, T) CLOTH_VARIANTS_LEAN_LARGE(X, T)
+// the fp64 LEAN build (25x25 class, eight waves per cloth; rest lengths = palette value + per-spring ulp offset)
+#define CLOTH_VARIANTS_LEAN64(X, T) X(T, 512, 2, 0, true)
 
 // every variant exists for FUSED = 0 (one external schedule), 1 (episodes, flat tiers), 2 (episodes incl. tier-2 resets and the cold policies)
 #define CLOTH_FUSED3(KW, T, NT, PPT, TAB, RR)                                                        \
@@ -36,14 +38,14 @@
 #define CLOTH_DEFN(T, NT, PPT, TAB, RR) CLOTH_FUSED3(, T, NT, PPT, TAB, RR)
 
 // The groups (object files). CLOTHHIP_INST_GROUPS of them; stepper_inst.hip defines group CLOTHHIP_INST_GROUP, everybody else declares.
-//   0 fp32 standard small   1 fp64 standard small   2 fp32 standard large   3 fp64 standard large   4 LEAN small (+ the relaxed-order companion)   5 LEAN large
+//   0 fp32 standard small   1 fp64 standard small   2 fp32 standard large   3 fp64 standard large   4 LEAN small (+ the relaxed-order companion)   5 LEAN large + fp64 LEAN
 #define CLOTHHIP_INST_GROUPS 6
 #define CLOTH_GROUP_0(M) CLOTH_VARIANTS_SMALL(M, float)
 #define CLOTH_GROUP_1(M) CLOTH_VARIANTS_SMALL(M, double)
 #define CLOTH_GROUP_2(M) CLOTH_VARIANTS_LARGE(M, float)
 #define CLOTH_GROUP_3(M) CLOTH_VARIANTS_LARGE(M, double)
 #define CLOTH_GROUP_4(M) CLOTH_VARIANTS_LEAN_SMALL(M, float)
-#define CLOTH_GROUP_5(M) CLOTH_VARIANTS_LEAN_LARGE(M, float)
+#define CLOTH_GROUP_5(M) CLOTH_VARIANTS_LEAN_LARGE(M, float) CLOTH_VARIANTS_LEAN64(M, double)
 #define CLOTH_RELAXED(KW) KW template __global__ void clothhip::k_run_schedule<float, 512, 2, 2, true, 3>(clothhip::StepArgs<float>);
 
 #ifndef CLOTHHIP_INST_GROUP          // a user of the kernels (clothhip_api.hip): nothing is instantiated here

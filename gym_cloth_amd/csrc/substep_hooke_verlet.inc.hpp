@@ -21,7 +21,7 @@
                     wme[q] = w_cnt(me.w);
                     T fx = (T)0 + (T)0, fy = (T)0 + (T)0, fz = (T)0 + k.mg;
                     uint32_t gl[HK_SLOTS];
-                    int iq_ = tid + q * NT; uint32_t vq_ = vm[LEAN ? q : 0];
+                    int iq_ = tid + q * NT; uint4 lw_ = uint4{0u, 0u, 0u, 0u}; if constexpr (LEAN64) lw_ = lstc[iq_]; uint32_t vq_ = LEAN64 ? lw_.x : vm[(LEAN && !LEAN64) ? q : 0];
                     if (LEAN) asm volatile("" : "+v"(iq_), "+v"(vq_));     // opaque: the stencil is recomputed every substep, not hoisted and held
 #pragma unroll
                     for (int sl = 0; sl < HK_SLOTS; sl++)
@@ -57,7 +57,7 @@
                             nbq[sl % HK_AHEAD] = cur[gn & HK_NBR_MASK];
                         }
                         __builtin_amdgcn_sched_barrier(0);  // the reads above stay above the arithmetic below
-                        const T r = LEAN ? lean_rest(sl) : (REST_R ? rr[REST_R ? q : 0][sl] : rest_at((g >> HK_POS_SHIFT) & HK_POS_MASK));
+                        const T r = LEAN64 ? lean_rest64(sl, lw_) : LEAN ? lean_rest(sl) : (REST_R ? rr[REST_R ? q : 0][sl] : rest_at((g >> HK_POS_SHIFT) & HK_POS_MASK));
                         const T kk = (LEAN ? lean_bend(sl) : (g & HK_BEND) != 0u) ? k.ks_bend : k.ks_str;
                         const T dx = nb.x - me.x, dy = nb.y - me.y, dz = nb.z - me.z;
                         const T l = fastnorm<T>(dx, dy, dz);                                      // :231

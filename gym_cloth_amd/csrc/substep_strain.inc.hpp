@@ -24,7 +24,7 @@
                     const int i = tid + q * NT;
                     const int r_ = (int)(rc[RELAXED ? q : 0] & 0xFFu), c_ = (int)(rc[RELAXED ? q : 0] >> 8);
                     const int key = (kind == 1 || kind == 5) ? c_ : r_;
-                    const bool on = i < P && ((vm[LEAN ? q : 0] >> kind) & 1u) && (((kind >= 4 ? key >> 1 : key) & 1) == par);
+                    const bool on = i < P && ((vm[(LEAN && !LEAN64) ? q : 0] >> kind) & 1u) && (((kind >= 4 ? key >> 1 : key) & 1) == par);
                     if (on) {
                         const int j = i + (kind == 0 ? -Ak_->N : kind == 1 ? -1 : kind == 2 ? -Ak_->N - 1 : kind == 3 ? -Ak_->N + 1 : kind == 4 ? -2 * Ak_->N : -2);
                         const Pt<T> a_ = cur[j], b_ = cur[i];                                  // ptA (the earlier point), ptB (the owner)
@@ -64,7 +64,7 @@
                         const Pt<T> me = cur[tid + q * NT];
                         const uint32_t cme_ = w_cnt(me.w);
                         uint32_t gl[HK_SLOTS / 2];
-                        int iq_ = tid + q * NT; uint32_t vq_ = vm[LEAN ? q : 0];
+                        int iq_ = tid + q * NT; uint4 lw_ = uint4{0u, 0u, 0u, 0u}; if constexpr (LEAN64) lw_ = lstc[iq_]; uint32_t vq_ = LEAN64 ? lw_.x : vm[(LEAN && !LEAN64) ? q : 0];
                         if (LEAN) asm volatile("" : "+v"(iq_), "+v"(vq_));
 #pragma unroll
                         for (int sl = 0; sl < HK_SLOTS / 2; sl++)
@@ -93,7 +93,7 @@
                                 nbq[sl % PP_AHEAD] = cur[gn & HK_NBR_MASK];
                             }
                             __builtin_amdgcn_sched_barrier(0);
-                            T r = LEAN ? lean_rest(sl) : (REST_R ? rr[REST_R ? q : 0][sl] : rest_at((g >> HK_POS_SHIFT) & HK_POS_MASK));
+                            T r = LEAN64 ? lean_rest64(sl, lw_) : LEAN ? lean_rest(sl) : (REST_R ? rr[REST_R ? q : 0][sl] : rest_at((g >> HK_POS_SHIFT) & HK_POS_MASK));
                             asm volatile("" : "+v"(r));     // or the thresholds below are hoisted out of the substep loop
                                                             // for all 18 springs and live in scratch
                             const T dx = nb.x - me.x, dy = nb.y - me.y, dz = nb.z - me.z;   // (ptA - ptB), as :270
@@ -122,7 +122,7 @@
                                     //  is compacted, the sl-th stencil position is the particle's popcount(valid below sl)-th entry)
                                     const uint32_t pos_ = TAB == 2 ? (uint32_t)pslot[sl * Ppad + iq_] : ((LEAN ? Ak_->gather[__popc(vq_ & ((1u << sl) - 1u)) * Ppad + iq_] : gl[sl])      // (the opaque copies: nothing of this is hoisted out of the substep loop and held)
                                                            >> HK_POS_SHIFT) & HK_POS_MASK;
-                                    T r = LEAN ? lean_rest(sl) : (REST_R ? rr[REST_R ? q : 0][sl] : rest_at(pos_));
+                                    T r = LEAN64 ? lean_rest64(sl, lw_) : LEAN ? lean_rest(sl) : (REST_R ? rr[REST_R ? q : 0][sl] : rest_at(pos_));
                                     asm volatile("" : "+v"(r));
                                     const T len2 = l2s[sl];
                                     const T t11 = r * k.c11, tt = r * k.tear_thresh;
