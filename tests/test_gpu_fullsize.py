@@ -104,7 +104,9 @@ def test_full_batch_bench_step_f64_sample_matches_oracle(E, n_side, tier, oracle
         ex = env.last_executed.copy()
     assert env.batch.fused_supported                                 # 512 x 25x25 and 1 024 x 50x50 alike
     var = env.batch.last_variant()
-    assert var["precision"] == "f64" and not var["lean"] and (var["fused"] >= 1) == bool(env.batch.fused_supported), var
+    # (round 6: the flat tiers' fp64 handle of the 25x25 class runs the fp64 LEAN build -- stencil recomputed, rest = palette bits + ulp offset --;
+    #  per-env rest tables (tier 2) and the large grids keep the standard arithmetic)
+    assert var["precision"] == "f64" and var["lean"] == (tier != "tier2" and n_side == 25) and (var["fused"] >= 1) == bool(env.batch.fused_supported), var
     if var["n_cus"] == 256:
         assert var["threads"] == 512 and var["particles_per_thread"] == (2 if n_side == 25 else 5), var
     pos1, prev1, _ = env.batch.get_state()
@@ -202,3 +204,41 @@ def test_time_sliced_launch_goes_out_per_generation_and_equals_the_single_launch
         assert np.array_equal(x, y, equal_nan=True)
     for x, y in zip(a[6], b[6]):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("E,n_side,want_tab", [(512, 25, 2), (1536, 25, -3), (1024, 50, 4)], ids=["512x25", "1536x25", "1024x50"])
+def test_benched_f32_handles_meet_the_oracle_directly_over_one_substep(E, n_side, want_tab, oracle_lib, monkeypatch):
+    """The fp32 variants the bench runs -- picked by clothhip_create from the batch size, no override -- against the fp64 ORACLE itself (not
+    against another fp32 build): ONE update() of the whole batch from its tier-1 post-reset states (crumpled by the reset pulls: every phase
+    acts), a seeded sample of 64 cloths replayed by the oracle from the same fp32 states and the same fp32 rest lengths. After a single substep
+    nothing has been amplified: the difference is the stepper's own rounding, <= 6e-7 on positions of O(1) (measured 2e-7; the band of
+    tests/test_gpu_parity.py::test_f32_single_substep_on_post_reset_states). Reference: Cloth.update, cloth.pyx:169-214."""
+    for v in DEBUG_VARS:
+        monkeypatch.delenv(v, raising=False)
+    cfg, env = _bench_env(E, n_side, "tier1", "f32")
+    pos0, prev0, pin0 = env.batch.get_state()
+    rest = env.batch.get_rest()
+    env.batch.update(1)
+    var = env.batch.last_variant()
+    assert var["precision"] == "f32" and var["lean"], var
+    if var["n_cus"] == 256:
+        assert var["table_mode"] == want_tab, var                 # the variant the bench record names for this batch size
+    pos1, prev1, _ = env.batch.get_state()
+    c, ev = cfg["cloth"], cfg["env"]
+    ocfg = {"n_side": n_side, "width": c["width"], "height": c["height"], "density": c["density"], "ks": c["ks"], "damping": c["damping"],
+            "thickness": c["thickness"], "plane_friction": c["plane_friction"], "tear_thresh": c["tear_thresh"],
+            "frames_per_sec": cfg["frames_per_sec"], "simulation_steps": cfg["simulation_steps"], "gravity": -9.8, "minimum_z": 0.0,
+            "grip_radius": ev["grip_radius"]}
+    sample = np.sort(np.random.RandomState(6000 + E + n_side).choice(E, 64, replace=False))
+    errs, moved = [], []
+    for e in sample:
+        oc = oracle_lib.OracleCloth(ocfg)
+        oc.set_state(pos0[e], prev0[e], pin0[e], rest[e if rest.shape[0] > 1 else 0])
+        oc.update(1)
+        op, oq, _ = oc.get_state()
+        errs.append(float(np.abs(pos1[e] - op).max()))
+        moved.append(float(np.abs(op - pos0[e]).max()))
+    print("\nfp32 %s over one substep vs the oracle, 64 of %d cloths: max err %.3e, largest move %.2e" % (var["name"], E, max(errs), max(moved)))
+    assert max(moved) > 1e-5                                      # the states are live
+    assert max(errs) <= 6e-7, sorted(errs)[-5:]
+    env.close()

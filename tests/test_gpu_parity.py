@@ -86,12 +86,28 @@ F32_WINDOW_MEASURED = {
 F32_WINDOW_SLACK = 3.0
 
 
+def f32_stated_band(name, nsub):
+    """The tolerance STATED IN ADVANCE for a teacher-forced fp32 window, by its length alone (SURVEY 7-H2: one fp32 ulp of a position is 6e-8;
+    rounding is not amplified over the first substeps, by ~1e3 .. 1e4 over 200 substeps of a pull; the friction fixture slides on the plane
+    with friction 0.5 and amplifies ten times more). This is the hard bound of the test; F32_WINDOW_MEASURED only adds a tighter regression
+    guard on top (a band fitted to the code's own output must not be the only assert)."""
+    soft = "friction" in name
+    if nsub <= 1:
+        return 1e-6
+    if nsub <= 10:
+        return 5e-6
+    if nsub <= 60:
+        return 1e-3 if soft else 5e-4
+    return 2e-2 if soft else 2e-3
+
+
 @pytest.mark.parametrize("name,lean", F32_WINDOW_CASES)
 def test_f32_teacher_forced_windows(name, lean, oracle_lib, monkeypatch):
     """fp32 instantiation, teacher-forced: restart from every reference checkpoint, run to the next one
-    (<= ~200 substeps) and compare. Tolerance (stated): 3x the error this very window showed when the bands were
-    set (F32_WINDOW_MEASURED above: the stepper is deterministic, so a window's error only moves when its arithmetic does), i.e.
-    <= 8.1e-7 after one substep, <= 5.4e-7 after <= 10, <= 1.8e-4 after <= 60, <= 1.5e-3 after <= 200 (friction fixture: 7.4e-4 / 1.7e-2).
+    (<= ~200 substeps) and compare. Tolerance: the band STATED for the window's length (f32_stated_band: <= 1e-6 after one substep,
+    <= 5e-6 after <= 10, <= 5e-4 after <= 60, <= 2e-3 after <= 200; friction fixture 1e-3 / 2e-2) is the hard assert; on top of it a
+    regression guard of 3x the error this very window showed when F32_WINDOW_MEASURED was recorded (the stepper is deterministic, so a
+    window's error only moves when its arithmetic does).
     Run for the standard variant and for every build of the LEAN variant; the library reports which variant each launch ran
     (clothhip_last_variant)."""
     from gym_cloth_amd import ClothBatch
@@ -130,11 +146,13 @@ def test_f32_teacher_forced_windows(name, lean, oracle_lib, monkeypatch):
             assert var["table_mode"] == 4 and var["threads"] == 512 and var["cloths_per_cu"] == 2 and var["lds_bytes"] <= 80 * 1024, var
         pos = b.positions()[0]
         err = max_abs(pos, g["cp_pos"][k + 1])
-        tol = F32_WINDOW_SLACK * F32_WINDOW_MEASURED[name][k]
-        worst.append((k, nsub, err, tol))
+        stated = f32_stated_band(name, nsub)
+        guard = F32_WINDOW_SLACK * F32_WINDOW_MEASURED[name][k]
+        worst.append((k, nsub, err, stated, min(stated, guard)))
     print("\nfp32 windows %s (lean %d): %s" % (name, lean, ["cp%d n=%d err=%.2e" % w[:3] for w in worst]))
     assert worst
-    assert all(w[2] <= w[3] for w in worst), worst
+    assert all(w[2] <= w[3] for w in worst), ("beyond the stated band of the window's length", worst)
+    assert all(w[2] <= w[4] for w in worst), ("regression guard: beyond 3x the error this window showed when the table was recorded", worst)
 
 
 @pytest.mark.parametrize("lean", [0, 8, 4, 6])
