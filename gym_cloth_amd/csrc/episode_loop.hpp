@@ -328,11 +328,24 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
         };
         const T dz_up = uni((T)sc.dz_up), dxp = uni((T)sc.dx_pull), dyp = uni((T)sc.dy_pull), dzp = uni((T)sc.dz_pull);
         const bool sliced = FUSED && Fp->budget_ticks != 0 && Fp->resume != nullptr;
+#ifndef CLOTHHIP_UNIFORM_SCHED
+#define CLOTHHIP_UNIFORM_SCHED 1
+#endif
+        // (round 6, from the ISA: the schedule's phase bounds and the loop counter are the same in every lane, but the compiler does not know --
+        //  held in VGPRs they turned the "which phase is substep `it` in" ladder at the head of every substep and the loop's exit test into
+        //  vector compares + exec-mask branches, ~40 cycles each, and occupied seven VGPRs across the whole loop: scalar from here on)
+        const int n_up_end_ = CLOTHHIP_UNIFORM_SCHED ? __builtin_amdgcn_readfirstlane(sc.n_up_end) : sc.n_up_end;
+        const int n_uprest_end_ = CLOTHHIP_UNIFORM_SCHED ? __builtin_amdgcn_readfirstlane(sc.n_uprest_end) : sc.n_uprest_end;
+        const int n_pull_end_ = CLOTHHIP_UNIFORM_SCHED ? __builtin_amdgcn_readfirstlane(sc.n_pull_end) : sc.n_pull_end;
+        const int n_griprest_end_ = CLOTHHIP_UNIFORM_SCHED ? __builtin_amdgcn_readfirstlane(sc.n_griprest_end) : sc.n_griprest_end;
+        const int n_total_ = CLOTHHIP_UNIFORM_SCHED ? __builtin_amdgcn_readfirstlane(sc.n_total) : sc.n_total;
+        const int break_on_tear_ = CLOTHHIP_UNIFORM_SCHED ? __builtin_amdgcn_readfirstlane(sc.break_on_tear) : sc.break_on_tear;
+        const int it0_ = CLOTHHIP_UNIFORM_SCHED ? __builtin_amdgcn_readfirstlane(resumed_run ? resume_it : 0) : (resumed_run ? resume_it : 0);
     const int tid_outer_ = tid;
 #ifdef CLOTHHIP_CELL_COUNTERS
     bool frozen_prev_ = false;
 #endif
-    for (int it = resumed_run ? resume_it : 0; it < sc.n_total; it++) {
+    for (int it = it0_; it < n_total_; it++) {
         // LEAN and fp64: everything derived from the thread index (LDS addresses of the owned particles, table offsets) is formed anew in
         // every substep instead of being hoisted out of the loop and held -- or spilled -- for the whole schedule
         int tid = tid_outer_;
@@ -356,8 +369,8 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
 #include "substep_strain.inc.hpp"
         if (timing) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory"); }
         done++;
-        if (sc.break_on_tear && misc[0]) break;                                            // cloth_env.py:511-514
-        if (FUSED && sliced && misc[7] && it + 1 < sc.n_total) { it_next = it + 1; break; }
+        if (break_on_tear_ && misc[0]) break;                                            // cloth_env.py:511-514
+        if (FUSED && sliced && misc[7] && it + 1 < n_total_) { it_next = it + 1; break; }
     }
         }   // the run
         resume_it = -1;

@@ -5,10 +5,10 @@
 // one-file kernel's. Names it uses from the kernel body: it, sc, dz_up, dxp, dyp, dzp, tid, P, cur, pvx/pvy/pvz; defines mode.
         // ---- ClothEnv._pull (cloth_env.py:352-367): adjust / nothing / release -------------------
         int mode = 0; T ax = 0, ay = 0, az = 0;
-        if (it < sc.n_up_end) { mode = 1; az = dz_up; }
-        else if (it < sc.n_uprest_end) { }
-        else if (it < sc.n_pull_end) { mode = 1; ax = dxp; ay = dyp; az = dzp; }
-        else if (it < sc.n_griprest_end) { }
+        if (it < n_up_end_) { mode = 1; az = dz_up; }
+        else if (it < n_uprest_end_) { }
+        else if (it < n_pull_end_) { mode = 1; ax = dxp; ay = dyp; az = dzp; }
+        else if (it < n_griprest_end_) { }
         else mode = 2;
         if (mode == 1) {
             Pt<T> cq[PPT];
@@ -29,7 +29,7 @@
                 }
             }
             __syncthreads();
-        } else if (mode == 2 && it == sc.n_griprest_end) {      // release() is idempotent: only its first call acts
+        } else if (mode == 2 && it == n_griprest_end_) {      // release() is idempotent: only its first call acts
 #pragma unroll
             for (int q = 0; q < PPT; q++) {
                 const int i = tid + q * NT;
