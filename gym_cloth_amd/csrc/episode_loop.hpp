@@ -343,7 +343,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
         const int it0_ = CLOTHHIP_UNIFORM_SCHED ? __builtin_amdgcn_readfirstlane(resumed_run ? resume_it : 0) : (resumed_run ? resume_it : 0);
     const int tid_outer_ = tid;
 #ifdef CLOTHHIP_CELL_COUNTERS
-    bool frozen_prev_ = false;
+    bool frozen_prev_ = false; (void)frozen_prev_;
 #endif
     for (int it = it0_; it < n_total_; it++) {
         // LEAN and fp64: everything derived from the thread index (LDS addresses of the owned particles, table offsets) is formed anew in
