@@ -131,6 +131,7 @@ SYMBOLS = [
     ("clothhip_debug_stats", C.c_int, [_vp, _i32p]),
     ("clothhip_last_variant", C.c_int, [_vp, _i32p]),
     ("clothhip_last_dispatches", C.c_int, [_vp, _i32p]),
+    ("clothhip_last_specialised", C.c_int, [_vp, _i32p]),
     ("clothhip_set_relaxed_order", C.c_int, [_vp, C.c_int32]),
     ("clothhip_selftest_windows", C.c_int, [_PP, _i32p, _i32p, _i32p, _i32p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_int32]),
     ("clothhip_selftest_layout", C.c_int, [_PP, C.c_int32, C.c_int32, C.c_int32, _i32p, C.c_int32]),

@@ -357,6 +357,10 @@ class ClothBatch(object):
         n = np.zeros(1, dtype=np.int32)
         check(self._L.clothhip_last_dispatches(self._h, _lib.i32p(n)))
         d["dispatches"] = int(n[0])            # kernel dispatches the launch went out as (one per generation of a time-sliced launch)
+        check(self._L.clothhip_last_specialised(self._h, _lib.i32p(n)))
+        d["spec_n_side"] = int(n[0])           # 25: the grid-specialised build of that variant ran (25x25 at compile time); 0: the generic build
+        if n[0]:
+            d["name"] = d["name"].replace(">", ",N%d>" % n[0], 1)
         return d
 
     def set_relaxed_order(self, on=True):

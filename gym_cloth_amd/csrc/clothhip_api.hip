@@ -71,6 +71,8 @@ struct clothhip_handle {
     bool lean = false, lean_dirty = true, lean_ok = false, lean_stencil_ok = false;
     bool relaxed = false;   // clothhip_set_relaxed_order(h, 1): THIS handle's episode launches run the relaxed-order companion kernel (bench only, no parity)
     int last_dispatches = 0; // kernel dispatches the last stepper launch was issued as (clothhip_last_dispatches)
+    int spec_now = 0;        // 25: the layout in use runs the grid-specialised build (decided by lean_refresh per launch: spec_ok); 0: the generic build
+    int last_spec = 0;       // what the last launch ran (clothhip_last_specialised)
     int lean_r = 3;         // cloths per CU the chosen LEAN build is compiled for (3: 168 VGPRs, 4: 128 VGPRs; 2: eight waves per cloth, table in LDS; 1: the large grids)
     float pal[3] = {0, 0, 0};
     double pal64[3] = {0, 0, 0};     // fp64 LEAN build: the smallest rest length of each spring type (the others are it + a few ulps: StepArgs::lstc)
@@ -214,6 +216,7 @@ static void free_handle(clothhip_handle *h) {
 }
 
 static const void *stepper_fn(const clothhip_handle *h, int fused);
+static bool spec_ok(const clothhip_handle *h);
 
 // The LDS a layout leaves the in-kernel metrics (from the hash table to the end of the allocation) against what they need; the
 // allocation is padded behind the layout's end when that fits the budget (the kernel addresses LDS by the layout's offsets: bytes
@@ -471,12 +474,19 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
         if (h->lds_bytes > 160 * 1024) { free_handle(h); return fail(CLOTHHIP_EINVAL, "n_side %d needs %d B of LDS (> 160 KiB)", h->N, h->lds_bytes); }
         if (h->lean) {                                   // the lean kernels too (which layout runs is decided per launch)
             const clothhip_handle::Layout keep = {h->nt, h->ppt, h->tab, h->rest_reg, h->cell_copy, h->lds_bytes};
+            const int keep_ht = h->HT, keep_hb = h->ht_bits;
             h->nt = h->lay_lean.nt; h->ppt = h->lay_lean.ppt; h->tab = h->lay_lean.tab; h->rest_reg = h->lay_lean.rest_reg;
-            for (int f = 0; f < 3; f++) {
-                const void *fl = stepper_fn(h, f);
-                if (!fl) { free_handle(h); return fail(CLOTHHIP_EINVAL, "no lean stepper variant for n_side %d", h->N); }
-                HC(hipFuncSetAttribute(fl, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            h->cell_copy = h->lay_lean.cell_copy; h->HT = h->lay_lean.HT; h->ht_bits = h->lay_lean.ht_bits;
+            for (int sp = 0; sp < 2; sp++) {             // the generic build of the layout and, where it exists for it, the grid-specialised one
+                h->spec_now = (sp == 1 && spec_ok(h)) ? 25 : 0;
+                if (sp == 1 && !h->spec_now) break;
+                for (int f = 0; f < 3; f++) {
+                    const void *fl = stepper_fn(h, f);
+                    if (!fl) { free_handle(h); return fail(CLOTHHIP_EINVAL, "no lean stepper variant for n_side %d", h->N); }
+                    HC(hipFuncSetAttribute(fl, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                }
             }
+            h->spec_now = 0; h->cell_copy = keep.cell_copy; h->HT = keep_ht; h->ht_bits = keep_hb;
             h->nt = keep.nt; h->ppt = keep.ppt; h->tab = keep.tab; h->rest_reg = keep.rest_reg;
         }
         const void *fn = stepper_fn(h, 0), *fnf = stepper_fn(h, 1), *fnf2 = stepper_fn(h, 2);
@@ -765,8 +775,20 @@ template <typename T> static StepArgs<T> make_args(clothhip_handle *h, const Clo
 // rest table is a three-value palette (re-checked whenever the table may have changed: per-env tables, i.e. tier 2, or odd
 // rest lengths uploaded by the caller switch back), else the standard variant. LDS is rebuilt by every launch, so the layout
 // may change from one launch to the next.
+// May the layout the handle's fields describe NOW run a grid-specialised kernel (k_run_schedule<..., NS = 25>)? Only if every constant that build
+// has compiled in (cloth_common.hpp: spec_*) is what this handle computed: the 25x25 grid, its window table, the hash-table size, the LEAN fp32
+// arithmetic in one of the specialised layouts with the cell-ordered copy where the build expects it, and all phases on (debug masks take the
+// generic build, as does CLOTHHIP_DEBUG_NOSPEC=1 -- the A/B and the bit-identity test of the two).
+static bool spec_ok(const clothhip_handle *h) {
+    if (getenv("CLOTHHIP_DEBUG_NOSPEC") && atoi(getenv("CLOTHHIP_DEBUG_NOSPEC"))) return false;
+    if (h->precision != CLOTHHIP_F32 || !h->rest_reg || h->N != 25 || h->phase_mask != 15) return false;
+    if (!((h->nt == 512 && h->ppt == 2 && h->tab == 2) || (h->nt == 256 && h->ppt == 3 && h->tab <= 0 && h->tab >= -3))) return false;
+    return h->P == spec_p(25) && h->Ppad == spec_ppad(25) && h->HT == spec_ht(25) && h->ht_bits == spec_htbits(25) && h->Spad == spec_spad(25) &&
+           h->wt.nW == spec_nw(25) && h->wt.reach_shift == 0 && h->cell_copy == spec_cell_copy(h->tab);
+}
+
 static int lean_refresh(clothhip_handle *h) {
-    if (!h->lean) return 0;
+    if (!h->lean) { h->spec_now = 0; return 0; }
     if (h->lean_dirty) {
         h->lean_dirty = false; h->lean_ok = false;
         if (h->rest_stride == 0 && h->precision == CLOTHHIP_F64) {
@@ -824,6 +846,7 @@ static int lean_refresh(clothhip_handle *h) {
     const clothhip_handle::Layout &L = (h->lean_ok && h->rest_stride == 0) ? h->lay_lean : h->lay_std;
     h->nt = L.nt; h->ppt = L.ppt; h->tab = L.tab; h->rest_reg = L.rest_reg; h->cell_copy = L.cell_copy; h->lds_bytes = L.lds_bytes;
     h->HT = L.HT; h->ht_bits = L.ht_bits;
+    h->spec_now = spec_ok(h) ? 25 : 0;
     return 0;
 }
 
@@ -831,6 +854,14 @@ static int lean_refresh(clothhip_handle *h) {
 template <typename T, int FUSED> static const void *stepper_fn_t(const clothhip_handle *h) {
 #define X(T_, NT, PPT, TAB, RR) \
     if (h->nt == NT && h->ppt == PPT && h->tab == TAB && h->rest_reg == RR) return (const void *)k_run_schedule<T_, NT, PPT, TAB, RR, FUSED>;
+    if constexpr (sizeof(T) == 4) {
+        if (h->spec_now == 25) {
+#define XS(T_, NT, PPT, TAB, RR) \
+            if (h->nt == NT && h->ppt == PPT && h->tab == TAB && h->rest_reg == RR) return (const void *)k_run_schedule<T_, NT, PPT, TAB, RR, FUSED, 25>;
+            CLOTH_VARIANTS_SPEC25(XS, T)
+#undef XS
+        }
+    }
     CLOTH_VARIANTS(X, T)
     if constexpr (sizeof(T) == 4) { CLOTH_VARIANTS_LEAN(X, T) } else { CLOTH_VARIANTS_LEAN64(X, T) }
 #undef X
@@ -864,22 +895,29 @@ template <typename T, int FUSED> static void launch_run(clothhip_handle *h, cons
     StepArgs<T> a = make_args<T>(h, d_sched);
     a.fz = (const FusedArgs<T> *)d_fz;
     a.e0 = 0;
-#define X(T_, NT, PPT, TAB, RR)                                                                         \
+#define XN(T_, NT, PPT, TAB, RR, NS_)                                                                   \
     if (h->nt == NT && h->ppt == PPT && h->tab == TAB && h->rest_reg == RR) {                           \
-        const int occ_ = cached_occupancy(h, (const void *)k_run_schedule<T_, NT, PPT, TAB, RR, FUSED>, NT);    \
+        const int occ_ = cached_occupancy(h, (const void *)k_run_schedule<T_, NT, PPT, TAB, RR, FUSED, NS_>, NT);    \
         const int cap_ = by_generation && occ_ > 0 && h->n_cus > 0 && !getenv("CLOTHHIP_DEBUG_ONE_LAUNCH") ? occ_ * h->n_cus : h->E;   \
         h->last_dispatches = 0;                                                                         \
         for (int e0_ = 0; e0_ < h->E; e0_ += cap_) {                                                    \
             a.e0 = e0_; h->last_dispatches++;                                                           \
-            hipLaunchKernelGGL((k_run_schedule<T_, NT, PPT, TAB, RR, FUSED>), dim3(std::min(cap_, h->E - e0_)), dim3(NT), h->lds_bytes, h->stream, a); \
+            hipLaunchKernelGGL((k_run_schedule<T_, NT, PPT, TAB, RR, FUSED, NS_>), dim3(std::min(cap_, h->E - e0_)), dim3(NT), h->lds_bytes, h->stream, a); \
         }                                                                                               \
         const int32_t v_[10] = {NT, PPT, TAB, RR ? 1 : 0, v_lean(TAB, RR, (int)sizeof(T_)) ? 1 : 0, FUSED, h->lds_bytes, occ_, h->n_cus, sizeof(T_) == 4 ? 1 : 0}; \
-        memcpy(h->last_variant, v_, sizeof(v_)); h->have_variant = true;                                \
+        memcpy(h->last_variant, v_, sizeof(v_)); h->have_variant = true; h->last_spec = NS_;            \
         return;                                                                                         \
+    }
+#define X(T_, NT, PPT, TAB, RR) XN(T_, NT, PPT, TAB, RR, 0)
+#define XS(T_, NT, PPT, TAB, RR) XN(T_, NT, PPT, TAB, RR, 25)
+    if constexpr (sizeof(T) == 4) {
+        if (h->spec_now == 25) { CLOTH_VARIANTS_SPEC25(XS, T) }
     }
     CLOTH_VARIANTS(X, T)
     if constexpr (sizeof(T) == 4) { CLOTH_VARIANTS_LEAN(X, T) } else { CLOTH_VARIANTS_LEAN64(X, T) }
 #undef X
+#undef XS
+#undef XN
 }
 
 // The relaxed-order companion (k_run_schedule<float, 512, 2, 2, true, 3>: Jacobi self-collision, coloured strain limit): ONE instantiation,
@@ -889,7 +927,7 @@ static void launch_relaxed(clothhip_handle *h, const void *d_fz) {
     StepArgs<float> a = make_args<float>(h, h->d_sched);
     a.fz = (const FusedArgs<float> *)d_fz;
     hipLaunchKernelGGL((k_run_schedule<float, 512, 2, 2, true, 3>), dim3(h->E), dim3(512), h->lds_bytes, h->stream, a);
-    h->last_dispatches = 1;
+    h->last_dispatches = 1; h->last_spec = 0;
     const int occ_ = cached_occupancy(h, (const void *)k_run_schedule<float, 512, 2, 2, true, 3>, 512);
     const int32_t v_[10] = {512, 2, 2, 1, 1, 3, h->lds_bytes, occ_, h->n_cus, 1};
     memcpy(h->last_variant, v_, sizeof(v_)); h->have_variant = true;
@@ -1367,6 +1405,13 @@ extern "C" int clothhip_set_relaxed_order(clothhip_handle *h, int32_t on) {
         HIPCHECK(hipFuncSetAttribute((const void *)k_run_schedule<float, 512, 2, 2, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     h->relaxed = on != 0;
+    return 0;
+}
+
+extern "C" int clothhip_last_specialised(clothhip_handle *h, int32_t *n_side) {
+    if (!h || !n_side) return fail(CLOTHHIP_EINVAL, "NULL argument");
+    if (!h->have_variant) return fail(CLOTHHIP_ESTATE, "no stepper launch on this handle yet");
+    *n_side = h->last_spec;
     return 0;
 }
 

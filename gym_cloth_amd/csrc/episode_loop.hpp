@@ -60,8 +60,10 @@ constexpr int v_waves_per_eu(int NT, int TAB, bool lean, int PPT = 0) {      // 
     if (TAB == 2 || TAB == 4) return NT / 128;                   // two cloths per CU (4: the large grids, table streamed)
     return TAB < 0 ? 3 - TAB : 3;                                // TAB 0, -1, -2, -3: three, four, five, six cloths per CU
 }
-template <typename T, int NT, int PPT, int TAB, bool REST_REG, int FUSED>
+// NS: 0 = any grid (sizes from the kernel arguments); 25 = the BASELINE grid known at compile time (cloth_common.hpp: spec_*)
+template <typename T, int NT, int PPT, int TAB, bool REST_REG, int FUSED, int NS = 0>
 __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (int)sizeof(T)), PPT)) void k_run_schedule(StepArgs<T> A) {
+    static_assert(NS == 0 || (NS == 25 && v_lean(TAB, REST_REG, (int)sizeof(T)) && sizeof(T) == 4 && FUSED != 3), "grid-specialised builds exist for the fp32 LEAN variants of 25x25");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int e = blockIdx.x + A.e0;
     const int tid = threadIdx.x;
@@ -87,9 +89,9 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
         sc.break_on_tear = 1; sc.active = 1; sc._pad = 0;
         sc.dz_up = sc.dx_pull = sc.dy_pull = sc.dz_pull = 0.0;
     }
-    const int P = A.P, Ppad = A.Ppad, HT = A.HT;
+    const int P = NS > 0 ? spec_p(NS) : A.P, Ppad = NS > 0 ? spec_ppad(NS) : A.Ppad, HT = NS > 0 ? spec_ht(NS) : A.HT;
     constexpr bool LEAN64 = v_lean(TAB, REST_REG, (int)sizeof(T)) && sizeof(T) == 8;
-    const LdsLayout lay((int)sizeof(T), Ppad, A.Spad, HT, TAB == 2 ? 2 : (v_ldstab(TAB) ? 1 : 0), A.cell_copy, LEAN64 ? 1 : 0);
+    const LdsLayout lay((int)sizeof(T), Ppad, KA_SPAD(&A), HT, TAB == 2 ? 2 : (v_ldstab(TAB) ? 1 : 0), KA_CELLCOPY(&A), LEAN64 ? 1 : 0);
     Pt<T> *cur = reinterpret_cast<Pt<T> *>(smem + lay.cur);
     uint32_t *hkey = reinterpret_cast<uint32_t *>(smem + lay.hkey);
     uint32_t *hco = reinterpret_cast<uint32_t *>(smem + lay.hco);
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
 #ifdef CLOTHHIP_FORCE_PM            // register-pressure bisection (dev): the phase mask as a compile-time constant
     const int pm = CLOTHHIP_FORCE_PM;
 #else
-    const int pm = A.phase_mask;
+    const int pm = NS > 0 ? (PH_HOOKE | PH_COLLIDE | PH_PLANE | PH_STRAIN) : A.phase_mask;     // (the specialised builds run every phase: debug masks take the generic build)
 #endif
 
     T pvx[PPT], pvy[PPT], pvz[PPT];         // previous positions of the owned particles
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
     uint32_t rc[RELAXED ? PPT : 1];         // RELAXED: the particle's grid position, r | c << 8 (parities of the colour classes)
     auto lean_entry = [&](int i, uint32_t vmq, int sl) -> uint32_t {      // a gather entry without its table-slot field
         const bool ok = ((vmq >> sl) & 1u) != 0u;
-        return (uint32_t)(ok ? i + lean_off(sl, A.N) : i) | (ok ? HK_VALID : 0u) | (sl < HK_SLOTS / 2 ? HK_ASB : 0u) |
+        return (uint32_t)(ok ? i + lean_off(sl, KA_N(&A)) : i) | (ok ? HK_VALID : 0u) | (sl < HK_SLOTS / 2 ? HK_ASB : 0u) |
                (lean_bend(sl) ? HK_BEND : 0u);
     };
     auto lean_rest = [&](int sl) -> T { return lean_bend(sl) ? A.pal_bend : (lean_shear(sl) ? A.pal_shear : A.pal_struct); };
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
             const bool ok = i < P;
             pvx[q] = ok ? gq[i] : (T)0; pvy[q] = ok ? gq[Ppad + i] : (T)0; pvz[q] = ok ? gq[2 * Ppad + i] : (T)0;
             if (LEAN64) { }
-            else if (LEAN) { const int r_ = i / A.N; vm[(LEAN && !LEAN64) ? q : 0] = ok ? lean_valid_mask(r_, i - r_ * A.N, A.N) : 0u; if (RELAXED) rc[RELAXED ? q : 0] = (uint32_t)r_ | ((uint32_t)(i - r_ * A.N) << 8); }
+            else if (LEAN) { const int r_ = i / KA_N(&A); vm[(LEAN && !LEAN64) ? q : 0] = ok ? lean_valid_mask(r_, i - r_ * KA_N(&A), KA_N(&A)) : 0u; if (RELAXED) rc[RELAXED ? q : 0] = (uint32_t)r_ | ((uint32_t)(i - r_ * KA_N(&A)) << 8); }
             else
 #pragma unroll
             for (int sl = 0; sl < HK_SLOTS; sl++) {
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
     auto init_lds = [&](int tear_flag, const uint32_t *s_ent, const T *s_rest) {
         if (v_ldstab(TAB) && s_ent != nullptr) {         // (nullptr: the table in LDS is intact, only the scratch behind it is rebuilt)
             WEnt<T> *d0 = reinterpret_cast<WEnt<T> *>(smem + lay.wtab);
-            for (int i = tid; i < A.Spad; i += NT) { WEnt<T> w_; w_.ab = s_ent[i]; w_.rest = s_rest[i]; d0[i] = w_; }
+            for (int i = tid; i < KA_SPAD(&A); i += NT) { WEnt<T> w_; w_.ab = s_ent[i]; w_.rest = s_rest[i]; d0[i] = w_; }
         }
         for (int h = tid; h < HT; h += NT) { hkey[h] = KEY_EMPTY; hco[h] = 0; }
         if (tid == 0) { misc[0] = tear_flag; misc[1] = 0; misc[2] = 0; misc[3] = 0; misc[4] = 0; misc[5] = 0; misc[6] = 0; misc[10] = 0x7fffffff; misc[11] = -1; misc[12] = 0; misc[13] = 0; misc[14] = 0; misc[20] = 0; misc[21] = 0; misc[22] = 0; misc[23] = 0; }
@@ -176,8 +178,8 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
     uint16_t *pslot = reinterpret_cast<uint16_t *>(smem + lay.pslot);       // TAB 2 only
     if (TAB == 2) {
         for (int i = tid; i < Ppad; i += NT) {
-            const int r_ = i / A.N;
-            const uint32_t vmi = i < P ? lean_valid_mask(r_, i - r_ * A.N, A.N) : 0u;
+            const int r_ = i / KA_N(&A);
+            const uint32_t vmi = i < P ? lean_valid_mask(r_, i - r_ * KA_N(&A), KA_N(&A)) : 0u;
 #pragma unroll
             for (int sl = 0; sl < HK_SLOTS / 2; sl++)      // the sl-th stencil position = the popcount(valid below sl)-th entry of the compacted table
                 pslot[sl * Ppad + i] = ((vmi >> sl) & 1u) ? (uint16_t)((A.gather[__popc(vmi & ((1u << sl) - 1u)) * Ppad + i] >> HK_POS_SHIFT) & HK_POS_MASK) : (uint16_t)0;

@@ -45,7 +45,7 @@
                             double *dpos = reinterpret_cast<double *>(smem + lay.wtab);
                             if (tid == 0) {
                                 side_ = mt_double(mt) > 0.5 ? 1 : 0;                             // cloth.pyx:75
-                                const int N_ = A.N;
+                                const int N_ = KA_N(&A);
                                 for (int r_ = 0; r_ < N_; r_++)
                                     for (int c_ = 0; c_ < N_; c_++) {
                                         double noise = mt_double(mt) * 0.01 - 0.005;             // :101
@@ -67,7 +67,7 @@
                                 if (i < P) { pvx[q] = (T)dpos[3 * i]; pvy[q] = (T)dpos[3 * i + 1]; pvz[q] = (T)dpos[3 * i + 2]; }
                             }
                             T *rw = F.rest_rw + (size_t)e * F.rest_stride;
-                            for (int p_ = tid; p_ < A.Spad; p_ += NT) {
+                            for (int p_ = tid; p_ < KA_SPAD(&A); p_ += NT) {
                                 const uint32_t en = F.wt_ent[p_];                                 // empty slots: ptA == ptB == 0 -> 0
                                 const double *PA = dpos + 3 * (en & WT_IDX_MASK), *PB = dpos + 3 * ((en >> WT_IDX_BITS) & WT_IDX_MASK);
                                 const double ux = PA[0] - PB[0], uy = PA[1] - PB[1], uz = PA[2] - PB[2];
@@ -171,7 +171,7 @@
                         lastz = bz; lasti = bi;
                         __syncthreads();
                     }
-                    const int pr = lasti / A.N, pc_ = lasti - pr * A.N;
+                    const int pr = lasti / KA_N(&A), pc_ = lasti - pr * KA_N(&A);
                     const Pt<T> pp = cur[lasti];
                     const double x = (double)pp.x, y = (double)pp.y;
                     double tgx, tgy;

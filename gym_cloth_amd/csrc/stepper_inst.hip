@@ -20,6 +20,10 @@ CLOTH_GROUP_4(CLOTH_DEFN)
 CLOTH_RELAXED()
 #elif CLOTHHIP_INST_GROUP == 5
 CLOTH_GROUP_5(CLOTH_DEFN)
+#elif CLOTHHIP_INST_GROUP == 6
+CLOTH_VARIANTS_SPEC25_A(CLOTH_DEFN_S25, float)
+#elif CLOTHHIP_INST_GROUP == 7
+CLOTH_VARIANTS_SPEC25_B(CLOTH_DEFN_S25, float)
 #else
 #error "unknown CLOTHHIP_INST_GROUP"
 #endif

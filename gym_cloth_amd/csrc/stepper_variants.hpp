@@ -29,6 +29,11 @@
 // the fp64 LEAN build (25x25 class, eight waves per cloth; rest lengths = palette value + per-spring ulp offset)
 #define CLOTH_VARIANTS_LEAN64(X, T) X(T, 512, 2, 0, true)
 
+// the grid-specialised builds (NS = 25: the BASELINE grid at compile time, cloth_common.hpp spec_*): the fp32 LEAN variants of the 25x25 class
+#define CLOTH_VARIANTS_SPEC25_A(X, T) X(T, 512, 2, 2, true) X(T, 256, 3, 0, true) X(T, 256, 3, -1, true)
+#define CLOTH_VARIANTS_SPEC25_B(X, T) X(T, 256, 3, -2, true) X(T, 256, 3, -3, true)
+#define CLOTH_VARIANTS_SPEC25(X, T) CLOTH_VARIANTS_SPEC25_A(X, T) CLOTH_VARIANTS_SPEC25_B(X, T)
+
 // every variant exists for FUSED = 0 (one external schedule), 1 (episodes, flat tiers), 2 (episodes incl. tier-2 resets and the cold policies)
 #define CLOTH_FUSED3(KW, T, NT, PPT, TAB, RR)                                                        \
     KW template __global__ void clothhip::k_run_schedule<T, NT, PPT, TAB, RR, 0>(clothhip::StepArgs<T>);  \
@@ -36,10 +41,16 @@
     KW template __global__ void clothhip::k_run_schedule<T, NT, PPT, TAB, RR, 2>(clothhip::StepArgs<T>);
 #define CLOTH_DECL(T, NT, PPT, TAB, RR) CLOTH_FUSED3(extern, T, NT, PPT, TAB, RR)
 #define CLOTH_DEFN(T, NT, PPT, TAB, RR) CLOTH_FUSED3(, T, NT, PPT, TAB, RR)
+#define CLOTH_FUSED3_S25(KW, T, NT, PPT, TAB, RR)                                                        \
+    KW template __global__ void clothhip::k_run_schedule<T, NT, PPT, TAB, RR, 0, 25>(clothhip::StepArgs<T>);  \
+    KW template __global__ void clothhip::k_run_schedule<T, NT, PPT, TAB, RR, 1, 25>(clothhip::StepArgs<T>);  \
+    KW template __global__ void clothhip::k_run_schedule<T, NT, PPT, TAB, RR, 2, 25>(clothhip::StepArgs<T>);
+#define CLOTH_DECL_S25(T, NT, PPT, TAB, RR) CLOTH_FUSED3_S25(extern, T, NT, PPT, TAB, RR)
+#define CLOTH_DEFN_S25(T, NT, PPT, TAB, RR) CLOTH_FUSED3_S25(, T, NT, PPT, TAB, RR)
 
 // The groups (object files). CLOTHHIP_INST_GROUPS of them; stepper_inst.hip defines group CLOTHHIP_INST_GROUP, everybody else declares.
-//   0 fp32 standard small   1 fp64 standard small   2 fp32 standard large   3 fp64 standard large   4 LEAN small (+ the relaxed-order companion)   5 LEAN large + fp64 LEAN
-#define CLOTHHIP_INST_GROUPS 6
+//   0 fp32 standard small   1 fp64 standard small   2 fp32 standard large   3 fp64 standard large   4 LEAN small (+ the relaxed-order companion)   5 LEAN large + fp64 LEAN   6, 7 the grid-specialised LEAN builds (25x25)
+#define CLOTHHIP_INST_GROUPS 8
 #define CLOTH_GROUP_0(M) CLOTH_VARIANTS_SMALL(M, float)
 #define CLOTH_GROUP_1(M) CLOTH_VARIANTS_SMALL(M, double)
 #define CLOTH_GROUP_2(M) CLOTH_VARIANTS_LARGE(M, float)
@@ -50,5 +61,6 @@
 
 #ifndef CLOTHHIP_INST_GROUP          // a user of the kernels (clothhip_api.hip): nothing is instantiated here
 CLOTH_GROUP_0(CLOTH_DECL) CLOTH_GROUP_1(CLOTH_DECL) CLOTH_GROUP_2(CLOTH_DECL) CLOTH_GROUP_3(CLOTH_DECL) CLOTH_GROUP_4(CLOTH_DECL) CLOTH_GROUP_5(CLOTH_DECL)
+CLOTH_VARIANTS_SPEC25(CLOTH_DECL_S25, float)
 CLOTH_RELAXED(extern)
 #endif

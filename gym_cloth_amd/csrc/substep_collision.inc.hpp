@@ -26,7 +26,7 @@
 #endif
                     // (ht_bits 0: a table whose size is not a power of two -- the two-per-CU layout of the large grids -- is indexed by the
                     //  high half of hash x size; which slot a cell gets never shows in the results)
-                    ch[q] = Ak_->ht_bits ? (ckey[q] * 2654435761u) >> (32 - Ak_->ht_bits) : __umulhi(ckey[q] * 2654435761u, (uint32_t)HT);
+                    ch[q] = KA_HTBITS(Ak_) ? (ckey[q] * 2654435761u) >> (32 - KA_HTBITS(Ak_)) : __umulhi(ckey[q] * 2654435761u, (uint32_t)HT);
                     pend[q] = i < P; made[q] = false; anyp |= pend[q];
                 }
                 // linear probing; the table has >= 1.5 P slots, so a free one always exists -- the probe bound only
@@ -88,7 +88,7 @@
                 cstart[q] = (int)(co >> 16);
                 if (i < P) {
                     memb[cstart[q] + (int)rank[q]] = (uint16_t)i;
-                    if (Ak_->cell_copy) cpos[cstart[q] + (int)rank[q]] = Pt<T>{cme[q].x, cme[q].y, cme[q].z, w_make<T>((uint32_t)i)};
+                    if (KA_CELLCOPY(Ak_)) cpos[cstart[q] + (int)rank[q]] = Pt<T>{cme[q].x, cme[q].y, cme[q].z, w_make<T>((uint32_t)i)};
                 }
                 const bool use = i < P && w_cnt(cme[q].w) == 0;
                 cn[q] = use ? (int)(co & 0xFFFFu) : 0;
@@ -149,7 +149,7 @@
                             const Pt<T> me_ = cur[iq_ < P ? iq_ : 0];
                             const int cs_ = cstart[q], cn_ = cn[q];
                             bool h_ = false;
-                            if (Ak_->cell_copy) {
+                            if (KA_CELLCOPY(Ak_)) {
                                 // a read past the cell's range (another cell's record or the padding behind the array) is masked out
                                 // by the member count; the trip base is clamped so that no read leaves the padded array
                                 // (round 5: four members per trip -- half the loop branches and LDS waits per member: +0.25 % at two cloths per
@@ -194,7 +194,7 @@
                         }
                     }
                 } else {
-                    if (Ak_->cell_copy) {
+                    if (KA_CELLCOPY(Ak_)) {
                         constexpr int CU = 2;
                         // a read past the cell's range (another cell's record or the padding behind the array) is masked out
                         // by the member count; the trip base is clamped so that no read leaves the padded array

@@ -155,7 +155,7 @@
                 if (misc[1] || (pm & PH_NOSKIP)) {
                     const bool all_ = (pm & PH_NOSKIP) != 0;
                     const int w0 = __builtin_amdgcn_readfirstlane(all_ ? 0 : (misc[10] >> 6));
-                    const int w1 = __builtin_amdgcn_readfirstlane(all_ ? Ak_->nW - 1 : (misc[11] >> 6));
+                    const int w1 = __builtin_amdgcn_readfirstlane(all_ ? KA_NW(Ak_) - 1 : (misc[11] >> 6));
                     const bool tic = __builtin_amdgcn_readfirstlane(!(k.tear_thresh < k.c11) ? 1 : 0) != 0;
                     const int wave_ = __builtin_amdgcn_readfirstlane(tid >> 6);
                     const int wl_ = (Ak_->Spad >> 6) - 1;                   // the table's last (padding, empty) window
@@ -163,8 +163,8 @@
 #ifdef CLOTHHIP_MW_PRIO
                     __builtin_amdgcn_s_setprio(CLOTHHIP_MW_PRIO);
 #endif
-                    const int tear = tic ? strain_sweep_mw<T, v_ldstab(TAB), NT / 64, SWEEP_STATS, true>(cur, wtab, Ak_->wt_ent, g_rest, Ak_->wt_dep, w0, w1, wl_, Ak_->wt_rshift, k, lane, wave_, sw_, st_)
-                                         : strain_sweep_mw<T, v_ldstab(TAB), NT / 64, SWEEP_STATS, false>(cur, wtab, Ak_->wt_ent, g_rest, Ak_->wt_dep, w0, w1, wl_, Ak_->wt_rshift, k, lane, wave_, sw_, st_);
+                    const int tear = tic ? strain_sweep_mw<T, v_ldstab(TAB), NT / 64, SWEEP_STATS, true>(cur, wtab, Ak_->wt_ent, g_rest, Ak_->wt_dep, w0, w1, wl_, KA_RSHIFT(Ak_), k, lane, wave_, sw_, st_)
+                                         : strain_sweep_mw<T, v_ldstab(TAB), NT / 64, SWEEP_STATS, false>(cur, wtab, Ak_->wt_ent, g_rest, Ak_->wt_dep, w0, w1, wl_, KA_RSHIFT(Ak_), k, lane, wave_, sw_, st_);
 #ifdef CLOTHHIP_MW_PRIO
                     __builtin_amdgcn_s_setprio(0);
 #endif
@@ -188,7 +188,7 @@
                 __builtin_amdgcn_s_setprio(3);            // the serial sweep is the critical path of the whole cloth
                 const bool all_ = (pm & PH_NOSKIP) != 0;
                 const int w0 = __builtin_amdgcn_readfirstlane(all_ ? 0 : (misc[10] >> 6));
-                const int w1 = __builtin_amdgcn_readfirstlane(all_ ? Ak_->nW - 1 : (misc[11] >> 6));
+                const int w1 = __builtin_amdgcn_readfirstlane(all_ ? KA_NW(Ak_) - 1 : (misc[11] >> 6));
                 if (lane == 0) misc[15]++;               // sweeps run (clothhip_debug_stats): in LDS -- as a register it was spilled, reloaded and stored by every sweep
                 // tear_thresh >= 1.1 (every shipped configuration): only a stretching spring can tear, the test sits in the commit
                 const bool tic = __builtin_amdgcn_readfirstlane(!(k.tear_thresh < k.c11) ? 1 : 0) != 0;
@@ -198,11 +198,11 @@
 #else
                 const unsigned long long fmask_ = 0ull;
 #endif
-                const int tear = tic ? (SWEEP_LEAN ? strain_sweep_lean<T, v_ldstab(TAB), SWEEP_STATS, SWEEP_AHEAD>(cur, wtab, Ak_->wt_ent, g_rest, Ak_->wt_dep, w0, w1, Ak_->wt_rshift, k,
+                const int tear = tic ? (SWEEP_LEAN ? strain_sweep_lean<T, v_ldstab(TAB), SWEEP_STATS, SWEEP_AHEAD>(cur, wtab, Ak_->wt_ent, g_rest, Ak_->wt_dep, w0, w1, KA_RSHIFT(Ak_), k,
                                                                                                   lane, st_windows, st_passes, st_commits)
-                                                   : strain_sweep<T, v_ldstab(TAB), SWEEP_TIMED, SWEEP_STATS, true>(cur, wtab, Ak_->wt_ent, g_rest, Ak_->wt_dep, w0, w1, Ak_->nW, Ak_->wt_rshift, k,
+                                                   : strain_sweep<T, v_ldstab(TAB), SWEEP_TIMED, SWEEP_STATS, true>(cur, wtab, Ak_->wt_ent, g_rest, Ak_->wt_dep, w0, w1, Ak_->nW, KA_RSHIFT(Ak_), k,
                                                                                                  lane, st_windows, st_passes, st_commits, tph, fmask_))
-                                     : strain_sweep<T, v_ldstab(TAB), SWEEP_TIMED, SWEEP_STATS, false>(cur, wtab, Ak_->wt_ent, g_rest, Ak_->wt_dep, w0, w1, Ak_->nW, Ak_->wt_rshift, k,
+                                     : strain_sweep<T, v_ldstab(TAB), SWEEP_TIMED, SWEEP_STATS, false>(cur, wtab, Ak_->wt_ent, g_rest, Ak_->wt_dep, w0, w1, Ak_->nW, KA_RSHIFT(Ak_), k,
                                                                                                   lane, st_windows, st_passes, st_commits, tph, fmask_);
                 if (__any(tear) && lane == 0) misc[0] = 1;
                 if (lane == 0) { misc[1] = 0; misc[10] = 0x7fffffff; misc[11] = -1; }

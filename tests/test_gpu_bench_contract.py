@@ -78,7 +78,7 @@ def test_bench_line_contract_small_batch():
     assert r["dispatches_per_launch"] == 1                                   # (64 cloths: one generation of workgroups per launch)
     assert (r["traffic"] is None) == (r["traffic_source"] is None)        # (64 cloths: no committed PMC record -> null, and said so)
     assert b["kind"] == "port" and b["cores"] >= 1 and b["value"] > 0 and "sample" in b and b["unit"] == "cloth-substeps/s"
-    assert "k_run_schedule<float,512,2,2,true,1>" in c["variant"]
+    assert "k_run_schedule<float,512,2,2,true,1,N25>" in c["variant"]        # the eight-wave LEAN build, specialised for the 25x25 grid
 
 
 def test_relaxed_companion_is_labelled(monkeypatch):
@@ -88,4 +88,4 @@ def test_relaxed_companion_is_labelled(monkeypatch):
     assert "true,3>" in rec["config"]["variant"] and rec["value"] > 0
     # per handle (ABI 7): a handle created next to it in the same process steps in the reference's order
     rec2 = bench.run_workload(25, 64, "f32", "tier1", "fused", 4, 2, 2, 0, 1, 0, step_ms=40.0)
-    assert rec2["config"]["exact_order"] is True and "true,1>" in rec2["config"]["variant"]
+    assert rec2["config"]["exact_order"] is True and "true,1,N25>" in rec2["config"]["variant"]
