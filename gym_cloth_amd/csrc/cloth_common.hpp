@@ -268,25 +268,28 @@ template <typename T> __device__ __forceinline__ DevConsts<T> load_consts(KArgsC
     return k;
 }
 // (in a phase's scope: shadows the kernel's `k`, `P`, `Ppad`, `HT` by freshly loaded copies)
-// Grid-specialised instantiations (round 6): k_run_schedule<..., NS> with NS = 25 knows the BASELINE grid at compile time -- particle count, padded
+// Grid-specialised instantiations (round 6): k_run_schedule<..., NS> with NS = 25 / 50 knows a BASELINE grid at compile time -- particle count, padded
 // count, hash-table size, window-table size, the whole LDS carve-up, "all phases on", whether the cell-ordered copy exists -- so none of it occupies
 // registers across the substep loop (the generic build holds ~30 loop-invariant VGPRs of LDS base addresses and constants: headline +1.9 %, the
 // six-per-CU build +3.3 %). NS = 0 is the generic build (any grid, debug phase masks). The host picks the specialised kernel only when every constant
 // below equals what it computed for the handle (clothhip_api.hip::spec_ok); the names are used inside the kernel body, where NS and TAB are in scope.
 constexpr int spec_p(int ns) { return ns * ns; }
 constexpr int spec_ppad(int ns) { return (ns * ns + 63) / 64 * 64; }
-constexpr int spec_ht(int ns) { int h = 64; while (h <= ns * ns + ns * ns / 2) h <<= 1; return h; }
-constexpr int spec_htbits(int ns) { int b = 0; while ((1 << b) < spec_ht(ns)) b++; return b; }
-constexpr int spec_nw(int ns) { return ns == 25 ? 55 : 0; }                 // windows of the strain sweep's table (cloth_tables.hpp; checked by the host)
-constexpr int spec_spad(int ns) { return ns == 25 ? 3776 : 0; }             // its slots incl. padding
-constexpr int spec_cell_copy(int tab) { return tab > -2 ? 1 : 0; }          // the LEAN layouts of the 25x25 class: no cell-ordered copy from five cloths per CU on
+// hash-table slots: the smallest power of two above 1.5 P -- except the two-cloths-per-CU layout of 50x50 (TAB 4), whose table is sized to the LDS left
+constexpr int spec_ht(int ns, int tab) { if (ns == 50 && tab == 4) return 2880; int h = 64; while (h <= ns * ns + ns * ns / 2) h <<= 1; return h; }
+constexpr int spec_htbits(int ns, int tab) { if (ns == 50 && tab == 4) return 0; int b = 0; while ((1 << b) < spec_ht(ns, tab)) b++; return b; }
+constexpr int spec_nw(int ns) { return ns == 25 ? 55 : (ns == 50 ? 227 : 0); }             // windows of the strain sweep's table (cloth_tables.hpp)
+constexpr int spec_spad(int ns) { return ns == 25 ? 3776 : (ns == 50 ? 14976 : 0); }       // its slots incl. padding
+constexpr int spec_rshift(int ns) { return ns == 50 ? 2 : 0; }                             // unit of the entries' reach field
+// the cell-ordered record copy: every specialised 25x25 layout but the LEAN builds for five / six cloths per CU has it; 50x50 at two per CU has not
+constexpr int spec_cell_copy(int ns, int tab) { return ns == 25 ? (tab > -2 ? 1 : 0) : 0; }
 #define KA_N(p_) (NS > 0 ? NS : (p_)->N)
-#define KA_HTBITS(p_) (NS > 0 ? spec_htbits(NS) : (p_)->ht_bits)
+#define KA_HTBITS(p_) (NS > 0 ? spec_htbits(NS, TAB) : (p_)->ht_bits)
 #define KA_NW(p_) (NS > 0 ? spec_nw(NS) : (p_)->nW)
 #define KA_SPAD(p_) (NS > 0 ? spec_spad(NS) : (p_)->Spad)
-#define KA_RSHIFT(p_) (NS > 0 ? 0 : (p_)->wt_rshift)
-#define KA_CELLCOPY(p_) (NS > 0 ? spec_cell_copy(TAB) : (p_)->cell_copy)
-#define CLOTH_PHASE_DIMS() const int P = NS > 0 ? spec_p(NS) : Ak_->P, Ppad = NS > 0 ? spec_ppad(NS) : Ak_->Ppad, HT = NS > 0 ? spec_ht(NS) : Ak_->HT;
+#define KA_RSHIFT(p_) (NS > 0 ? spec_rshift(NS) : (p_)->wt_rshift)
+#define KA_CELLCOPY(p_) (NS > 0 ? spec_cell_copy(NS, TAB) : (p_)->cell_copy)
+#define CLOTH_PHASE_DIMS() const int P = NS > 0 ? spec_p(NS) : Ak_->P, Ppad = NS > 0 ? spec_ppad(NS) : Ak_->Ppad, HT = NS > 0 ? spec_ht(NS, TAB) : Ak_->HT;
 #define CLOTH_PHASE_ARGS()                                                        \
     asm volatile("" : "+s"(Ak_));                                                 \
     const DevConsts<T> k = load_consts<T>(Ak_);                                   \

@@ -71,7 +71,7 @@ struct clothhip_handle {
     bool lean = false, lean_dirty = true, lean_ok = false, lean_stencil_ok = false;
     bool relaxed = false;   // clothhip_set_relaxed_order(h, 1): THIS handle's episode launches run the relaxed-order companion kernel (bench only, no parity)
     int last_dispatches = 0; // kernel dispatches the last stepper launch was issued as (clothhip_last_dispatches)
-    int spec_now = 0;        // 25: the layout in use runs the grid-specialised build (decided by lean_refresh per launch: spec_ok); 0: the generic build
+    int spec_now = 0;        // 25 / 50: the layout in use runs that grid-specialised build (decided by lean_refresh per launch: spec_ns); 0: the generic build
     int last_spec = 0;       // what the last launch ran (clothhip_last_specialised)
     int lean_r = 3;         // cloths per CU the chosen LEAN build is compiled for (3: 168 VGPRs, 4: 128 VGPRs; 2: eight waves per cloth, table in LDS; 1: the large grids)
     float pal[3] = {0, 0, 0};
@@ -216,7 +216,7 @@ static void free_handle(clothhip_handle *h) {
 }
 
 static const void *stepper_fn(const clothhip_handle *h, int fused);
-static bool spec_ok(const clothhip_handle *h);
+static int spec_ns(const clothhip_handle *h);
 
 // The LDS a layout leaves the in-kernel metrics (from the hash table to the end of the allocation) against what they need; the
 // allocation is padded behind the layout's end when that fits the budget (the kernel addresses LDS by the layout's offsets: bytes
@@ -478,7 +478,7 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
             h->nt = h->lay_lean.nt; h->ppt = h->lay_lean.ppt; h->tab = h->lay_lean.tab; h->rest_reg = h->lay_lean.rest_reg;
             h->cell_copy = h->lay_lean.cell_copy; h->HT = h->lay_lean.HT; h->ht_bits = h->lay_lean.ht_bits;
             for (int sp = 0; sp < 2; sp++) {             // the generic build of the layout and, where it exists for it, the grid-specialised one
-                h->spec_now = (sp == 1 && spec_ok(h)) ? 25 : 0;
+                h->spec_now = sp == 1 ? spec_ns(h) : 0;
                 if (sp == 1 && !h->spec_now) break;
                 for (int f = 0; f < 3; f++) {
                     const void *fl = stepper_fn(h, f);
@@ -496,6 +496,14 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
         // the attribute is per kernel function and process-global: always the CU's full 160 KiB, so that a later handle
         // with a smaller footprint can never lower it under an earlier one
         HC(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        h->spec_now = spec_ns(h);                        // the grid-specialised build of the standard layout, where one exists (tier 2 at 25x25)
+        if (h->spec_now) {
+            for (int f = 0; f < 3; f++) {
+                const void *fs = stepper_fn(h, f);
+                if (fs) HC(hipFuncSetAttribute(fs, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            }
+        }
+        h->spec_now = 0;
     }
 #undef HC
     // initial state: flat tier-1 grid for every env, shared rest table
@@ -775,20 +783,27 @@ template <typename T> static StepArgs<T> make_args(clothhip_handle *h, const Clo
 // rest table is a three-value palette (re-checked whenever the table may have changed: per-env tables, i.e. tier 2, or odd
 // rest lengths uploaded by the caller switch back), else the standard variant. LDS is rebuilt by every launch, so the layout
 // may change from one launch to the next.
-// May the layout the handle's fields describe NOW run a grid-specialised kernel (k_run_schedule<..., NS = 25>)? Only if every constant that build
-// has compiled in (cloth_common.hpp: spec_*) is what this handle computed: the 25x25 grid, its window table, the hash-table size, the LEAN fp32
-// arithmetic in one of the specialised layouts with the cell-ordered copy where the build expects it, and all phases on (debug masks take the
-// generic build, as does CLOTHHIP_DEBUG_NOSPEC=1 -- the A/B and the bit-identity test of the two).
-static bool spec_ok(const clothhip_handle *h) {
-    if (getenv("CLOTHHIP_DEBUG_NOSPEC") && atoi(getenv("CLOTHHIP_DEBUG_NOSPEC"))) return false;
-    if (h->precision != CLOTHHIP_F32 || !h->rest_reg || h->N != 25 || h->phase_mask != 15) return false;
-    if (!((h->nt == 512 && h->ppt == 2 && h->tab == 2) || (h->nt == 256 && h->ppt == 3 && h->tab <= 0 && h->tab >= -3))) return false;
-    return h->P == spec_p(25) && h->Ppad == spec_ppad(25) && h->HT == spec_ht(25) && h->ht_bits == spec_htbits(25) && h->Spad == spec_spad(25) &&
-           h->wt.nW == spec_nw(25) && h->wt.reach_shift == 0 && h->cell_copy == spec_cell_copy(h->tab);
+// Which grid-specialised kernel (k_run_schedule<..., NS>, NS = 25 or 50) may run the layout the handle's fields describe NOW -- 0: none, the generic
+// build. Only if the variant is one of the specialised ones (stepper_variants.hpp: CLOTH_SPEC_*) AND every constant that build has compiled in
+// (cloth_common.hpp: spec_*) is what this handle computed: grid, window table, hash-table size, whether the cell-ordered copy exists, all phases
+// on (debug masks take the generic build, as does CLOTHHIP_DEBUG_NOSPEC=1 -- the A/B and the bit-identity test of the two).
+static int spec_ns(const clothhip_handle *h) {
+    if (getenv("CLOTHHIP_DEBUG_NOSPEC") && atoi(getenv("CLOTHHIP_DEBUG_NOSPEC"))) return 0;
+    if (h->phase_mask != 15 || (h->N != 25 && h->N != 50)) return 0;
+    const int ns = h->N;
+    bool listed = false;
+#define XS(T_, NT, PPT, TAB, RR, NS_) \
+    if (NS_ == ns && (sizeof(T_) == 4) == (h->precision == CLOTHHIP_F32) && h->nt == NT && h->ppt == PPT && h->tab == TAB && h->rest_reg == RR) listed = true;
+    CLOTH_SPEC_F32(XS) CLOTH_SPEC_F64(XS)
+#undef XS
+    if (!listed) return 0;
+    const bool same = h->P == spec_p(ns) && h->Ppad == spec_ppad(ns) && h->HT == spec_ht(ns, h->tab) && h->ht_bits == spec_htbits(ns, h->tab) &&
+                      h->Spad == spec_spad(ns) && h->wt.nW == spec_nw(ns) && h->wt.reach_shift == spec_rshift(ns) && h->cell_copy == spec_cell_copy(ns, h->tab);
+    return same ? ns : 0;
 }
 
 static int lean_refresh(clothhip_handle *h) {
-    if (!h->lean) { h->spec_now = 0; return 0; }
+    if (!h->lean) { h->spec_now = spec_ns(h); return 0; }
     if (h->lean_dirty) {
         h->lean_dirty = false; h->lean_ok = false;
         if (h->rest_stride == 0 && h->precision == CLOTHHIP_F64) {
@@ -846,7 +861,7 @@ static int lean_refresh(clothhip_handle *h) {
     const clothhip_handle::Layout &L = (h->lean_ok && h->rest_stride == 0) ? h->lay_lean : h->lay_std;
     h->nt = L.nt; h->ppt = L.ppt; h->tab = L.tab; h->rest_reg = L.rest_reg; h->cell_copy = L.cell_copy; h->lds_bytes = L.lds_bytes;
     h->HT = L.HT; h->ht_bits = L.ht_bits;
-    h->spec_now = spec_ok(h) ? 25 : 0;
+    h->spec_now = spec_ns(h);
     return 0;
 }
 
@@ -854,13 +869,11 @@ static int lean_refresh(clothhip_handle *h) {
 template <typename T, int FUSED> static const void *stepper_fn_t(const clothhip_handle *h) {
 #define X(T_, NT, PPT, TAB, RR) \
     if (h->nt == NT && h->ppt == PPT && h->tab == TAB && h->rest_reg == RR) return (const void *)k_run_schedule<T_, NT, PPT, TAB, RR, FUSED>;
-    if constexpr (sizeof(T) == 4) {
-        if (h->spec_now == 25) {
-#define XS(T_, NT, PPT, TAB, RR) \
-            if (h->nt == NT && h->ppt == PPT && h->tab == TAB && h->rest_reg == RR) return (const void *)k_run_schedule<T_, NT, PPT, TAB, RR, FUSED, 25>;
-            CLOTH_VARIANTS_SPEC25(XS, T)
+    if (h->spec_now) {
+#define XS(T_, NT, PPT, TAB, RR, NS_) \
+        if constexpr (sizeof(T_) == sizeof(T)) { if (h->spec_now == NS_ && h->nt == NT && h->ppt == PPT && h->tab == TAB && h->rest_reg == RR) return (const void *)k_run_schedule<T, NT, PPT, TAB, RR, FUSED, NS_>; }
+        CLOTH_SPEC_F32(XS) CLOTH_SPEC_F64(XS)
 #undef XS
-        }
     }
     CLOTH_VARIANTS(X, T)
     if constexpr (sizeof(T) == 4) { CLOTH_VARIANTS_LEAN(X, T) } else { CLOTH_VARIANTS_LEAN64(X, T) }
@@ -909,10 +922,8 @@ template <typename T, int FUSED> static void launch_run(clothhip_handle *h, cons
         return;                                                                                         \
     }
 #define X(T_, NT, PPT, TAB, RR) XN(T_, NT, PPT, TAB, RR, 0)
-#define XS(T_, NT, PPT, TAB, RR) XN(T_, NT, PPT, TAB, RR, 25)
-    if constexpr (sizeof(T) == 4) {
-        if (h->spec_now == 25) { CLOTH_VARIANTS_SPEC25(XS, T) }
-    }
+#define XS(T_, NT, PPT, TAB, RR, NS_) if constexpr (sizeof(T_) == sizeof(T)) { if (h->spec_now == NS_) { XN(T, NT, PPT, TAB, RR, NS_) } }
+    if (h->spec_now) { CLOTH_SPEC_F32(XS) CLOTH_SPEC_F64(XS) }
     CLOTH_VARIANTS(X, T)
     if constexpr (sizeof(T) == 4) { CLOTH_VARIANTS_LEAN(X, T) } else { CLOTH_VARIANTS_LEAN64(X, T) }
 #undef X

@@ -60,10 +60,10 @@ constexpr int v_waves_per_eu(int NT, int TAB, bool lean, int PPT = 0) {      // 
     if (TAB == 2 || TAB == 4) return NT / 128;                   // two cloths per CU (4: the large grids, table streamed)
     return TAB < 0 ? 3 - TAB : 3;                                // TAB 0, -1, -2, -3: three, four, five, six cloths per CU
 }
-// NS: 0 = any grid (sizes from the kernel arguments); 25 = the BASELINE grid known at compile time (cloth_common.hpp: spec_*)
+// NS: 0 = any grid (sizes from the kernel arguments); 25 / 50 = a BASELINE grid known at compile time (cloth_common.hpp: spec_*)
 template <typename T, int NT, int PPT, int TAB, bool REST_REG, int FUSED, int NS = 0>
 __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (int)sizeof(T)), PPT)) void k_run_schedule(StepArgs<T> A) {
-    static_assert(NS == 0 || (NS == 25 && v_lean(TAB, REST_REG, (int)sizeof(T)) && sizeof(T) == 4 && FUSED != 3), "grid-specialised builds exist for the fp32 LEAN variants of 25x25");
+    static_assert((NS == 0 || NS == 25 || NS == 50) && (NS == 0 || FUSED != 3), "grid-specialised builds exist for 25x25 and 50x50 (stepper_variants.hpp: CLOTH_SPEC_*)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int e = blockIdx.x + A.e0;
     const int tid = threadIdx.x;
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
         sc.break_on_tear = 1; sc.active = 1; sc._pad = 0;
         sc.dz_up = sc.dx_pull = sc.dy_pull = sc.dz_pull = 0.0;
     }
-    const int P = NS > 0 ? spec_p(NS) : A.P, Ppad = NS > 0 ? spec_ppad(NS) : A.Ppad, HT = NS > 0 ? spec_ht(NS) : A.HT;
+    const int P = NS > 0 ? spec_p(NS) : A.P, Ppad = NS > 0 ? spec_ppad(NS) : A.Ppad, HT = NS > 0 ? spec_ht(NS, TAB) : A.HT;
     constexpr bool LEAN64 = v_lean(TAB, REST_REG, (int)sizeof(T)) && sizeof(T) == 8;
     const LdsLayout lay((int)sizeof(T), Ppad, KA_SPAD(&A), HT, TAB == 2 ? 2 : (v_ldstab(TAB) ? 1 : 0), KA_CELLCOPY(&A), LEAN64 ? 1 : 0);
     Pt<T> *cur = reinterpret_cast<Pt<T> *>(smem + lay.cur);

@@ -21,9 +21,13 @@ CLOTH_RELAXED()
 #elif CLOTHHIP_INST_GROUP == 5
 CLOTH_GROUP_5(CLOTH_DEFN)
 #elif CLOTHHIP_INST_GROUP == 6
-CLOTH_VARIANTS_SPEC25_A(CLOTH_DEFN_S25, float)
+CLOTH_SPEC_A(CLOTH_DEFN_S)
 #elif CLOTHHIP_INST_GROUP == 7
-CLOTH_VARIANTS_SPEC25_B(CLOTH_DEFN_S25, float)
+CLOTH_SPEC_B(CLOTH_DEFN_S)
+#elif CLOTHHIP_INST_GROUP == 8
+#ifndef CLOTHHIP_FAST_BUILD
+CLOTH_SPEC_C_F32(CLOTH_DEFN_S) CLOTH_SPEC_C_F64(CLOTH_DEFN_S)
+#endif
 #else
 #error "unknown CLOTHHIP_INST_GROUP"
 #endif

@@ -379,10 +379,10 @@ int clothhip_last_variant(clothhip_handle *h, int32_t v[10]);
  * them all). CLOTHHIP_ESTATE before the first launch. */
 int clothhip_last_dispatches(clothhip_handle *h, int32_t *n);
 
-/* (new, ABI 7) 25 when the handle's last stepper launch ran a GRID-SPECIALISED build of the variant clothhip_last_variant names -- the kernel
- * compiled with the 25x25 grid of the shipped configurations (cfg/t1_rgbd.yaml:15-16) as compile-time constants: particle count, LDS carve-up,
- * hash- and window-table sizes --, 0 for the generic build (any grid). Same arithmetic, same results bit for bit (tests/test_gpu_lean.py);
- * CLOTHHIP_DEBUG_NOSPEC=1 at launch time forces the generic build. */
+/* (new, ABI 7) 25 or 50 when the handle's last stepper launch ran a GRID-SPECIALISED build of the variant clothhip_last_variant names -- the
+ * kernel compiled with the 25x25 grid of the shipped configurations (cfg/t1_rgbd.yaml:15-16) or the 50x50 grid of BASELINE configs[4] as
+ * compile-time constants: particle count, LDS carve-up, hash- and window-table sizes --, 0 for the generic build (any grid). Same arithmetic,
+ * same results bit for bit (tests/test_gpu_lean.py, tests/test_gpu_fullsize.py); CLOTHHIP_DEBUG_NOSPEC=1 at launch time forces the generic build. */
 int clothhip_last_specialised(clothhip_handle *h, int32_t *n_side);
 
 /* (new, ABI 7; measurement only, NOT a reference path) on != 0: THIS handle's clothhip_run_actions launches run the relaxed-order

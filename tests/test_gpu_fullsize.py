@@ -69,6 +69,9 @@ def test_picked_f32_variant_is_the_benched_one_and_equals_the_standard_variant(E
         for k, v in want.items():
             assert (vp[k] >= v) if k == "cloths_per_cu" else (vp[k] == v), (k, vp)
         assert vp["fused"] == (2 if tier == "tier2" else 1) and vp["precision"] == "f32", vp
+        # (round 6) every benched fp32 handle runs the grid-specialised build of its variant; the standard-arithmetic run it is compared with
+        # below is the specialised tier-2 build at 25x25 (same variant as tier 2's pick) and a generic build at 50x50
+        assert vp["spec_n_side"] == n_side, vp
         generations = -(-E // (vp["cloths_per_cu"] * vp["n_cus"]))
         assert generations == (2 if E in (2048, 1024) else 1), (generations, vp)
     assert not vs["lean"], vs
@@ -107,6 +110,8 @@ def test_full_batch_bench_step_f64_sample_matches_oracle(E, n_side, tier, oracle
     # (round 6: the flat tiers' fp64 handle of the 25x25 class runs the fp64 LEAN build -- stencil recomputed, rest = palette bits + ulp offset --;
     #  per-env rest tables (tier 2) and the large grids keep the standard arithmetic)
     assert var["precision"] == "f64" and var["lean"] == (tier != "tier2" and n_side == 25) and (var["fused"] >= 1) == bool(env.batch.fused_supported), var
+    if var["n_cus"] == 256:
+        assert var["spec_n_side"] == (25 if var["lean"] else 0), var          # the fp64 LEAN build of 25x25 is grid-specialised, the others generic
     if var["n_cus"] == 256:
         assert var["threads"] == 512 and var["particles_per_thread"] == (2 if n_side == 25 else 5), var
     pos1, prev1, _ = env.batch.get_state()

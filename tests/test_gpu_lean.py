@@ -45,9 +45,9 @@ def test_lean_variant_is_bit_identical_to_the_standard_f32_variant(tier, build, 
         assert v["cloths_per_cu"] >= build, v                        # three / four cloths resident per CU (a build that needs fewer
                                                                      # registers than its cap may fit one more)
     assert va_f["cloths_per_cu"] == 2, va_f
-    # (round 6) a 25x25 handle runs the GRID-SPECIALISED build of its LEAN variant (the grid's sizes as compile-time constants), the standard
-    # arithmetic the generic one: the comparison below therefore also pins the specialised kernels to the generic standard variant bit for bit
-    assert vb_f["spec_n_side"] == 25 and vb_s["spec_n_side"] == 25 and va_f["spec_n_side"] == 0 and ",N25>" in vb_f["name"], (vb_f, vb_s, va_f)
+    # (round 6) a 25x25 fp32 handle runs the GRID-SPECIALISED build of its variant (the grid's sizes as compile-time constants), LEAN and
+    # standard arithmetic alike; the specialised builds are held to the generic ones by the test below
+    assert vb_f["spec_n_side"] == 25 and vb_s["spec_n_side"] == 25 and va_f["spec_n_side"] == 25 and ",N25>" in vb_f["name"], (vb_f, vb_s, va_f)
     assert a["executed"].sum() > 100000 and a["exec2"].sum() > 10000
     for k in a:
         if k == "state":
@@ -57,7 +57,7 @@ def test_lean_variant_is_bit_identical_to_the_standard_f32_variant(tier, build, 
             assert np.array_equal(a[k], b[k]), k
 
 
-@pytest.mark.parametrize("build", [8, 6])
+@pytest.mark.parametrize("build", [8, 6, 0])
 def test_grid_specialised_build_equals_the_generic_build_of_the_same_variant(build, monkeypatch):
     """CLOTHHIP_DEBUG_NOSPEC=1 makes the handle run the generic build (grid sizes from the kernel arguments) of the very same LEAN variant:
     same records, observations and particles as the specialised one, over an episode launch with resets and over the per-step path; and a
@@ -77,7 +77,7 @@ def test_grid_specialised_build_equals_the_generic_build_of_the_same_variant(bui
     monkeypatch.delenv("CLOTHHIP_DEBUG_NOSPEC", raising=False)
     monkeypatch.setenv("CLOTHHIP_DEBUG_PHASES", "31")                # all phases + "walk every window": not what the specialised build compiled in
     c, vc_f, _ = _run("tier1", build, monkeypatch, E=8, T=1)
-    assert vc_f["spec_n_side"] == 0 and vc_f["lean"], vc_f
+    assert vc_f["spec_n_side"] == 0 and vc_f["lean"] == (build != 0), vc_f
 
 
 def test_lean_handle_steps_aside_for_per_env_rest_tables(monkeypatch):
