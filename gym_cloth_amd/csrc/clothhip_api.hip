@@ -791,6 +791,16 @@ static int spec_ns(const clothhip_handle *h) {
     if (getenv("CLOTHHIP_DEBUG_NOSPEC") && atoi(getenv("CLOTHHIP_DEBUG_NOSPEC"))) return 0;
     if (h->phase_mask != 15 || (h->N != 25 && h->N != 50)) return 0;
     const int ns = h->N;
+    {   // the physics constants the build has compiled in (cloth_common.hpp: spec_phys) must be this handle's
+        const SpecPhys q = spec_phys(ns);
+        const ClothParams &p = h->prm;
+        if (p.width != q.width || p.height != q.height || p.density != q.density || p.ks != q.ks || p.damping != q.damping || p.thickness != q.thickness ||
+            p.plane_friction != q.plane_friction || p.tear_thresh != q.tear_thresh || p.gravity != q.gravity || p.minimum_z != q.minimum_z ||
+            p.frames_per_sec != q.frames_per_sec || p.simulation_steps != q.simulation_steps) return 0;
+        // (belt and braces: the literals the kernel holds are what make_consts gives the generic build, bit for bit)
+        if (h->precision == CLOTHHIP_F32) { const DevConsts<float> a = make_consts<float>(p), b = spec_consts<float>(ns); if (memcmp(&a, &b, sizeof(a)) != 0) return 0; }
+        else { const DevConsts<double> a = make_consts<double>(p), b = spec_consts<double>(ns); if (memcmp(&a, &b, sizeof(a)) != 0) return 0; }
+    }
     bool listed = false;
 #define XS(T_, NT, PPT, TAB, RR, NS_) \
     if (NS_ == ns && (sizeof(T_) == 4) == (h->precision == CLOTHHIP_F32) && h->nt == NT && h->ppt == PPT && h->tab == TAB && h->rest_reg == RR) listed = true;
