@@ -286,6 +286,13 @@ template <typename T> constexpr DevConsts<T> spec_consts(int ns) {
     k.c11 = (T)1.1;
     return k;
 }
+// the fp32 palette of the flat tiers' rest lengths at grid ns (cloth.pyx:117-146, :417: structural dx, shearing sqrt(dx^2 + dy^2), bending 2 dx,
+// rounded to float): what the LEAN arithmetic of a specialised fp32 build uses as literals; the host compares them with the palette it read
+// back from the device's rest table (spec_ns) -- a mismatch selects the generic build
+constexpr float spec_pal(int ns, int type) {
+    const double dx = 1.0 / (ns - 1);
+    return type == 0 ? (float)dx : (type == 1 ? (float)__builtin_sqrt(dx * dx + dx * dx) : (float)(2.0 * dx));
+}
 // NS > 0: the constants as LITERALS (no scalar loads at the head of every phase, no SGPRs held, constant subexpressions folded: +1 % on the
 // headline) -- all but sim_steps: the fp32 arithmetic divides by it through v_rcp_f32, which the compiler would fold to the correctly rounded
 // reciprocal, and the specialised build must stay bit-identical to the generic one (every other use of a constant is an exactly rounded operation).

@@ -216,7 +216,7 @@ static void free_handle(clothhip_handle *h) {
 }
 
 static const void *stepper_fn(const clothhip_handle *h, int fused);
-static int spec_ns(const clothhip_handle *h);
+static int spec_ns(const clothhip_handle *h, bool with_palette = true);
 
 // The LDS a layout leaves the in-kernel metrics (from the hash table to the end of the allocation) against what they need; the
 // allocation is padded behind the layout's end when that fits the budget (the kernel addresses LDS by the layout's offsets: bytes
@@ -478,7 +478,7 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
             h->nt = h->lay_lean.nt; h->ppt = h->lay_lean.ppt; h->tab = h->lay_lean.tab; h->rest_reg = h->lay_lean.rest_reg;
             h->cell_copy = h->lay_lean.cell_copy; h->HT = h->lay_lean.HT; h->ht_bits = h->lay_lean.ht_bits;
             for (int sp = 0; sp < 2; sp++) {             // the generic build of the layout and, where it exists for it, the grid-specialised one
-                h->spec_now = sp == 1 ? spec_ns(h) : 0;
+                h->spec_now = sp == 1 ? spec_ns(h, false) : 0;
                 if (sp == 1 && !h->spec_now) break;
                 for (int f = 0; f < 3; f++) {
                     const void *fl = stepper_fn(h, f);
@@ -496,7 +496,7 @@ extern "C" int clothhip_create(const ClothParams *params, int32_t n_envs, int32_
         // the attribute is per kernel function and process-global: always the CU's full 160 KiB, so that a later handle
         // with a smaller footprint can never lower it under an earlier one
         HC(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        h->spec_now = spec_ns(h);                        // the grid-specialised build of the standard layout, where one exists (tier 2 at 25x25)
+        h->spec_now = spec_ns(h, false);                 // the grid-specialised build of the standard layout, where one exists (tier 2 at 25x25)
         if (h->spec_now) {
             for (int f = 0; f < 3; f++) {
                 const void *fs = stepper_fn(h, f);
@@ -787,7 +787,8 @@ template <typename T> static StepArgs<T> make_args(clothhip_handle *h, const Clo
 // build. Only if the variant is one of the specialised ones (stepper_variants.hpp: CLOTH_SPEC_*) AND every constant that build has compiled in
 // (cloth_common.hpp: spec_*) is what this handle computed: grid, window table, hash-table size, whether the cell-ordered copy exists, all phases
 // on (debug masks take the generic build, as does CLOTHHIP_DEBUG_NOSPEC=1 -- the A/B and the bit-identity test of the two).
-static int spec_ns(const clothhip_handle *h) {
+// (with_palette false: clothhip_create, which prepares every kernel the handle may launch before any rest table has been read back)
+static int spec_ns(const clothhip_handle *h, bool with_palette) {
     if (getenv("CLOTHHIP_DEBUG_NOSPEC") && atoi(getenv("CLOTHHIP_DEBUG_NOSPEC"))) return 0;
     if (h->phase_mask != 15 || (h->N != 25 && h->N != 50)) return 0;
     const int ns = h->N;
@@ -809,7 +810,12 @@ static int spec_ns(const clothhip_handle *h) {
     if (!listed) return 0;
     const bool same = h->P == spec_p(ns) && h->Ppad == spec_ppad(ns) && h->HT == spec_ht(ns, h->tab) && h->ht_bits == spec_htbits(ns, h->tab) &&
                       h->Spad == spec_spad(ns) && h->wt.nW == spec_nw(ns) && h->wt.reach_shift == spec_rshift(ns) && h->cell_copy == spec_cell_copy(ns, h->tab);
-    return same ? ns : 0;
+    if (!same) return 0;
+    // the LEAN fp32 builds hold the rest-length palette as literals: it must be what lean_refresh read back from the device's table
+    if (with_palette && h->precision == CLOTHHIP_F32 && h->rest_reg) {
+        for (int t = 0; t < 3; t++) { const float v = spec_pal(ns, t); if (memcmp(&v, &h->pal[t], 4) != 0) return 0; }
+    }
+    return ns;
 }
 
 static int lean_refresh(clothhip_handle *h) {

@@ -137,7 +137,11 @@ __global__ __launch_bounds__(NT, v_waves_per_eu(NT, TAB, v_lean(TAB, REST_REG, (
         return (uint32_t)(ok ? i + lean_off(sl, KA_N(&A)) : i) | (ok ? HK_VALID : 0u) | (sl < HK_SLOTS / 2 ? HK_ASB : 0u) |
                (lean_bend(sl) ? HK_BEND : 0u);
     };
-    auto lean_rest = [&](int sl) -> T { return lean_bend(sl) ? A.pal_bend : (lean_shear(sl) ? A.pal_shear : A.pal_struct); };
+    auto lean_rest = [&](int sl) -> T {
+        if constexpr (NS > 0 && sizeof(T) == 4)        // (specialised fp32 builds: the palette as literals, cloth_common.hpp spec_pal -- held as kernel arguments the three
+            return (T)(lean_bend(sl) ? spec_pal(NS, 2) : (lean_shear(sl) ? spec_pal(NS, 1) : spec_pal(NS, 0)));   //  values were spilled and restored at every use)
+        else return lean_bend(sl) ? A.pal_bend : (lean_shear(sl) ? A.pal_shear : A.pal_struct);
+    };
     {   // HBM -> LDS / registers, coalesced
         const T *gp = A.pos + (size_t)e * 3 * Ppad, *gq = A.prev + (size_t)e * 3 * Ppad;
         const uint8_t *gc = A.cnt + (size_t)e * Ppad;
