@@ -13,4 +13,4 @@ cat $T/g?.log $T/api.log |
   grep -E "Function Name|Name:| VGPRs:|AGPRs:|VGPRs Spill|ScratchSize" |
   sed -E 's/^[^ ]+ remark: +//; s/ \[-Rpass.*$//' |
   awk '/Name:/ {if (line) print line; line=$NF; next} {gsub(/^ +/,""); line=line "  " $0} END {print line}' |
-  while read -r name rest; do printf "%-62s %s\n" "$(echo "$name" | c++filt | cut -c1-60)" "$rest"; done | sort
+  while read -r name rest; do printf "%-70s %s\n" "$(echo "$name" | c++filt | cut -c1-68)" "$rest"; done | sort
